@@ -1,0 +1,96 @@
+"""EfficientNet image encoder, functional torch-fp32 restatement (oracle side, CPU).
+
+Follows model/modules/efficientnet_custom.py: MBConvBlock.forward :91-132, EfficientNet.extract_features
+:262-285, EfficientNet.forward :287-313.  Parameters come from a ``state_dict``-style mapping with the
+reference's key names (``_conv_stem.weight``, ``_blocks.{i}._expand_conv.weight`` ...), so golden
+weights load into the reference with ``strict=True`` and into this function unchanged.
+
+Stochastic ops (drop_connect efficient_net_custom_utils.py:129-154, pooled-feature dropout
+efficientnet_custom.py:310-312) are only reproducible with p = 0 or in eval mode:
+``drop_connect`` / ``dropout`` must be 0.0 when ``train`` is True.
+"""
+from typing import Dict, Optional
+
+import torch
+import torch.nn.functional as F
+
+from .arch import Arch, BN_EPS, BN_MOMENTUM
+
+
+def swish(x):
+    """efficient_net_custom_utils.py:64-69 (forward of SwishImplementation)."""
+    return x * torch.sigmoid(x)
+
+
+def _bn(sd: Dict[str, torch.Tensor], p: str, x, train: bool, new_buffers: Optional[dict]):
+    """nn.BatchNorm2d(momentum=0.01, eps=1e-3): batch statistics in train mode, running stats in eval."""
+    rm, rv = sd[p + ".running_mean"], sd[p + ".running_var"]
+    if train:
+        rm, rv = rm.clone(), rv.clone()
+        y = F.batch_norm(x, rm, rv, sd[p + ".weight"], sd[p + ".bias"], True, BN_MOMENTUM, BN_EPS)
+        if new_buffers is not None:
+            new_buffers[p + ".running_mean"] = rm
+            new_buffers[p + ".running_var"] = rv
+        return y
+    return F.batch_norm(x, rm, rv, sd[p + ".weight"], sd[p + ".bias"], False, BN_MOMENTUM, BN_EPS)
+
+
+def _conv_static_same(x, w, bias, stride, pad, groups=1):
+    """Conv2dStaticSamePadding.forward, efficient_net_custom_utils.py:273-276:
+    ZeroPad2d((l, r, t, b)) then conv2d(padding=0)."""
+    if any(pad):
+        x = F.pad(x, pad)
+    return F.conv2d(x, w, bias, stride, 0, 1, groups)
+
+
+def mbconv(sd, p: str, x, blk, train: bool, new_buffers=None, taps: Optional[dict] = None):
+    """MBConvBlock.forward (efficientnet_custom.py:91-132) with drop_connect disabled."""
+    inp = x
+    if blk.expand != 1:
+        x = F.conv2d(x, sd[p + "._expand_conv.weight"])
+        if taps is not None:
+            taps[p + ".expand_out"] = x
+        x = swish(_bn(sd, p + "._bn0", x, train, new_buffers))
+    x = _conv_static_same(x, sd[p + "._depthwise_conv.weight"], None, blk.s, blk.pad, groups=blk.cexp)
+    if taps is not None:
+        taps[p + ".dw_out"] = x
+    x = swish(_bn(sd, p + "._bn1", x, train, new_buffers))
+    # squeeze & excite (:114-119)
+    sq = F.adaptive_avg_pool2d(x, 1)
+    sq = F.conv2d(sq, sd[p + "._se_reduce.weight"], sd[p + "._se_reduce.bias"])
+    sq = swish(sq)
+    sq = F.conv2d(sq, sd[p + "._se_expand.weight"], sd[p + "._se_expand.bias"])
+    x = torch.sigmoid(sq) * x
+    x = F.conv2d(x, sd[p + "._project_conv.weight"])
+    if taps is not None:
+        taps[p + ".project_out"] = x
+    x = _bn(sd, p + "._bn2", x, train, new_buffers)
+    if blk.skip:
+        x = x + inp
+    return x
+
+
+def extract_features(sd, x, arch: Arch, train: bool, prefix: str = "", new_buffers=None,
+                     taps: Optional[dict] = None):
+    """EfficientNet.extract_features (efficientnet_custom.py:262-285)."""
+    p = prefix
+    x = _conv_static_same(x, sd[p + "_conv_stem.weight"], None, 2, arch.stem_pad)
+    x = swish(_bn(sd, p + "_bn0", x, train, new_buffers))
+    if taps is not None:
+        taps["stem"] = x
+    for blk in arch.blocks:
+        x = mbconv(sd, f"{p}_blocks.{blk.idx}", x, blk, train, new_buffers, taps)
+        if taps is not None:
+            taps[f"block{blk.idx}"] = x
+    x = F.conv2d(x, sd[p + "_conv_head.weight"])
+    x = swish(_bn(sd, p + "_bn1", x, train, new_buffers))
+    return x
+
+
+def forward(sd, x, arch: Arch, train: bool, prefix: str = "", new_buffers=None, taps=None,
+            return_map: bool = False):
+    """EfficientNet.forward (efficientnet_custom.py:287-313): features -> global avg pool -> flatten
+    (-> dropout, identity here).  Returns [b, head_out]."""
+    fmap = extract_features(sd, x, arch, train, prefix, new_buffers, taps)
+    pooled = F.adaptive_avg_pool2d(fmap, 1).flatten(1)
+    return (pooled, fmap) if return_map else pooled
