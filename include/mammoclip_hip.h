@@ -1,0 +1,234 @@
+/*
+ * mammoclip_hip.h -- C ABI of libmammoclip_hip.so: hand-written gfx950 (MI355X / CDNA4) kernels for the
+ * Mammo-CLIP image<->text contrastive pre-training hot path.
+ *
+ * The reference (batmanlab/Mammo-CLIP) has no FFI of its own: its hot path bottoms out in torch
+ * operators (conv2d / batch_norm / linear / matmul / cross_entropy ...).  Every entry point below
+ * replaces one such operator call-site (or a fused group of them) and cites it as
+ *   [ref: <file>:<lines>]  relative to  src/codebase/breastclip/ .
+ * The host-side mirror of the reference's Python API (build_model / build_loss / BreastClip ...) lives in
+ * mammo-clip_amd/breastclip/ and binds these symbols with ctypes.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; all pointers are DEVICE pointers unless stated otherwise
+ *   - bf16 tensors are raw uint16 bit patterns; activations are row-major [rows, channels] (NHWC),
+ *     channels % 8 == 0, base pointers 16-byte aligned
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); calls are asynchronous
+ *   - return 0 on success, non-zero on error; mc_last_error() gives the message (thread-local)
+ *   - no hidden allocation: workspaces / partial buffers are caller-provided
+ */
+#ifndef MAMMOCLIP_HIP_H
+#define MAMMOCLIP_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef uint16_t mc_bf16;
+
+const char* mc_last_error(void);
+int mc_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * bf16 MFMA GEMM:  C[M,N] (+)= alpha * op(A)[M,K] . op(B)[K,N] + bias[N]  -> act -> + R
+ * [ref: model/modules/efficientnet_custom.py:104,122,283 (1x1 convs _expand_conv/_project_conv/_conv_head),
+ *       model/modules/text_encoder.py:48 (BertModel linears and attention matmuls),
+ *       and their autograd backward (dgrad: b_kmajor, wgrad: a_kmajor+b_kmajor+split-K atomics)]
+ * a_kmajor = 0: A[m*lda + k]   1: A[k*lda + m]        b_kmajor = 0: B[n*ldb + k]   1: B[k*ldb + n]
+ * batch index z -> (b1, b2) = (z / nb2, z % nb2); operand offsets b1*s?1 + b2*s?2 (elements).
+ * Prologue (fused BN + SiLU (+ SE gate) on the streamed operand, [ref: efficientnet_custom.py:110-119]):
+ *   pro_operand 1 = A (k-contiguous: row = pixel, k = channel), 2 = B (k-major: k = pixel, n = channel)
+ *   v' = silu(v*pro_scale[c] + pro_shift[c]) * pro_gate[(pixel / pro_rows_per_img) * pro_nch + c]
+ * stat_partials (optional, bf16 output only): float[rows][2][N] with rows = mc_gemm_stat_rows();
+ *   row r holds the column sums / sums of squares of the C rows handled by workgroup-row r.
+ */
+typedef struct mc_gemm_args {
+    const mc_bf16* A;
+    const mc_bf16* B;
+    void* C;
+    long long M, K;
+    int N;
+    long long lda, ldb, ldc;
+    int a_kmajor, b_kmajor;
+    int c_f32, c_atomic;
+    int splits;
+    int batch, nb2;
+    long long sA1, sA2, sB1, sB2, sC1, sC2;
+    const float* bias;
+    long long bias_stride1;
+    int act;                 /* 0 none, 1 erf-GELU */
+    const mc_bf16* R;
+    long long ldr;
+    float alpha;             /* 0 is read as 1 */
+    int pro_operand;
+    const float* pro_scale;
+    const float* pro_shift;
+    const float* pro_gate;
+    long long pro_rows_per_img;
+    int pro_nch;
+    float* stat_partials;
+    int max_grid_m;          /* 0 = default */
+} mc_gemm_args;
+int mc_gemm_bf16(const mc_gemm_args* args, void* stream);
+int mc_gemm_stat_rows(const mc_gemm_args* args);
+
+/* ------------------------------------------------------------------------------------------------
+ * small helpers */
+int mc_cast_f32_bf16(const float* src, mc_bf16* dst, long long n, void* stream);
+int mc_cast_bf16_f32(const mc_bf16* src, float* dst, long long n, void* stream);
+int mc_transpose_f32(const float* src, float* dst, int rows, int cols, void* stream); /* dst[c][r] = src[r][c] */
+/* stem weight [C0,3,3,3] fp32 (OIHW) -> bf16 [C0,32], k = cin*9 + kh*3 + kw, zero padded 27..31 */
+int mc_stem_weight_prep(const float* w, mc_bf16* out, int c0, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * stem im2col: fp32 image batch with arbitrary element strides (NCHW or the trainer's permuted NHWC
+ * view, [ref: trainer_ddp.py:288-291]) -> bf16 patches [n*oh*ow, 32] for the 3x3 stride-2 stem conv
+ * with static padding (pad_l, pad_t) [ref: efficientnet_custom.py:273, efficient_net_custom_utils.py:248-276] */
+int mc_stem_im2col(const float* x, long long sn, long long sc, long long sh, long long sw,
+                   int n, int h, int w, int pad_l, int pad_t, int oh, int ow, mc_bf16* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * depthwise k x k convolution, NHWC bf16, static asymmetric zero padding
+ * [ref: efficientnet_custom.py:109 (_depthwise_conv) + :110-111 (_bn1 statistics), :105-107 fused as
+ *  prologue: x' = silu(x*pro_scale[c] + pro_shift[c]) applied to in-range inputs only]
+ * w_kkc: fp32 [k*k][C] (tap-major).  stat_partials: float[mc_dwconv_stat_rows()][2][C] (optional). */
+typedef struct mc_dwconv_args {
+    const mc_bf16* x;        /* [n,h,w,c] */
+    const mc_bf16* dy;       /* [n,oh,ow,c]  (backward only) */
+    void* out;               /* fwd: y bf16 [n,oh,ow,c]; bwd_data: dx bf16 [n,h,w,c]; bwd_weight: dw f32 [k*k][c] (+=) */
+    const float* w_kkc;
+    int n, h, w, c;
+    int k, stride, pad_l, pad_t, oh, ow;
+    const float* pro_scale;
+    const float* pro_shift;
+    float* stat_partials;
+} mc_dwconv_args;
+int mc_dwconv_stat_rows(const mc_dwconv_args* args);
+int mc_dwconv_fwd(const mc_dwconv_args* args, void* stream);
+int mc_dwconv_bwd_data(const mc_dwconv_args* args, void* stream);
+int mc_dwconv_bwd_weight(const mc_dwconv_args* args, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * training-mode BatchNorm pieces [ref: efficientnet_custom.py:64,74,88,177,205; momentum 0.01, eps 1e-3]
+ * finalize: partials float[rows][2][C] (sum, sum of squares) -> mean, invstd, scale = gamma*invstd,
+ * shift = beta - mean*scale; running stats updated with the unbiased variance when update_running. */
+int mc_bn_finalize(const float* partials, int rows, int c, double count, const float* gamma,
+                   const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                   int update_running, float* mean, float* invstd, float* scale, float* shift, void* stream);
+/* eval mode: scale/shift from running statistics */
+int mc_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,
+                      const float* running_var, float eps, int c, float* scale, float* shift, void* stream);
+
+/* elementwise family on x[n_img * hw, c] (bf16):  z = x*scale[c] + shift[c];  y = act(z)  (act 0 none, 1 SiLU)
+ * apply:  out = y * rowscale[img] + res            (rowscale = drop_connect keep/keep_prob, res = skip input)
+ *         [ref: efficientnet_custom.py:123-131, efficient_net_custom_utils.py:129-154]
+ * pool:   pooled[img, c] = mean_hw y               [ref: efficientnet_custom.py:115 (SE squeeze), :307 (_avg_pooling)] */
+typedef struct mc_bnact_args {
+    const mc_bf16* x;
+    long long n_img, hw;
+    int c;
+    const float* scale;
+    const float* shift;
+    int act;
+    /* apply */
+    const float* rowscale;   /* [n_img] or NULL */
+    const mc_bf16* res;      /* or NULL */
+    mc_bf16* out;
+    /* pool */
+    float* pooled;           /* [n_img, c] */
+    /* backward: upstream gradient of y is  g*mul[img,c] + add[img,c]  (any of the three may be NULL;
+     * g NULL = 0, mul NULL = 1, add NULL = 0), then dz = that * act'(z) * rowscale[img] */
+    const mc_bf16* g;
+    const float* mul;
+    const float* add;
+    const float* mean;
+    const float* invstd;
+    float* partials;         /* bwd_reduce: float[mc_bnact_rows()][2][c] = (sum dz, sum dz*xhat) */
+    const float* coef;       /* bwd_apply: float[3][c] from mc_bn_bwd_finalize: dx = A*dz + B*x + C */
+    mc_bf16* dx;
+    float* dgate;            /* se_dgate: [n_img, c] = sum_hw g * act(z) */
+} mc_bnact_args;
+int mc_bnact_rows(const mc_bnact_args* args);
+int mc_bnact_apply(const mc_bnact_args* args, void* stream);
+int mc_bnact_pool(const mc_bnact_args* args, void* stream);
+int mc_bnact_bwd_reduce(const mc_bnact_args* args, void* stream);
+int mc_bnact_bwd_apply(const mc_bnact_args* args, void* stream);
+int mc_bnact_se_dgate(const mc_bnact_args* args, void* stream);
+/* dgamma = sum dz*xhat, dbeta = sum dz; coef[0..2][c] for bwd_apply */
+int mc_bn_bwd_finalize(const float* partials, int rows, int c, double count, const float* gamma,
+                       const float* mean, const float* invstd, float* dgamma, float* dbeta, float* coef,
+                       void* stream);
+
+/* column sums of a bf16 matrix: out[c] = sum_m x[m, c]  (bias gradients).  partials: float[rows][c] */
+int mc_colsum_rows(long long m, int c);
+int mc_colsum_bf16(const mc_bf16* x, long long m, int c, long long ld, float* partials, float* out,
+                   int accumulate, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * squeeze-excite MLP on pooled features [ref: efficientnet_custom.py:114-119]
+ *   r = silu(w1 . pooled + b1);  gate = sigmoid(w2 . r + b2);  w1 [cs, c], w2 [c, cs] fp32 */
+int mc_se_fwd(const float* pooled, const float* w1, const float* b1, const float* w2, const float* b2,
+              int n, int c, int cs, float* gate, void* stream);
+/* ws: float[n * (c + 2*cs)] scratch; dw*, db* are accumulated (+=) */
+int mc_se_bwd(const float* pooled, const float* gate, const float* dgate, const float* w1, const float* b1,
+              const float* w2, const float* b2, int n, int c, int cs, float* dpooled, float* dw1, float* db1,
+              float* dw2, float* db2, float* ws, void* stream);
+
+/* dropout on fp32 vectors (pooled image features [ref: efficientnet_custom.py:310-312]); y = x * mask/(1-p),
+ * mask = philox(seed, stream_id, index): calling it on the gradient with the same ids is the backward. */
+int mc_dropout_f32(const float* x, float* y, long long n, float p, unsigned long long seed,
+                   unsigned int stream_id, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * BERT pieces [ref: model/modules/text_encoder.py:47-49 -> transformers BertModel] */
+/* embeddings: y = dropout(LN(word[ids] + pos[t] + type[tt]))  -> bf16 [b*t, h]; saves mean/rstd */
+int mc_bert_embed_fwd(const long long* ids, const long long* tt, const float* word, const float* pos,
+                      const float* type, const float* gamma, const float* beta, float eps, int b, int t,
+                      int h, float p, unsigned long long seed, unsigned int stream_id, mc_bf16* y,
+                      float* mean, float* rstd, void* stream);
+int mc_bert_embed_bwd(const mc_bf16* dy, const long long* ids, const long long* tt, const float* word,
+                      const float* pos, const float* type, const float* gamma, const float* mean,
+                      const float* rstd, int b, int t, int h, float p, unsigned long long seed,
+                      unsigned int stream_id, float* dword, float* dpos, float* dtype, float* dgamma,
+                      float* dbeta, void* stream);    /* all outputs accumulated (+=) */
+/* y = LN(dropout(x) + res) ; rows x h */
+int mc_add_ln_fwd(const mc_bf16* x, const mc_bf16* res, const float* gamma, const float* beta, float eps,
+                  long long rows, int h, float p, unsigned long long seed, unsigned int stream_id,
+                  mc_bf16* y, float* mean, float* rstd, void* stream);
+/* dx = dropout-masked grad wrt x, dres = grad wrt res (pre-LN sum grad); dgamma/dbeta accumulated (+=) */
+int mc_add_ln_bwd(const mc_bf16* dy, const mc_bf16* x, const mc_bf16* res, const float* gamma,
+                  const float* mean, const float* rstd, long long rows, int h, float p,
+                  unsigned long long seed, unsigned int stream_id, mc_bf16* dx, mc_bf16* dres,
+                  float* dgamma, float* dbeta, void* stream);
+/* row softmax of fp32 scores [rows, t] -> probs (bf16) and dropped probs (bf16; may alias probs when p == 0) */
+int mc_softmax_fwd(const float* scores, long long rows, int t, float p, unsigned long long seed,
+                   unsigned int stream_id, mc_bf16* probs, mc_bf16* probs_drop, void* stream);
+/* dscores = probs * (dp - sum(probs*dp)) * alpha with dp = dprobs_drop * mask/(1-p); bf16 out */
+int mc_softmax_bwd(const mc_bf16* probs, const float* dprobs_drop, long long rows, int t, float p,
+                   unsigned long long seed, unsigned int stream_id, float alpha, mc_bf16* dscores, void* stream);
+int mc_gelu_fwd(const mc_bf16* x, mc_bf16* y, long long n, void* stream);
+int mc_gelu_bwd(const mc_bf16* dy, const mc_bf16* x, mc_bf16* dx, long long n, void* stream);
+/* mask bias for attention: out[b, t] = (1 - mask[b,t]) * -3.0e38-ish (finfo.min)  */
+int mc_mask_bias(const long long* mask, float* out, long long n, void* stream);
+/* eos pooling [ref: model/clip.py:65-68]: out[b, :] = h[b, sum(mask[b]) - 1, :]  (bf16 -> fp32) */
+int mc_eos_gather(const mc_bf16* hid, const long long* mask, int b, int t, int h, float* out, void* stream);
+int mc_eos_scatter(const float* dout, const long long* mask, int b, int t, int h, mc_bf16* dhid, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * fp32 small GEMM with arbitrary strides: C[m,n] = alpha * sum_k A[m*ars + k*acs] * B[k*brs + n*bcs] + beta*C + bias[n]
+ * [ref: model/modules/projection.py:23-29 (LinearProjectionHead); loss/breast_clip.py:46-100 (logits)] */
+int mc_sgemm(const float* a, long long ars, long long acs, const float* b, long long brs, long long bcs,
+             float* c, long long ldc, int m, int n, int k, float alpha, float beta, const float* bias,
+             void* stream);
+/* y = x / ||x||_2 per row (no epsilon) [ref: model/clip.py:90-91]; bwd: dx = (dy - y*(y.dy)) / ||x|| */
+int mc_l2norm_fwd(const float* x, int rows, int d, float* y, float* norm, void* stream);
+int mc_l2norm_bwd(const float* dy, const float* y, const float* norm, int rows, int d, float* dx, void* stream);
+/* mean cross-entropy over rows of logits [rows, n] with labels row + label_offset, weight w:
+ * loss_out[0] += w * mean_r (lse_r - logit[r, label]);  dlogits = w/rows * (softmax - onehot)  (in place)
+ * [ref: loss/breast_clip.py:50-100 (F.cross_entropy with labels + rank*batch)] */
+int mc_ce_fwd_bwd(float* logits, int rows, int n, int label_offset, float w, float* loss_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

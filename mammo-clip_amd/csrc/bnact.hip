@@ -1,0 +1,481 @@
+// Training-mode BatchNorm + SiLU family on NHWC bf16 tensors x[n_img*hw, c], and the squeeze-excite MLP.
+// [ref: efficientnet_custom.py:64-88 (BatchNorm2d momentum 0.01 eps 1e-3), :104-131 (MBConvBlock.forward),
+//       efficient_net_custom_utils.py:64-80 (SwishImplementation fwd/bwd), :129-154 (drop_connect)]
+// All kernels are HBM-bound streaming passes: 16-byte (8-channel) vector accesses, per-channel parameters
+// in registers, reductions leave as small partial buffers finished by a tiny finalize kernel (fp64 sums).
+#include "common.cuh"
+#include "../../include/mammoclip_hip.h"
+
+namespace {
+
+struct RowMap {
+    int cv, cvp, rpb, rl, cl;
+    __device__ RowMap(int c) {
+        cv = c / 8;
+        cvp = cv < 256 ? cv : 256;
+        rpb = 256 / cvp;
+        rl = threadIdx.x / cvp;
+        cl = threadIdx.x % cvp;
+    }
+};
+
+__global__ void bn_finalize_k(const float* __restrict__ partials, int rows, int c, double count,
+                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                              float* __restrict__ rmean, float* __restrict__ rvar, float momentum, float eps,
+                              int update, float* __restrict__ mean, float* __restrict__ invstd,
+                              float* __restrict__ scale, float* __restrict__ shift) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= c) return;
+    double s = 0.0, s2 = 0.0;
+    for (int r = 0; r < rows; ++r) {
+        s += (double)partials[((long long)r * 2) * c + i];
+        s2 += (double)partials[((long long)r * 2 + 1) * c + i];
+    }
+    double m = s / count;
+    double var = s2 / count - m * m;
+    if (var < 0.0) var = 0.0;
+    float is = (float)(1.0 / sqrt(var + (double)eps));
+    mean[i] = (float)m;
+    invstd[i] = is;
+    float sc = gamma[i] * is;
+    scale[i] = sc;
+    shift[i] = beta[i] - (float)m * sc;
+    if (update) {
+        double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+        rmean[i] = (1.f - momentum) * rmean[i] + momentum * (float)m;
+        rvar[i] = (1.f - momentum) * rvar[i] + momentum * (float)unbiased;
+    }
+}
+
+__global__ void bn_eval_coeffs_k(const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
+                                 int c, float* scale, float* shift) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= c) return;
+    float sc = gamma[i] / sqrtf(rv[i] + eps);
+    scale[i] = sc;
+    shift[i] = beta[i] - rm[i] * sc;
+}
+
+__global__ __launch_bounds__(256) void bnact_apply_k(const mc_bnact_args p) {
+    const int cvn = p.c / 8;
+    const long long total = p.n_img * p.hw * cvn;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        int cv = (int)(i % cvn);
+        long long pix = i / cvn;
+        float f[8], s[8], t[8];
+        unpack8(*reinterpret_cast<const uint4*>(p.x + pix * p.c + cv * 8), f);
+        load8f(p.scale + cv * 8, s);
+        load8f(p.shift + cv * 8, t);
+        float rs = p.rowscale ? p.rowscale[pix / p.hw] : 1.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            float z = f[q] * s[q] + t[q];
+            f[q] = (p.act == 1 ? silu_f(z) : z) * rs;
+        }
+        if (p.res) {
+            float r[8];
+            unpack8(*reinterpret_cast<const uint4*>(p.res + pix * p.c + cv * 8), r);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) f[q] += r[q];
+        }
+        *reinterpret_cast<uint4*>(p.out + pix * p.c + cv * 8) = pack8(f);
+    }
+}
+
+// per-image reductions over hw: MODE 0 = pool (mean of act(z)), MODE 1 = SE dgate (sum g*act(z))
+template <int MODE>
+__global__ __launch_bounds__(256) void bnact_img_reduce_k(const mc_bnact_args p) {
+    RowMap rm(p.c);
+    __shared__ float red[256 * 8];
+    const long long img = blockIdx.x;
+    const bf16_t* xb = p.x + img * p.hw * p.c;
+    const bf16_t* gb = (MODE == 1) ? p.g + img * p.hw * p.c : nullptr;
+    float* dst = (MODE == 0 ? p.pooled : p.dgate) + img * p.c;
+    const float post = (MODE == 0) ? 1.0f / (float)p.hw : 1.0f;
+    for (int cbase = 0; cbase < rm.cv; cbase += rm.cvp) {
+        int v = cbase + rm.cl;
+        float acc[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc[q] = 0.f;
+        if (rm.rl < rm.rpb && v < rm.cv) {
+            float s[8], t[8];
+            load8f(p.scale + v * 8, s);
+            load8f(p.shift + v * 8, t);
+            for (long long r = (long long)blockIdx.y * rm.rpb + rm.rl; r < p.hw; r += (long long)gridDim.y * rm.rpb) {
+                float f[8];
+                unpack8(*reinterpret_cast<const uint4*>(xb + r * p.c + v * 8), f);
+                if (MODE == 0) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        float z = f[q] * s[q] + t[q];
+                        acc[q] += (p.act == 1 ? silu_f(z) : z);
+                    }
+                } else {
+                    float g[8];
+                    unpack8(*reinterpret_cast<const uint4*>(gb + r * p.c + v * 8), g);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        float z = f[q] * s[q] + t[q];
+                        acc[q] += g[q] * (p.act == 1 ? silu_f(z) : z);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) red[threadIdx.x * 8 + q] = acc[q];
+        __syncthreads();
+        if (rm.rl == 0 && v < rm.cv) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                float s = 0.f;
+                for (int r = 0; r < rm.rpb; ++r) s += red[(r * rm.cvp + rm.cl) * 8 + q];
+                if (gridDim.y == 1) dst[v * 8 + q] = s * post;
+                else atomicAdd(dst + v * 8 + q, s * post);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__device__ __forceinline__ void bwd_dz8(const mc_bnact_args& p, long long pix, int c8, const float* x,
+                                        const float* s, const float* t, float* dz) {
+    float up[8];
+    if (p.g) unpack8(*reinterpret_cast<const uint4*>(p.g + pix * p.c + c8), up);
+    else {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) up[q] = 0.f;
+    }
+    long long img = 0;
+    if (p.mul || p.add || p.rowscale) img = pix / p.hw;
+    if (p.mul) {
+        float m[8];
+        load8f(p.mul + img * p.c + c8, m);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) up[q] *= m[q];
+    }
+    if (p.add) {
+        float a[8];
+        load8f(p.add + img * p.c + c8, a);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) up[q] += a[q];
+    }
+    float rs = p.rowscale ? p.rowscale[img] : 1.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        float d = up[q] * rs;
+        if (p.act == 1) d *= silu_grad_f(x[q] * s[q] + t[q]);
+        dz[q] = d;
+    }
+}
+
+__global__ __launch_bounds__(256) void bnact_bwd_reduce_k(const mc_bnact_args p) {
+    RowMap rm(p.c);
+    __shared__ float red[256 * 16];
+    const long long rows = p.n_img * p.hw;
+    for (int cbase = 0; cbase < rm.cv; cbase += rm.cvp) {
+        int v = cbase + rm.cl;
+        float a0[8], a1[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { a0[q] = 0.f; a1[q] = 0.f; }
+        if (rm.rl < rm.rpb && v < rm.cv) {
+            float s[8], t[8], mu[8], is[8];
+            load8f(p.scale + v * 8, s);
+            load8f(p.shift + v * 8, t);
+            load8f(p.mean + v * 8, mu);
+            load8f(p.invstd + v * 8, is);
+            for (long long r = (long long)blockIdx.x * rm.rpb + rm.rl; r < rows; r += (long long)gridDim.x * rm.rpb) {
+                float x[8], dz[8];
+                unpack8(*reinterpret_cast<const uint4*>(p.x + r * p.c + v * 8), x);
+                bwd_dz8(p, r, v * 8, x, s, t, dz);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    a0[q] += dz[q];
+                    a1[q] += dz[q] * (x[q] - mu[q]) * is[q];
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { red[threadIdx.x * 16 + q] = a0[q]; red[threadIdx.x * 16 + 8 + q] = a1[q]; }
+        __syncthreads();
+        if (rm.rl == 0 && v < rm.cv) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                float sm = 0.f;
+                for (int r = 0; r < rm.rpb; ++r) sm += red[(r * rm.cvp + rm.cl) * 16 + q];
+                p.partials[((long long)blockIdx.x * 2 + (q >> 3)) * p.c + v * 8 + (q & 7)] = sm;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void bnact_bwd_apply_k(const mc_bnact_args p) {
+    const int cvn = p.c / 8;
+    const long long total = p.n_img * p.hw * cvn;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        int cv = (int)(i % cvn);
+        long long pix = i / cvn;
+        float x[8], s[8], t[8], dz[8], A[8], B[8], Cc[8];
+        unpack8(*reinterpret_cast<const uint4*>(p.x + pix * p.c + cv * 8), x);
+        load8f(p.scale + cv * 8, s);
+        load8f(p.shift + cv * 8, t);
+        bwd_dz8(p, pix, cv * 8, x, s, t, dz);
+        load8f(p.coef + cv * 8, A);
+        load8f(p.coef + p.c + cv * 8, B);
+        load8f(p.coef + 2 * p.c + cv * 8, Cc);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) dz[q] = A[q] * dz[q] + B[q] * x[q] + Cc[q];
+        *reinterpret_cast<uint4*>(p.dx + pix * p.c + cv * 8) = pack8(dz);
+    }
+}
+
+__global__ void bn_bwd_finalize_k(const float* __restrict__ partials, int rows, int c, double count,
+                                  const float* __restrict__ gamma, const float* __restrict__ mean,
+                                  const float* __restrict__ invstd, float* __restrict__ dgamma,
+                                  float* __restrict__ dbeta, float* __restrict__ coef) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= c) return;
+    double s0 = 0.0, s1 = 0.0;
+    for (int r = 0; r < rows; ++r) {
+        s0 += (double)partials[((long long)r * 2) * c + i];
+        s1 += (double)partials[((long long)r * 2 + 1) * c + i];
+    }
+    dbeta[i] = (float)s0;
+    dgamma[i] = (float)s1;
+    double gi = (double)gamma[i] * (double)invstd[i];
+    coef[i] = (float)gi;
+    coef[c + i] = (float)(-gi * (double)invstd[i] * s1 / count);
+    coef[2 * c + i] = (float)(gi * ((double)invstd[i] * s1 * (double)mean[i] - s0) / count);
+}
+
+// ---------------------------------------------------------------- squeeze-excite MLP
+__global__ __launch_bounds__(256) void se_fwd_k(const float* __restrict__ pooled, const float* __restrict__ w1,
+                                                const float* __restrict__ b1, const float* __restrict__ w2,
+                                                const float* __restrict__ b2, int c, int cs, float* __restrict__ gate) {
+    extern __shared__ float sh[];                      // r[cs]
+    const int img = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* pv = pooled + (long long)img * c;
+    for (int j = wave; j < cs; j += 4) {
+        float s = 0.f;
+        for (int i = lane; i < c; i += 64) s += w1[(long long)j * c + i] * pv[i];
+        s = wave_sum(s);
+        if (lane == 0) sh[j] = silu_f(s + b1[j]);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < c; i += 256) {
+        float s = b2[i];
+        for (int j = 0; j < cs; ++j) s += w2[(long long)i * cs + j] * sh[j];
+        gate[(long long)img * c + i] = sigmoid_f(s);
+    }
+}
+
+// per image: ds = dgate*gate*(1-gate); r, du; dpooled.  ws layout per image: ds[c] | r[cs] | du[cs]
+__global__ __launch_bounds__(256) void se_bwd_k(const float* __restrict__ pooled, const float* __restrict__ gate,
+                                                const float* __restrict__ dgate, const float* __restrict__ w1,
+                                                const float* __restrict__ b1, const float* __restrict__ w2, int c,
+                                                int cs, float* __restrict__ dpooled, float* __restrict__ ws) {
+    extern __shared__ float sh[];                      // ds[c] | u[cs] | du[cs]
+    float* ds = sh;
+    float* u = sh + c;
+    float* du = u + cs;
+    const int img = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* pv = pooled + (long long)img * c;
+    float* wsi = ws + (long long)img * (c + 2 * cs);
+    for (int i = threadIdx.x; i < c; i += 256) {
+        float g = gate[(long long)img * c + i];
+        float d = dgate[(long long)img * c + i] * g * (1.f - g);
+        ds[i] = d;
+        wsi[i] = d;
+    }
+    for (int j = wave; j < cs; j += 4) {
+        float s = 0.f;
+        for (int i = lane; i < c; i += 64) s += w1[(long long)j * c + i] * pv[i];
+        s = wave_sum(s);
+        if (lane == 0) u[j] = s + b1[j];
+    }
+    __syncthreads();
+    for (int j = wave; j < cs; j += 4) {
+        float s = 0.f;
+        for (int i = lane; i < c; i += 64) s += w2[(long long)i * cs + j] * ds[i];
+        s = wave_sum(s);
+        if (lane == 0) {
+            float d = s * silu_grad_f(u[j]);
+            du[j] = d;
+            wsi[c + j] = silu_f(u[j]);
+            wsi[c + cs + j] = d;
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < c; i += 256) {
+        float s = 0.f;
+        for (int j = 0; j < cs; ++j) s += w1[(long long)j * c + i] * du[j];
+        dpooled[(long long)img * c + i] = s;
+    }
+}
+
+// weight / bias gradients, reduced over the n images (no atomics)
+__global__ void se_wgrad_k(const float* __restrict__ pooled, const float* __restrict__ ws, int n, int c, int cs,
+                           float* __restrict__ dw1, float* __restrict__ db1, float* __restrict__ dw2,
+                           float* __restrict__ db2) {
+    const long long stride = c + 2 * cs;
+    long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long n1 = (long long)c * cs;
+    if (e < n1) {                       // dw2[ci, j] += sum_n ds[n,ci] * r[n,j]
+        int ci = (int)(e / cs), j = (int)(e % cs);
+        float s = 0.f;
+        for (int i = 0; i < n; ++i) s += ws[i * stride + ci] * ws[i * stride + c + j];
+        dw2[e] += s;
+    } else if (e < 2 * n1) {            // dw1[j, ci] += sum_n du[n,j] * pooled[n,ci]
+        long long e2 = e - n1;
+        int j = (int)(e2 / c), ci = (int)(e2 % c);
+        float s = 0.f;
+        for (int i = 0; i < n; ++i) s += ws[i * stride + c + cs + j] * pooled[(long long)i * c + ci];
+        dw1[e2] += s;
+    } else if (e < 2 * n1 + c) {
+        int ci = (int)(e - 2 * n1);
+        float s = 0.f;
+        for (int i = 0; i < n; ++i) s += ws[i * stride + ci];
+        db2[ci] += s;
+    } else if (e < 2 * n1 + c + cs) {
+        int j = (int)(e - 2 * n1 - c);
+        float s = 0.f;
+        for (int i = 0; i < n; ++i) s += ws[i * stride + c + cs + j];
+        db1[j] += s;
+    }
+}
+
+int check_bnact(const mc_bnact_args& p) {
+    MC_CHECK(p.x && p.scale && p.shift, "bnact: null x/scale/shift");
+    MC_CHECK(p.n_img > 0 && p.hw > 0 && p.c > 0 && p.c % 8 == 0, "bnact: bad shape (c % 8 == 0 required)");
+    MC_CHECK(mc_aligned16(p.x), "bnact: x must be 16-byte aligned");
+    return MC_OK;
+}
+int stream_blocks(long long total_vec) {
+    long long b = (total_vec + 255) / 256;
+    if (b > 8192) b = 8192;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+}  // namespace
+
+extern "C" int mc_bn_finalize(const float* partials, int rows, int c, double count, const float* gamma,
+                              const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                              int update_running, float* mean, float* invstd, float* scale, float* shift, void* stream) {
+    MC_CHECK(partials && gamma && beta && mean && invstd && scale && shift && rows > 0 && c > 0 && count > 0, "bn_finalize: bad args");
+    MC_CHECK(!update_running || (running_mean && running_var), "bn_finalize: running buffers missing");
+    hipLaunchKernelGGL(bn_finalize_k, dim3(mc_div_up(c, 128)), dim3(128), 0, (hipStream_t)stream, partials, rows, c, count,
+                       gamma, beta, running_mean, running_var, momentum, eps, update_running, mean, invstd, scale, shift);
+    MC_LAUNCH_CHECK();
+    return MC_OK;
+}
+extern "C" int mc_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,
+                                 const float* running_var, float eps, int c, float* scale, float* shift, void* stream) {
+    MC_CHECK(gamma && beta && running_mean && running_var && scale && shift && c > 0, "bn_eval_coeffs: bad args");
+    hipLaunchKernelGGL(bn_eval_coeffs_k, dim3(mc_div_up(c, 128)), dim3(128), 0, (hipStream_t)stream, gamma, beta,
+                       running_mean, running_var, eps, c, scale, shift);
+    MC_LAUNCH_CHECK();
+    return MC_OK;
+}
+extern "C" int mc_bnact_rows(const mc_bnact_args* a) {
+    int cv = a->c / 8;
+    int cvp = cv < 256 ? cv : 256;
+    int rpb = 256 / (cvp > 0 ? cvp : 1);
+    long long rows = a->n_img * a->hw;
+    long long b = (rows + (long long)rpb * 32 - 1) / ((long long)rpb * 32);
+    if (b < 1) b = 1;
+    if (b > 1024) b = 1024;
+    return (int)b;
+}
+extern "C" int mc_bnact_apply(const mc_bnact_args* a, void* stream) {
+    const mc_bnact_args& p = *a;
+    if (int e = check_bnact(p)) return e;
+    MC_CHECK(p.out, "bnact_apply: null out");
+    hipLaunchKernelGGL(bnact_apply_k, dim3(stream_blocks(p.n_img * p.hw * (p.c / 8))), dim3(256), 0, (hipStream_t)stream, p);
+    MC_LAUNCH_CHECK();
+    return MC_OK;
+}
+static int img_splits(const mc_bnact_args& p) {
+    int cv = p.c / 8;
+    int cvp = cv < 256 ? cv : 256;
+    int rpb = 256 / cvp;
+    long long per = (p.hw + (long long)rpb * 64 - 1) / ((long long)rpb * 64);
+    long long want = 2048 / (p.n_img > 0 ? p.n_img : 1);
+    if (want < 1) want = 1;
+    long long s = per < want ? per : want;
+    if (s < 1) s = 1;
+    return (int)s;
+}
+extern "C" int mc_bnact_pool(const mc_bnact_args* a, void* stream) {
+    const mc_bnact_args& p = *a;
+    if (int e = check_bnact(p)) return e;
+    MC_CHECK(p.pooled, "bnact_pool: null pooled");
+    int sp = img_splits(p);
+    if (sp > 1) {
+        hipError_t e = hipMemsetAsync(p.pooled, 0, sizeof(float) * p.n_img * p.c, (hipStream_t)stream);
+        MC_CHECK(e == hipSuccess, "bnact_pool: memset failed");
+    }
+    hipLaunchKernelGGL((bnact_img_reduce_k<0>), dim3((unsigned)p.n_img, sp), dim3(256), 0, (hipStream_t)stream, p);
+    MC_LAUNCH_CHECK();
+    return MC_OK;
+}
+extern "C" int mc_bnact_se_dgate(const mc_bnact_args* a, void* stream) {
+    const mc_bnact_args& p = *a;
+    if (int e = check_bnact(p)) return e;
+    MC_CHECK(p.g && p.dgate, "bnact_se_dgate: null g/dgate");
+    int sp = img_splits(p);
+    if (sp > 1) {
+        hipError_t e = hipMemsetAsync(p.dgate, 0, sizeof(float) * p.n_img * p.c, (hipStream_t)stream);
+        MC_CHECK(e == hipSuccess, "bnact_se_dgate: memset failed");
+    }
+    hipLaunchKernelGGL((bnact_img_reduce_k<1>), dim3((unsigned)p.n_img, sp), dim3(256), 0, (hipStream_t)stream, p);
+    MC_LAUNCH_CHECK();
+    return MC_OK;
+}
+extern "C" int mc_bnact_bwd_reduce(const mc_bnact_args* a, void* stream) {
+    const mc_bnact_args& p = *a;
+    if (int e = check_bnact(p)) return e;
+    MC_CHECK(p.partials && p.mean && p.invstd, "bnact_bwd_reduce: null partials/mean/invstd");
+    hipLaunchKernelGGL(bnact_bwd_reduce_k, dim3(mc_bnact_rows(a)), dim3(256), 0, (hipStream_t)stream, p);
+    MC_LAUNCH_CHECK();
+    return MC_OK;
+}
+extern "C" int mc_bnact_bwd_apply(const mc_bnact_args* a, void* stream) {
+    const mc_bnact_args& p = *a;
+    if (int e = check_bnact(p)) return e;
+    MC_CHECK(p.coef && p.dx, "bnact_bwd_apply: null coef/dx");
+    hipLaunchKernelGGL(bnact_bwd_apply_k, dim3(stream_blocks(p.n_img * p.hw * (p.c / 8))), dim3(256), 0, (hipStream_t)stream, p);
+    MC_LAUNCH_CHECK();
+    return MC_OK;
+}
+extern "C" int mc_bn_bwd_finalize(const float* partials, int rows, int c, double count, const float* gamma,
+                                  const float* mean, const float* invstd, float* dgamma, float* dbeta, float* coef,
+                                  void* stream) {
+    MC_CHECK(partials && gamma && mean && invstd && dgamma && dbeta && coef && rows > 0 && c > 0, "bn_bwd_finalize: bad args");
+    hipLaunchKernelGGL(bn_bwd_finalize_k, dim3(mc_div_up(c, 128)), dim3(128), 0, (hipStream_t)stream, partials, rows, c,
+                       count, gamma, mean, invstd, dgamma, dbeta, coef);
+    MC_LAUNCH_CHECK();
+    return MC_OK;
+}
+extern "C" int mc_se_fwd(const float* pooled, const float* w1, const float* b1, const float* w2, const float* b2, int n,
+                         int c, int cs, float* gate, void* stream) {
+    MC_CHECK(pooled && w1 && b1 && w2 && b2 && gate && n > 0 && c > 0 && cs > 0, "se_fwd: bad args");
+    hipLaunchKernelGGL(se_fwd_k, dim3(n), dim3(256), cs * sizeof(float), (hipStream_t)stream, pooled, w1, b1, w2, b2, c, cs, gate);
+    MC_LAUNCH_CHECK();
+    return MC_OK;
+}
+extern "C" int mc_se_bwd(const float* pooled, const float* gate, const float* dgate, const float* w1, const float* b1,
+                         const float* w2, const float* b2, int n, int c, int cs, float* dpooled, float* dw1, float* db1,
+                         float* dw2, float* db2, float* ws, void* stream) {
+    MC_CHECK(pooled && gate && dgate && w1 && b1 && w2 && dpooled && dw1 && db1 && dw2 && db2 && ws, "se_bwd: null arg");
+    MC_CHECK(n > 0 && c > 0 && cs > 0, "se_bwd: bad shape");
+    (void)b2;
+    hipLaunchKernelGGL(se_bwd_k, dim3(n), dim3(256), (c + 2 * cs) * sizeof(float), (hipStream_t)stream, pooled, gate, dgate,
+                       w1, b1, w2, c, cs, dpooled, ws);
+    MC_LAUNCH_CHECK();
+    long long total = 2LL * c * cs + c + cs;
+    hipLaunchKernelGGL(se_wgrad_k, dim3(mc_div_up(total, 256)), dim3(256), 0, (hipStream_t)stream, pooled, ws, n, c, cs, dw1,
+                       db1, dw2, db2);
+    MC_LAUNCH_CHECK();
+    return MC_OK;
+}

@@ -1,0 +1,120 @@
+// Shared device helpers for the gfx950 (MI355X / CDNA4) kernels of the Mammo-CLIP hot path.
+// wave = 64 lanes; activations are bf16 (raw uint16 bits) in NHWC / row-major [rows, channels]
+// layout with channels % 8 == 0, so every access is a 16-byte vector of 8 channels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef unsigned short bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+#define MC_OK 0
+#define MC_ERR_ARG 1
+#define MC_ERR_LAUNCH 2
+
+extern "C" void mc_set_error(const char* msg);   // api_util.hip
+
+#define MC_CHECK(cond, msg)                     \
+    do {                                        \
+        if (!(cond)) {                          \
+            mc_set_error(msg);                  \
+            return MC_ERR_ARG;                  \
+        }                                       \
+    } while (0)
+
+#define MC_LAUNCH_CHECK()                                     \
+    do {                                                      \
+        hipError_t e__ = hipGetLastError();                   \
+        if (e__ != hipSuccess) {                              \
+            mc_set_error(hipGetErrorString(e__));             \
+            return MC_ERR_LAUNCH;                             \
+        }                                                     \
+    } while (0)
+
+__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+__device__ __forceinline__ float bf_lo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+
+// round-to-nearest-even, NaN preserved (same rounding as torch's float -> bfloat16)
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)0x7fc0;
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
+    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+__device__ __forceinline__ void unpack8(const uint4& v, float* f) {
+    f[0] = bf_lo(v.x); f[1] = bf_hi(v.x); f[2] = bf_lo(v.y); f[3] = bf_hi(v.y);
+    f[4] = bf_lo(v.z); f[5] = bf_hi(v.z); f[6] = bf_lo(v.w); f[7] = bf_hi(v.w);
+}
+__device__ __forceinline__ uint4 pack8(const float* f) {
+    uint4 v;
+    v.x = pack_bf2(f[0], f[1]); v.y = pack_bf2(f[2], f[3]);
+    v.z = pack_bf2(f[4], f[5]); v.w = pack_bf2(f[6], f[7]);
+    return v;
+}
+__device__ __forceinline__ void load8f(const float* p, float* f) {   // p 16-byte aligned
+    float4 a = *reinterpret_cast<const float4*>(p);
+    float4 b = *reinterpret_cast<const float4*>(p + 4);
+    f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+}
+
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float silu_f(float x) { return x * sigmoid_f(x); }
+// d silu(z)/dz = s(1 + z(1-s))  (efficient_net_custom_utils.py:71-75)
+__device__ __forceinline__ float silu_grad_f(float z) {
+    float s = sigmoid_f(z);
+    return s * (1.0f + z * (1.0f - s));
+}
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+    float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+    float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// ---- Philox4x32-10 counter-based RNG: dropout masks are a pure function of (seed, stream, index),
+// so the backward pass (and a re-forward) regenerates them instead of storing them.
+__device__ __forceinline__ uint4 philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                            uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return make_uint4(c0, c1, c2, c3);
+}
+// 8 keep/scale factors for the 8 consecutive elements starting at element index idx8*8
+__device__ __forceinline__ void dropout_scale8(unsigned long long seed, uint32_t stream,
+                                               unsigned long long idx8, float p, float* s) {
+    float inv = 1.0f / (1.0f - p);
+    uint32_t thr = (uint32_t)(p * 65536.0f);
+    uint4 r = philox4x32((uint32_t)idx8, (uint32_t)(idx8 >> 32), stream, 0x5bd1e995u,
+                         (uint32_t)seed, (uint32_t)(seed >> 32));
+    uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        s[2 * i] = ((w[i] & 0xffffu) >= thr) ? inv : 0.0f;
+        s[2 * i + 1] = ((w[i] >> 16) >= thr) ? inv : 0.0f;
+    }
+}
+
+static inline int mc_div_up(long long a, long long b) { return (int)((a + b - 1) / b); }
+static inline bool mc_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }

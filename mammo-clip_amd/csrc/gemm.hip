@@ -1,0 +1,420 @@
+// bf16 MFMA GEMM family for gfx950: C[M,N] (+)= alpha * op(A)[M,K] . op(B)[K,N]  (+bias, act, residual)
+//
+// One kernel template covers every matmul-shaped op on the hot path:
+//   * pointwise (1x1) convolutions in NHWC = GEMM over pixels  (efficientnet_custom.py:104,122,283)
+//   * their dgrad (B k-major = weight used un-transposed) and wgrad (A and B k-major, reduction over
+//     pixels, split-K with fp32 atomics)
+//   * BERT linears / attention matmuls (batched over (batch, head) with strides; no transposes)
+// Operands are staged global -> registers -> LDS (zero-filled out of range, optional fused
+// BN+SiLU(+SE gate) prologue on the streamed operand), fragments are read with ds_read_b128 and fed
+// to v_mfma_f32_16x16x32_bf16; 4 waves per workgroup, double-buffered LDS, one barrier per K tile.
+// The epilogue goes back through LDS so global stores are 16-byte row segments, and can emit
+// per-column sum / sum-of-squares partials (training-mode BatchNorm statistics of the conv output).
+#include "common.cuh"
+#include "../../include/mammoclip_hip.h"
+
+namespace {
+
+template <int BK> struct LdsCfg {
+    static constexpr int ROW_BYTES = BK * 2 + 16;   // padded row: conflict-light ds_read_b128
+};
+
+struct Frag {
+    uint4 v;
+};
+
+__device__ __forceinline__ uint4 zero4() { return make_uint4(0u, 0u, 0u, 0u); }
+
+// fused prologue on a vector of 8 channels [ch0, ch0+8) of pixel `pix`:
+//   v' = silu(v * scale[c] + shift[c]) * gate[(pix / rows_per_img) * nch + c]
+__device__ __forceinline__ uint4 apply_prologue(uint4 v, const mc_gemm_args& p, long long pix, int ch0) {
+    float f[8], s[8], t[8];
+    unpack8(v, f);
+    load8f(p.pro_scale + ch0, s);
+    load8f(p.pro_shift + ch0, t);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f[i] = silu_f(f[i] * s[i] + t[i]);
+    if (p.pro_gate) {
+        long long img = pix / p.pro_rows_per_img;
+        float g[8];
+        load8f(p.pro_gate + img * p.pro_nch + ch0, g);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) f[i] *= g[i];
+    }
+    return pack8(f);
+}
+
+template <int BM, int BN, int BK, int WGM, int WGN>
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(const mc_gemm_args p) {
+    constexpr int ROWB = LdsCfg<BK>::ROW_BYTES;
+    constexpr int WM = BM / WGM, WN = BN / WGN;
+    constexpr int FM = WM / 16, FN = WN / 16;
+    constexpr int KCH = BK / 8;                       // 16-byte chunks per row (k-contiguous mode)
+    constexpr int A_CH = (BM * KCH + 255) / 256;      // chunks per thread, k-contiguous A
+    constexpr int B_CH = (BN * KCH + 255) / 256;
+    constexpr int KP = BK / 2;                        // k pairs per tile (k-major mode)
+    constexpr int A_CHT = (KP * (BM / 8) + 255) / 256;
+    constexpr int B_CHT = (KP * (BN / 8) + 255) / 256;
+    constexpr int A_REGS = (A_CH > 2 * A_CHT) ? A_CH : 2 * A_CHT;
+    constexpr int B_REGS = (B_CH > 2 * B_CHT) ? B_CH : 2 * B_CHT;
+    constexpr int STAGE_BYTES = (BM + BN) * ROWB;
+    constexpr int CROW = (BN + 8) * 2;                // epilogue tile row bytes (bf16)
+    constexpr int EPI_BYTES = BM * CROW;
+    constexpr int LDS_BYTES = (2 * STAGE_BYTES > EPI_BYTES) ? 2 * STAGE_BYTES : EPI_BYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int n0 = blockIdx.x * BN;
+
+    // batch / split decomposition of blockIdx.z
+    const int split = blockIdx.z % p.splits;
+    const int bz = blockIdx.z / p.splits;
+    const int b1 = bz / p.nb2, b2 = bz % p.nb2;
+    const bf16_t* __restrict__ A = p.A + b1 * p.sA1 + b2 * p.sA2;
+    const bf16_t* __restrict__ B = p.B + b1 * p.sB1 + b2 * p.sB2;
+    const long long coff = b1 * p.sC1 + b2 * p.sC2;
+    const float* bias = p.bias ? p.bias + (long long)b1 * p.bias_stride1 : nullptr;
+
+    // K range of this split (multiples of BK)
+    const long long ktiles = (p.K + BK - 1) / BK;
+    const long long tps = (ktiles + p.splits - 1) / p.splits;
+    const long long kbeg = (long long)split * tps * BK;
+    long long kend = kbeg + tps * BK;
+    if (kend > p.K) kend = p.K;
+
+    const long long mtiles = (p.M + BM - 1) / BM;
+
+    float colsum[8], colsq[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { colsum[i] = 0.f; colsq[i] = 0.f; }
+
+    for (long long mt = blockIdx.y; mt < mtiles; mt += gridDim.y) {
+        const long long m0 = mt * BM;
+        f32x4_t acc[FM][FN];
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+        uint4 ra[A_REGS], rb[B_REGS];
+
+        auto load_tiles = [&](long long k0) {
+            // ---------------- A ----------------
+            if (!p.a_kmajor) {
+#pragma unroll
+                for (int i = 0; i < A_CH; ++i) {
+                    int c = tid + i * 256;
+                    int row = c / KCH, kc = c % KCH;
+                    long long m = m0 + row, k = k0 + kc * 8;
+                    uint4 v = zero4();
+                    if (c < BM * KCH && m < p.M && k < kend) {
+                        v = *reinterpret_cast<const uint4*>(A + m * p.lda + k);
+                        if (p.pro_operand == 1) v = apply_prologue(v, p, m, (int)k);
+                    }
+                    ra[i] = v;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < A_CHT; ++i) {
+                    int c = tid + i * 256;
+                    int xc = c % (BM / 8), kp = c / (BM / 8);
+                    long long m = m0 + xc * 8, k = k0 + 2 * kp;
+                    uint4 v0 = zero4(), v1 = zero4();
+                    if (c < KP * (BM / 8) && m < p.M) {
+                        if (k < kend) v0 = *reinterpret_cast<const uint4*>(A + k * p.lda + m);
+                        if (k + 1 < kend) v1 = *reinterpret_cast<const uint4*>(A + (k + 1) * p.lda + m);
+                    }
+                    ra[2 * i] = v0; ra[2 * i + 1] = v1;
+                }
+            }
+            // ---------------- B ----------------
+            if (!p.b_kmajor) {
+#pragma unroll
+                for (int i = 0; i < B_CH; ++i) {
+                    int c = tid + i * 256;
+                    int row = c / KCH, kc = c % KCH;
+                    long long n = n0 + row, k = k0 + kc * 8;
+                    uint4 v = zero4();
+                    if (c < BN * KCH && n < p.N && k < kend)
+                        v = *reinterpret_cast<const uint4*>(B + n * p.ldb + k);
+                    rb[i] = v;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < B_CHT; ++i) {
+                    int c = tid + i * 256;
+                    int xc = c % (BN / 8), kp = c / (BN / 8);
+                    long long n = n0 + xc * 8, k = k0 + 2 * kp;
+                    uint4 v0 = zero4(), v1 = zero4();
+                    if (c < KP * (BN / 8) && n < p.N) {
+                        if (k < kend) {
+                            v0 = *reinterpret_cast<const uint4*>(B + k * p.ldb + n);
+                            if (p.pro_operand == 2) v0 = apply_prologue(v0, p, k, (int)n);
+                        }
+                        if (k + 1 < kend) {
+                            v1 = *reinterpret_cast<const uint4*>(B + (k + 1) * p.ldb + n);
+                            if (p.pro_operand == 2) v1 = apply_prologue(v1, p, k + 1, (int)n);
+                        }
+                    }
+                    rb[2 * i] = v0; rb[2 * i + 1] = v1;
+                }
+            }
+        };
+
+        // k-major operands are transposed on the way into LDS: thread holds rows k, k+1 for 8
+        // consecutive x; it writes 8 dwords {x_j: (k, k+1)}.  The 16-byte slot index inside the row is
+        // XOR-swizzled with (x >> 3) & 7 so the 32-lane write groups (same k-pair, 16 x-chunks) do not
+        // pile onto one bank; the fragment reader applies the same XOR.
+        auto store_tiles = [&](int buf) {
+            unsigned char* sA = smem + buf * STAGE_BYTES;
+            unsigned char* sB = sA + BM * ROWB;
+            if (!p.a_kmajor) {
+#pragma unroll
+                for (int i = 0; i < A_CH; ++i) {
+                    int c = tid + i * 256;
+                    if (c < BM * KCH) {
+                        int row = c / KCH, kc = c % KCH;
+                        *reinterpret_cast<uint4*>(sA + row * ROWB + kc * 16) = ra[i];
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < A_CHT; ++i) {
+                    int c = tid + i * 256;
+                    if (c < KP * (BM / 8)) {
+                        int xc = c % (BM / 8), kp = c / (BM / 8);
+                        const uint32_t* w0 = reinterpret_cast<const uint32_t*>(&ra[2 * i]);
+                        const uint32_t* w1 = reinterpret_cast<const uint32_t*>(&ra[2 * i + 1]);
+                        int slot = ((kp >> 2) ^ (xc & 7)) & (KCH - 1);
+                        int boff = slot * 16 + (kp & 3) * 4;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            uint32_t a = w0[j >> 1], b = w1[j >> 1];
+                            uint32_t d = (j & 1) ? ((a >> 16) | (b & 0xffff0000u)) : ((a & 0xffffu) | (b << 16));
+                            *reinterpret_cast<uint32_t*>(sA + (xc * 8 + j) * ROWB + boff) = d;
+                        }
+                    }
+                }
+            }
+            if (!p.b_kmajor) {
+#pragma unroll
+                for (int i = 0; i < B_CH; ++i) {
+                    int c = tid + i * 256;
+                    if (c < BN * KCH) {
+                        int row = c / KCH, kc = c % KCH;
+                        *reinterpret_cast<uint4*>(sB + row * ROWB + kc * 16) = rb[i];
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < B_CHT; ++i) {
+                    int c = tid + i * 256;
+                    if (c < KP * (BN / 8)) {
+                        int xc = c % (BN / 8), kp = c / (BN / 8);
+                        const uint32_t* w0 = reinterpret_cast<const uint32_t*>(&rb[2 * i]);
+                        const uint32_t* w1 = reinterpret_cast<const uint32_t*>(&rb[2 * i + 1]);
+                        int slot = ((kp >> 2) ^ (xc & 7)) & (KCH - 1);
+                        int boff = slot * 16 + (kp & 3) * 4;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            uint32_t a = w0[j >> 1], b = w1[j >> 1];
+                            uint32_t d = (j & 1) ? ((a >> 16) | (b & 0xffff0000u)) : ((a & 0xffffu) | (b << 16));
+                            *reinterpret_cast<uint32_t*>(sB + (xc * 8 + j) * ROWB + boff) = d;
+                        }
+                    }
+                }
+            }
+        };
+
+        auto compute = [&](int buf) {
+            const unsigned char* sA = smem + buf * STAGE_BYTES;
+            const unsigned char* sB = sA + BM * ROWB;
+#pragma unroll
+            for (int kk = 0; kk < BK / 32; ++kk) {
+                bf16x8_t af[FM], bfr[FN];
+                const int slot = kk * 4 + (lane >> 4);
+#pragma unroll
+                for (int i = 0; i < FM; ++i) {
+                    int row = wm * WM + i * 16 + (lane & 15);
+                    int s = p.a_kmajor ? ((slot ^ ((row >> 3) & 7)) & (KCH - 1)) : slot;
+                    af[i] = *reinterpret_cast<const bf16x8_t*>(sA + row * ROWB + s * 16);
+                }
+#pragma unroll
+                for (int j = 0; j < FN; ++j) {
+                    int row = wn * WN + j * 16 + (lane & 15);
+                    int s = p.b_kmajor ? ((slot ^ ((row >> 3) & 7)) & (KCH - 1)) : slot;
+                    bfr[j] = *reinterpret_cast<const bf16x8_t*>(sB + row * ROWB + s * 16);
+                }
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < FN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            }
+        };
+
+        // ---------------- main loop ----------------
+        if (kbeg < kend) {
+            load_tiles(kbeg);
+            int buf = 0;
+            for (long long k0 = kbeg; k0 < kend; k0 += BK) {
+                store_tiles(buf);
+                __syncthreads();
+                if (k0 + BK < kend) load_tiles(k0 + BK);
+                compute(buf);
+                buf ^= 1;
+            }
+        }
+        __syncthreads();   // all fragment reads done before smem is reused by the epilogue
+
+        // ---------------- epilogue ----------------
+        const float alpha = p.alpha;
+        if (p.c_f32) {
+            float* C = reinterpret_cast<float*>(p.C) + coff;
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j) {
+                    int n = n0 + wn * WN + j * 16 + (lane & 15);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        long long m = m0 + wm * WM + i * 16 + (lane >> 4) * 4 + r;
+                        if (m < p.M && n < p.N) {
+                            float v = acc[i][j][r] * alpha;
+                            if (bias && split == 0) v += bias[n];
+                            if (p.c_atomic) atomicAdd(C + m * p.ldc + n, v);
+                            else C[m * p.ldc + n] = v;
+                        }
+                    }
+                }
+        } else {
+            // registers -> LDS tile (bf16 of alpha*acc kept in fp32 until bias/act? no: bias/act are
+            // applied on the fp32 value here, then rounded once)
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j) {
+                    int col = wn * WN + j * 16 + (lane & 15);
+                    int n = n0 + col;
+                    float bv = (bias && n < p.N) ? bias[n] : 0.f;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        int row = wm * WM + i * 16 + (lane >> 4) * 4 + r;
+                        float v = acc[i][j][r] * alpha + bv;
+                        if (p.act == 1) v = gelu_f(v);
+                        *reinterpret_cast<bf16_t*>(smem + row * CROW + col * 2) = f2bf(v);
+                    }
+                }
+            __syncthreads();
+            bf16_t* C = reinterpret_cast<bf16_t*>(p.C) + coff;
+            constexpr int CPR = BN / 8;                 // 16-byte chunks per tile row
+            constexpr int RPP = 256 / CPR;              // rows per pass
+            const int cc = tid % CPR, r0 = tid / CPR;
+            const int n = n0 + cc * 8;
+            if (n < p.N) {
+                for (int row = r0; row < BM; row += RPP) {
+                    long long m = m0 + row;
+                    if (m >= p.M) break;
+                    uint4 v = *reinterpret_cast<const uint4*>(smem + row * CROW + cc * 16);
+                    if (p.R) {
+                        float f[8], g[8];
+                        unpack8(v, f);
+                        uint4 rv = *reinterpret_cast<const uint4*>(p.R + coff + m * p.ldr + n);
+                        unpack8(rv, g);
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) f[q] += g[q];
+                        v = pack8(f);
+                    }
+                    if (p.stat_partials) {
+                        float f[8];
+                        unpack8(v, f);
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) { colsum[q] += f[q]; colsq[q] += f[q] * f[q]; }
+                    }
+                    *reinterpret_cast<uint4*>(C + m * p.ldc + n) = v;
+                }
+            }
+            __syncthreads();
+        }
+    }
+
+    // ---------------- column statistics partials ----------------
+    if (p.stat_partials) {
+        constexpr int CPR = BN / 8;
+        constexpr int RPP = 256 / CPR;
+        float* red = reinterpret_cast<float*>(smem);     // [RPP][BN][2]
+        const int cc = tid % CPR, r0 = tid / CPR;
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            red[(r0 * BN + cc * 8 + q) * 2 + 0] = colsum[q];
+            red[(r0 * BN + cc * 8 + q) * 2 + 1] = colsq[q];
+        }
+        __syncthreads();
+        for (int c = tid; c < BN; c += 256) {
+            float s = 0.f, s2 = 0.f;
+            for (int r = 0; r < RPP; ++r) { s += red[(r * BN + c) * 2]; s2 += red[(r * BN + c) * 2 + 1]; }
+            int n = n0 + c;
+            if (n < p.N) {
+                float* dst = p.stat_partials + (long long)blockIdx.y * 2 * p.N;
+                dst[n] = s;
+                dst[p.N + n] = s2;
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int BK, int WGM, int WGN>
+int launch(const mc_gemm_args& p, int grid_m, hipStream_t st) {
+    dim3 grid(mc_div_up(p.N, BN), grid_m, p.batch * p.splits);
+    hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, BK, WGM, WGN>), grid, dim3(256), 0, st, p);
+    MC_LAUNCH_CHECK();
+    return MC_OK;
+}
+
+}  // namespace
+
+extern "C" int mc_gemm_stat_rows(const mc_gemm_args* a) {
+    // number of partial rows the launch will write ( = gridDim.y )
+    long long mtiles = (a->M + 127) / 128;
+    long long cap = a->max_grid_m > 0 ? a->max_grid_m : 512;
+    return (int)(mtiles < cap ? mtiles : cap);
+}
+
+extern "C" int mc_gemm_bf16(const mc_gemm_args* a, void* stream) {
+    mc_gemm_args p = *a;
+    MC_CHECK(p.A && p.B && p.C, "gemm: null operand");
+    MC_CHECK(p.M > 0 && p.N > 0 && p.K > 0, "gemm: empty problem");
+    MC_CHECK(mc_aligned16(p.A) && mc_aligned16(p.B) && mc_aligned16(p.C), "gemm: operands must be 16-byte aligned");
+    MC_CHECK(p.lda % 8 == 0 && p.ldb % 8 == 0, "gemm: lda/ldb must be multiples of 8 elements");
+    MC_CHECK(p.c_f32 || p.ldc % 8 == 0, "gemm: ldc must be a multiple of 8 for bf16 output");
+    MC_CHECK((p.a_kmajor ? p.M : p.K) % 8 == 0, "gemm: contiguous extent of A must be a multiple of 8");
+    MC_CHECK((p.b_kmajor ? p.N : p.K) % 8 == 0, "gemm: contiguous extent of B must be a multiple of 8");
+    MC_CHECK(p.c_f32 || p.N % 8 == 0, "gemm: N must be a multiple of 8 for bf16 output");
+    if (p.batch <= 0) p.batch = 1;
+    if (p.nb2 <= 0) p.nb2 = 1;
+    if (p.splits <= 0) p.splits = 1;
+    MC_CHECK(p.splits == 1 || (p.c_f32 && p.c_atomic), "gemm: split-K needs fp32 atomic output");
+    MC_CHECK(!(p.stat_partials && (p.c_f32 || p.batch != 1 || p.splits != 1)), "gemm: stats need plain bf16 output");
+    MC_CHECK(p.pro_operand == 0 || (p.pro_scale && p.pro_shift), "gemm: prologue needs scale/shift");
+    MC_CHECK(p.pro_operand != 1 || !p.a_kmajor, "gemm: A prologue needs k-contiguous A");
+    MC_CHECK(p.pro_operand != 2 || p.b_kmajor, "gemm: B prologue needs k-major B");
+    MC_CHECK(!p.R || (!p.c_f32 && p.ldr % 8 == 0), "gemm: residual needs bf16 output and ldr % 8 == 0");
+    if (p.alpha == 0.f) p.alpha = 1.f;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    long long mtiles = (p.M + 127) / 128;
+    long long cap = p.max_grid_m > 0 ? p.max_grid_m : 512;
+    int grid_m = (int)(mtiles < cap ? mtiles : cap);
+    if (!p.stat_partials && p.max_grid_m <= 0) {
+        // no persistent accumulators needed: one tile per block up to the grid limit
+        grid_m = (int)(mtiles < 65535 ? mtiles : 65535);
+    }
+    const bool small_k = p.K <= 48;
+    if (p.N > 64) {
+        return small_k ? launch<128, 128, 32, 2, 2>(p, grid_m, st) : launch<128, 128, 64, 2, 2>(p, grid_m, st);
+    } else if (p.N > 32) {
+        return small_k ? launch<128, 64, 32, 2, 2>(p, grid_m, st) : launch<128, 64, 64, 2, 2>(p, grid_m, st);
+    }
+    return small_k ? launch<128, 32, 32, 4, 1>(p, grid_m, st) : launch<128, 32, 64, 4, 1>(p, grid_m, st);
+}

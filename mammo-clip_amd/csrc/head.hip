@@ -1,0 +1,128 @@
+// Projection heads, L2 normalisation and the InfoNCE cross-entropy, all fp32 (the reference keeps
+// embeddings / logits / loss in fp32 even under autocast).
+// [ref: model/modules/projection.py:23-29, model/clip.py:86-91, loss/breast_clip.py:46-100]
+// These are tiny (b x 512 x W*b); a simple LDS-tiled VALU kernel with arbitrary strides serves every layout.
+#include "common.cuh"
+#include "../../include/mammoclip_hip.h"
+
+namespace {
+
+constexpr int TS = 32;
+
+__global__ __launch_bounds__(256) void sgemm_k(const float* __restrict__ a, long long ars, long long acs,
+                                               const float* __restrict__ b, long long brs, long long bcs,
+                                               float* __restrict__ c, long long ldc, int m, int n, int k, float alpha,
+                                               float beta, const float* __restrict__ bias) {
+    __shared__ float sa[TS][TS + 1], sb[TS][TS + 1];
+    const int tx = threadIdx.x % 16, ty = threadIdx.x / 16;       // 16 x 16 threads, 2 x 2 outputs each
+    const int m0 = blockIdx.y * TS, n0 = blockIdx.x * TS;
+    float acc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+    for (int k0 = 0; k0 < k; k0 += TS) {
+        for (int e = threadIdx.x; e < TS * TS; e += 256) {
+            int r = e / TS, cc = e % TS;
+            // choose the faster-varying index by stride to keep loads coalesced where possible
+            int mi = m0 + r, ki = k0 + cc;
+            sa[r][cc] = (mi < m && ki < k) ? a[mi * ars + ki * acs] : 0.f;
+            int kj = k0 + r, nj = n0 + cc;
+            sb[r][cc] = (kj < k && nj < n) ? b[kj * brs + nj * bcs] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int kk = 0; kk < TS; ++kk) {
+            float a0 = sa[ty][kk], a1 = sa[ty + 16][kk];
+            float b0 = sb[kk][tx], b1 = sb[kk][tx + 16];
+            acc[0][0] = fmaf(a0, b0, acc[0][0]); acc[0][1] = fmaf(a0, b1, acc[0][1]);
+            acc[1][0] = fmaf(a1, b0, acc[1][0]); acc[1][1] = fmaf(a1, b1, acc[1][1]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            int mi = m0 + ty + i * 16, nj = n0 + tx + j * 16;
+            if (mi < m && nj < n) {
+                float v = alpha * acc[i][j];
+                if (bias) v += bias[nj];
+                if (beta != 0.f) v += beta * c[mi * ldc + nj];
+                c[mi * ldc + nj] = v;
+            }
+        }
+}
+
+__global__ void l2norm_fwd_k(const float* __restrict__ x, int rows, int d, float* __restrict__ y, float* __restrict__ norm) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    float s = 0.f;
+    for (int i = lane; i < d; i += 64) { float v = x[(long long)row * d + i]; s += v * v; }
+    s = sqrtf(wave_sum(s));
+    if (lane == 0) norm[row] = s;
+    for (int i = lane; i < d; i += 64) y[(long long)row * d + i] = x[(long long)row * d + i] / s;
+}
+__global__ void l2norm_bwd_k(const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ norm,
+                             int rows, int d, float* __restrict__ dx) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    float s = 0.f;
+    for (int i = lane; i < d; i += 64) s += dy[(long long)row * d + i] * y[(long long)row * d + i];
+    s = wave_sum(s);
+    float inv = 1.f / norm[row];
+    for (int i = lane; i < d; i += 64)
+        dx[(long long)row * d + i] = (dy[(long long)row * d + i] - y[(long long)row * d + i] * s) * inv;
+}
+
+// one wave per row: lse, loss contribution, dlogits in place
+__global__ void ce_fwd_bwd_k(float* __restrict__ logits, int rows, int n, int label_offset, float w,
+                             float* __restrict__ loss_out) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    float* lr = logits + (long long)row * n;
+    float mx = -3.4e38f;
+    for (int i = lane; i < n; i += 64) mx = fmaxf(mx, lr[i]);
+    mx = wave_max(mx);
+    float s = 0.f;
+    for (int i = lane; i < n; i += 64) s += __expf(lr[i] - mx);
+    s = wave_sum(s);
+    const float lse = mx + __logf(s);
+    const int label = row + label_offset;
+    const float scale = w / (float)rows;
+    if (lane == 0) atomicAdd(loss_out, (lse - lr[label]) * scale);
+    const float inv = 1.f / s;
+    for (int i = lane; i < n; i += 64) {
+        float pr = __expf(lr[i] - mx) * inv;
+        lr[i] = (pr - (i == label ? 1.f : 0.f)) * scale;
+    }
+}
+
+}  // namespace
+
+extern "C" int mc_sgemm(const float* a, long long ars, long long acs, const float* b, long long brs, long long bcs,
+                        float* c, long long ldc, int m, int n, int k, float alpha, float beta, const float* bias,
+                        void* stream) {
+    MC_CHECK(a && b && c && m > 0 && n > 0 && k > 0, "sgemm: bad args");
+    dim3 grid(mc_div_up(n, TS), mc_div_up(m, TS));
+    hipLaunchKernelGGL(sgemm_k, grid, dim3(256), 0, (hipStream_t)stream, a, ars, acs, b, brs, bcs, c, ldc, m, n, k, alpha,
+                       beta, bias);
+    MC_LAUNCH_CHECK();
+    return MC_OK;
+}
+extern "C" int mc_l2norm_fwd(const float* x, int rows, int d, float* y, float* norm, void* stream) {
+    MC_CHECK(x && y && norm && rows > 0 && d > 0, "l2norm_fwd: bad args");
+    hipLaunchKernelGGL(l2norm_fwd_k, dim3(mc_div_up(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, rows, d, y, norm);
+    MC_LAUNCH_CHECK();
+    return MC_OK;
+}
+extern "C" int mc_l2norm_bwd(const float* dy, const float* y, const float* norm, int rows, int d, float* dx, void* stream) {
+    MC_CHECK(dy && y && norm && dx && rows > 0 && d > 0, "l2norm_bwd: bad args");
+    hipLaunchKernelGGL(l2norm_bwd_k, dim3(mc_div_up(rows, 4)), dim3(256), 0, (hipStream_t)stream, dy, y, norm, rows, d, dx);
+    MC_LAUNCH_CHECK();
+    return MC_OK;
+}
+extern "C" int mc_ce_fwd_bwd(float* logits, int rows, int n, int label_offset, float w, float* loss_out, void* stream) {
+    MC_CHECK(logits && loss_out && rows > 0 && n > 0, "ce: bad args");
+    MC_CHECK(label_offset >= 0 && label_offset + rows <= n, "ce: labels out of range");
+    hipLaunchKernelGGL(ce_fwd_bwd_k, dim3(mc_div_up(rows, 4)), dim3(256), 0, (hipStream_t)stream, logits, rows, n,
+                       label_offset, w, loss_out);
+    MC_LAUNCH_CHECK();
+    return MC_OK;
+}

@@ -1,0 +1,218 @@
+// error state, casts, transposes, stem im2col / weight prep, fp32 dropout, bf16 column sums.
+#include "common.cuh"
+#include "../../include/mammoclip_hip.h"
+#include <string.h>
+
+static thread_local char g_err[512] = "";
+extern "C" void mc_set_error(const char* msg) {
+    strncpy(g_err, msg ? msg : "", sizeof(g_err) - 1);
+    g_err[sizeof(g_err) - 1] = 0;
+}
+extern "C" const char* mc_last_error(void) { return g_err; }
+extern "C" int mc_version(void) { return 100; }
+
+namespace {
+
+__global__ void cast_f32_bf16_k(const float* __restrict__ s, bf16_t* __restrict__ d, long long n) {
+    long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+    const long long stride = (long long)gridDim.x * blockDim.x * 8;
+    for (; i < n; i += stride) {
+        if (i + 8 <= n && ((((uintptr_t)(s + i)) & 15u) == 0) && ((((uintptr_t)(d + i)) & 15u) == 0)) {
+            float f[8];
+            load8f(s + i, f);
+            *reinterpret_cast<uint4*>(d + i) = pack8(f);
+        } else {
+            for (long long j = i; j < n && j < i + 8; ++j) d[j] = f2bf(s[j]);
+        }
+    }
+}
+__global__ void cast_bf16_f32_k(const bf16_t* __restrict__ s, float* __restrict__ d, long long n) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) d[i] = bf2f(s[i]);
+}
+__global__ void transpose_f32_k(const float* __restrict__ s, float* __restrict__ d, int rows, int cols) {
+    __shared__ float tile[32][33];
+    int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+    for (int j = threadIdx.y; j < 32; j += blockDim.y) {
+        int r = by + j, c = bx + threadIdx.x;
+        if (r < rows && c < cols) tile[j][threadIdx.x] = s[(long long)r * cols + c];
+    }
+    __syncthreads();
+    for (int j = threadIdx.y; j < 32; j += blockDim.y) {
+        int c = bx + j, r = by + threadIdx.x;
+        if (r < rows && c < cols) d[(long long)c * rows + r] = tile[threadIdx.x][j];
+    }
+}
+__global__ void stem_weight_prep_k(const float* __restrict__ w, bf16_t* __restrict__ out, int c0) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < c0 * 32) {
+        int o = i / 32, k = i % 32;
+        out[i] = (k < 27) ? f2bf(w[o * 27 + k]) : (bf16_t)0;
+    }
+}
+
+// one thread per output pixel: gathers the 3x3x3 patch (k = cin*9 + kh*3 + kw) and writes 64 bytes
+__global__ void stem_im2col_k(const float* __restrict__ x, long long sn, long long sc, long long sh,
+                              long long sw, int n, int h, int w, int pad_l, int pad_t, int oh, int ow,
+                              bf16_t* __restrict__ out) {
+    long long pix = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long total = (long long)n * oh * ow;
+    if (pix >= total) return;
+    int ox = (int)(pix % ow);
+    int oy = (int)((pix / ow) % oh);
+    long long img = pix / ((long long)ow * oh);
+    float v[32];
+#pragma unroll
+    for (int i = 27; i < 32; ++i) v[i] = 0.f;
+    const float* base = x + img * sn;
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            int iy = oy * 2 + kh - pad_t;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                int ix = ox * 2 + kw - pad_l;
+                float val = 0.f;
+                if (iy >= 0 && iy < h && ix >= 0 && ix < w) val = base[c * sc + iy * sh + ix * sw];
+                v[c * 9 + kh * 3 + kw] = val;
+            }
+        }
+    uint4* o = reinterpret_cast<uint4*>(out + pix * 32);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) o[q] = pack8(v + q * 8);
+}
+
+__global__ void dropout_f32_k(const float* __restrict__ x, float* __restrict__ y, long long n, float p,
+                              unsigned long long seed, unsigned int sid) {
+    long long i8 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long n8 = (n + 7) / 8;
+    if (i8 >= n8) return;
+    float s[8];
+    dropout_scale8(seed, sid, (unsigned long long)i8, p, s);
+    for (int j = 0; j < 8; ++j) {
+        long long i = i8 * 8 + j;
+        if (i < n) y[i] = x[i] * s[j];
+    }
+}
+
+// column sums of bf16 [m, c] (row stride ld): thread = (row group, 8-channel vector)
+__global__ __launch_bounds__(256) void colsum_partial_k(const bf16_t* __restrict__ x, long long m, int c,
+                                                        long long ld, float* __restrict__ partials) {
+    const int cv = c / 8;
+    const int cvp = cv < 256 ? cv : 256;
+    const int rpb = 256 / cvp;                 // row lanes per block iteration
+    const int tid = threadIdx.x;
+    const int rl = tid / cvp, cl = tid % cvp;
+    __shared__ float red[256 * 8];
+    for (int cbase = 0; cbase < cv; cbase += cvp) {
+        int v = cbase + cl;
+        float acc[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc[q] = 0.f;
+        if (rl < rpb && v < cv) {
+            for (long long r = (long long)blockIdx.x * rpb + rl; r < m; r += (long long)gridDim.x * rpb) {
+                float f[8];
+                unpack8(*reinterpret_cast<const uint4*>(x + r * ld + v * 8), f);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) acc[q] += f[q];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) red[tid * 8 + q] = acc[q];
+        __syncthreads();
+        if (rl == 0 && v < cv) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                float s = 0.f;
+                for (int r = 0; r < rpb; ++r) s += red[(r * cvp + cl) * 8 + q];
+                partials[(long long)blockIdx.x * c + v * 8 + q] = s;
+            }
+        }
+        __syncthreads();
+    }
+}
+__global__ void colsum_final_k(const float* __restrict__ partials, int rows, int c, float* __restrict__ out,
+                               int accumulate) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= c) return;
+    double s = 0.0;
+    for (int r = 0; r < rows; ++r) s += (double)partials[(long long)r * c + i];
+    out[i] = accumulate ? out[i] + (float)s : (float)s;
+}
+
+}  // namespace
+
+extern "C" int mc_cast_f32_bf16(const float* src, mc_bf16* dst, long long n, void* stream) {
+    if (n <= 0) return MC_OK;
+    MC_CHECK(src && dst, "cast: null pointer");
+    int blocks = mc_div_up(n, 256 * 8);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(cast_f32_bf16_k, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, dst, n);
+    MC_LAUNCH_CHECK();
+    return MC_OK;
+}
+extern "C" int mc_cast_bf16_f32(const mc_bf16* src, float* dst, long long n, void* stream) {
+    if (n <= 0) return MC_OK;
+    MC_CHECK(src && dst, "cast: null pointer");
+    int blocks = mc_div_up(n, 256);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(cast_bf16_f32_k, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, dst, n);
+    MC_LAUNCH_CHECK();
+    return MC_OK;
+}
+extern "C" int mc_transpose_f32(const float* src, float* dst, int rows, int cols, void* stream) {
+    MC_CHECK(src && dst && rows > 0 && cols > 0, "transpose: bad args");
+    dim3 grid(mc_div_up(cols, 32), mc_div_up(rows, 32));
+    hipLaunchKernelGGL(transpose_f32_k, grid, dim3(32, 8), 0, (hipStream_t)stream, src, dst, rows, cols);
+    MC_LAUNCH_CHECK();
+    return MC_OK;
+}
+extern "C" int mc_stem_weight_prep(const float* w, mc_bf16* out, int c0, void* stream) {
+    MC_CHECK(w && out && c0 > 0, "stem_weight_prep: bad args");
+    hipLaunchKernelGGL(stem_weight_prep_k, dim3(mc_div_up(c0 * 32, 256)), dim3(256), 0, (hipStream_t)stream, w, out, c0);
+    MC_LAUNCH_CHECK();
+    return MC_OK;
+}
+extern "C" int mc_stem_im2col(const float* x, long long sn, long long sc, long long sh, long long sw, int n,
+                              int h, int w, int pad_l, int pad_t, int oh, int ow, mc_bf16* out, void* stream) {
+    MC_CHECK(x && out && n > 0 && h > 0 && w > 0 && oh > 0 && ow > 0, "stem_im2col: bad args");
+    MC_CHECK(mc_aligned16(out), "stem_im2col: out must be 16-byte aligned");
+    long long total = (long long)n * oh * ow;
+    hipLaunchKernelGGL(stem_im2col_k, dim3(mc_div_up(total, 256)), dim3(256), 0, (hipStream_t)stream, x, sn, sc,
+                       sh, sw, n, h, w, pad_l, pad_t, oh, ow, out);
+    MC_LAUNCH_CHECK();
+    return MC_OK;
+}
+extern "C" int mc_dropout_f32(const float* x, float* y, long long n, float p, unsigned long long seed,
+                              unsigned int stream_id, void* stream) {
+    if (n <= 0) return MC_OK;
+    MC_CHECK(x && y && p >= 0.f && p < 1.f, "dropout: bad args");
+    long long n8 = (n + 7) / 8;
+    hipLaunchKernelGGL(dropout_f32_k, dim3(mc_div_up(n8, 256)), dim3(256), 0, (hipStream_t)stream, x, y, n, p,
+                       seed, stream_id);
+    MC_LAUNCH_CHECK();
+    return MC_OK;
+}
+extern "C" int mc_colsum_rows(long long m, int c) {
+    int cv = c / 8;
+    int cvp = cv < 256 ? cv : 256;
+    int rpb = 256 / (cvp > 0 ? cvp : 1);
+    long long blocks = (m + (long long)rpb * 16 - 1) / ((long long)rpb * 16);
+    if (blocks < 1) blocks = 1;
+    if (blocks > 1024) blocks = 1024;
+    return (int)blocks;
+}
+extern "C" int mc_colsum_bf16(const mc_bf16* x, long long m, int c, long long ld, float* partials, float* out,
+                              int accumulate, void* stream) {
+    MC_CHECK(x && partials && out && m > 0 && c > 0, "colsum: bad args");
+    MC_CHECK(c % 8 == 0 && ld % 8 == 0 && mc_aligned16(x), "colsum: c and ld must be multiples of 8, x aligned");
+    int rows = mc_colsum_rows(m, c);
+    hipLaunchKernelGGL(colsum_partial_k, dim3(rows), dim3(256), 0, (hipStream_t)stream, x, m, c, ld, partials);
+    MC_LAUNCH_CHECK();
+    hipLaunchKernelGGL(colsum_final_k, dim3(mc_div_up(c, 256)), dim3(256), 0, (hipStream_t)stream, partials, rows, c,
+                       out, accumulate);
+    MC_LAUNCH_CHECK();
+    return MC_OK;
+}

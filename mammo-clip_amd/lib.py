@@ -1,0 +1,138 @@
+"""ctypes binding of libmammoclip_hip.so (the C ABI declared in include/mammoclip_hip.h).
+
+There is deliberately NO fallback: if the shared library is missing or a call fails, an exception is
+raised.  The product never routes through a CPU / eager-PyTorch path.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmammoclip_hip.so")
+
+P, LL, I, F, D, U, ULL = C.c_void_p, C.c_longlong, C.c_int, C.c_float, C.c_double, C.c_uint, C.c_ulonglong
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [
+        ("A", P), ("B", P), ("C", P),
+        ("M", LL), ("K", LL), ("N", I),
+        ("lda", LL), ("ldb", LL), ("ldc", LL),
+        ("a_kmajor", I), ("b_kmajor", I),
+        ("c_f32", I), ("c_atomic", I),
+        ("splits", I),
+        ("batch", I), ("nb2", I),
+        ("sA1", LL), ("sA2", LL), ("sB1", LL), ("sB2", LL), ("sC1", LL), ("sC2", LL),
+        ("bias", P), ("bias_stride1", LL),
+        ("act", I),
+        ("R", P), ("ldr", LL),
+        ("alpha", F),
+        ("pro_operand", I),
+        ("pro_scale", P), ("pro_shift", P), ("pro_gate", P),
+        ("pro_rows_per_img", LL), ("pro_nch", I),
+        ("stat_partials", P),
+        ("max_grid_m", I),
+    ]
+
+
+class DwconvArgs(C.Structure):
+    _fields_ = [
+        ("x", P), ("dy", P), ("out", P), ("w_kkc", P),
+        ("n", I), ("h", I), ("w", I), ("c", I),
+        ("k", I), ("stride", I), ("pad_l", I), ("pad_t", I), ("oh", I), ("ow", I),
+        ("pro_scale", P), ("pro_shift", P), ("stat_partials", P),
+    ]
+
+
+class BnactArgs(C.Structure):
+    _fields_ = [
+        ("x", P), ("n_img", LL), ("hw", LL), ("c", I),
+        ("scale", P), ("shift", P), ("act", I),
+        ("rowscale", P), ("res", P), ("out", P),
+        ("pooled", P),
+        ("g", P), ("mul", P), ("add", P), ("mean", P), ("invstd", P),
+        ("partials", P), ("coef", P), ("dx", P), ("dgate", P),
+    ]
+
+
+_SIGS = {
+    "mc_version": ([], I),
+    "mc_gemm_bf16": ([C.POINTER(GemmArgs), P], I),
+    "mc_gemm_stat_rows": ([C.POINTER(GemmArgs)], I),
+    "mc_cast_f32_bf16": ([P, P, LL, P], I),
+    "mc_cast_bf16_f32": ([P, P, LL, P], I),
+    "mc_transpose_f32": ([P, P, I, I, P], I),
+    "mc_stem_weight_prep": ([P, P, I, P], I),
+    "mc_stem_im2col": ([P, LL, LL, LL, LL, I, I, I, I, I, I, I, P, P], I),
+    "mc_dwconv_stat_rows": ([C.POINTER(DwconvArgs)], I),
+    "mc_dwconv_fwd": ([C.POINTER(DwconvArgs), P], I),
+    "mc_dwconv_bwd_data": ([C.POINTER(DwconvArgs), P], I),
+    "mc_dwconv_bwd_weight": ([C.POINTER(DwconvArgs), P], I),
+    "mc_bn_finalize": ([P, I, I, D, P, P, P, P, F, F, I, P, P, P, P, P], I),
+    "mc_bn_eval_coeffs": ([P, P, P, P, F, I, P, P, P], I),
+    "mc_bnact_rows": ([C.POINTER(BnactArgs)], I),
+    "mc_bnact_apply": ([C.POINTER(BnactArgs), P], I),
+    "mc_bnact_pool": ([C.POINTER(BnactArgs), P], I),
+    "mc_bnact_bwd_reduce": ([C.POINTER(BnactArgs), P], I),
+    "mc_bnact_bwd_apply": ([C.POINTER(BnactArgs), P], I),
+    "mc_bnact_se_dgate": ([C.POINTER(BnactArgs), P], I),
+    "mc_bn_bwd_finalize": ([P, I, I, D, P, P, P, P, P, P, P], I),
+    "mc_colsum_rows": ([LL, I], I),
+    "mc_colsum_bf16": ([P, LL, I, LL, P, P, I, P], I),
+    "mc_se_fwd": ([P, P, P, P, P, I, I, I, P, P], I),
+    "mc_se_bwd": ([P, P, P, P, P, P, P, I, I, I, P, P, P, P, P, P, P], I),
+    "mc_dropout_f32": ([P, P, LL, F, ULL, U, P], I),
+    "mc_bert_embed_fwd": ([P, P, P, P, P, P, P, F, I, I, I, F, ULL, U, P, P, P, P], I),
+    "mc_bert_embed_bwd": ([P, P, P, P, P, P, P, P, P, I, I, I, F, ULL, U, P, P, P, P, P, P], I),
+    "mc_add_ln_fwd": ([P, P, P, P, F, LL, I, F, ULL, U, P, P, P, P], I),
+    "mc_add_ln_bwd": ([P, P, P, P, P, P, LL, I, F, ULL, U, P, P, P, P, P], I),
+    "mc_softmax_fwd": ([P, LL, I, F, ULL, U, P, P, P], I),
+    "mc_softmax_bwd": ([P, P, LL, I, F, ULL, U, F, P, P], I),
+    "mc_gelu_fwd": ([P, P, LL, P], I),
+    "mc_gelu_bwd": ([P, P, P, LL, P], I),
+    "mc_mask_bias": ([P, P, LL, P], I),
+    "mc_eos_gather": ([P, P, I, I, I, P, P], I),
+    "mc_eos_scatter": ([P, P, I, I, I, P, P], I),
+    "mc_sgemm": ([P, LL, LL, P, LL, LL, P, LL, I, I, I, F, F, P, P], I),
+    "mc_l2norm_fwd": ([P, I, I, P, P, P], I),
+    "mc_l2norm_bwd": ([P, P, P, I, I, P, P], I),
+    "mc_ce_fwd_bwd": ([P, I, I, I, F, P, P], I),
+}
+
+EXPORTS = sorted(list(_SIGS.keys()) + ["mc_last_error"])
+
+_lib = None
+
+
+class MammoClipHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library (once).  Raises if it has not been built: there is no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MammoClipHipError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  The HIP path is the only path.")
+    lib = C.CDLL(LIB_PATH)
+    lib.mc_last_error.argtypes = []
+    lib.mc_last_error.restype = C.c_char_p
+    for name, (args, res) in _SIGS.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = res
+    _lib = lib
+    return lib
+
+
+def check(status: int, what: str = ""):
+    if status != 0:
+        msg = load().mc_last_error().decode("utf-8", "replace")
+        raise MammoClipHipError(f"{what} failed (status {status}): {msg}")
+
+
+def call(name: str, *args):
+    lib = load()
+    check(getattr(lib, name)(*args), name)

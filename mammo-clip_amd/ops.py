@@ -1,0 +1,418 @@
+"""Thin tensor-level wrappers over the C ABI (lib.py).  torch is used only for device memory and streams.
+
+Every function launches hand-written HIP kernels asynchronously on torch's current stream.  Tensors are
+bf16 activations in row-major [rows, channels] (NHWC) layout unless noted, fp32 parameters / statistics.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import lib as L
+
+BF16 = torch.bfloat16
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _st():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk_dev(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise L.MammoClipHipError("mammo_clip_amd ops need tensors on a HIP device (there is no CPU fallback)")
+
+
+def empty(shape, dtype, like):
+    return torch.empty(shape, dtype=dtype, device=like.device)
+
+
+# ------------------------------------------------------------------------------------------- GEMM
+def gemm(A, B, C_out, M, N, K, lda, ldb, ldc, a_kmajor=0, b_kmajor=0, c_f32=0, c_atomic=0, splits=1,
+         batch=1, nb2=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), bias=None, bias_stride1=0, act=0, R=None, ldr=0,
+         alpha=1.0, pro=None, stat_partials=None, max_grid_m=0):
+    """pro = (operand, scale, shift, gate or None, rows_per_img, nch)"""
+    a = L.GemmArgs()
+    a.A, a.B, a.C = _p(A), _p(B), _p(C_out)
+    a.M, a.K, a.N = M, K, N
+    a.lda, a.ldb, a.ldc = lda, ldb, ldc
+    a.a_kmajor, a.b_kmajor, a.c_f32, a.c_atomic, a.splits = a_kmajor, b_kmajor, c_f32, c_atomic, splits
+    a.batch, a.nb2 = batch, nb2
+    a.sA1, a.sA2, a.sB1, a.sB2, a.sC1, a.sC2 = sA[0], sA[1], sB[0], sB[1], sC[0], sC[1]
+    a.bias, a.bias_stride1, a.act = _p(bias), bias_stride1, act
+    a.R, a.ldr, a.alpha = _p(R), ldr, alpha
+    if pro is not None:
+        a.pro_operand = pro[0]
+        a.pro_scale, a.pro_shift, a.pro_gate = _p(pro[1]), _p(pro[2]), _p(pro[3])
+        a.pro_rows_per_img, a.pro_nch = pro[4], pro[5]
+    a.stat_partials = _p(stat_partials)
+    a.max_grid_m = max_grid_m
+    L.call("mc_gemm_bf16", C.byref(a), _st())
+
+
+def gemm_stat_rows(M):
+    a = L.GemmArgs()
+    a.M = M
+    return L.load().mc_gemm_stat_rows(C.byref(a))
+
+
+def linear_fwd(x, w, bias=None, act=0, residual=None, stats=False, pro=None, out=None):
+    """y[M,N] = x[M,K] . w[N,K]^T (+bias)(act)(+residual).  stats -> also returns [rows,2,N] partials."""
+    M, K = x.shape
+    N = w.shape[0]
+    y = out if out is not None else empty((M, N), BF16, x)
+    part = None
+    if stats:
+        part = empty((gemm_stat_rows(M), 2, N), torch.float32, x)
+    p = None
+    if pro is not None:
+        p = (1, pro[0], pro[1], pro[2], pro[3], K)
+    gemm(x, w, y, M, N, K, x.stride(0), w.stride(0), y.stride(0), bias=bias, act=act, R=residual,
+         ldr=(residual.stride(0) if residual is not None else 0), pro=p, stat_partials=part)
+    return (y, part) if stats else y
+
+
+def linear_dgrad(dy, w, residual=None):
+    """dx[M,K] = dy[M,N] . w[N,K]  (+ residual)"""
+    M, N = dy.shape
+    K = w.shape[1]
+    dx = empty((M, K), BF16, dy)
+    gemm(dy, w, dx, M, K, N, dy.stride(0), w.stride(0), dx.stride(0), b_kmajor=1, R=residual,
+         ldr=(residual.stride(0) if residual is not None else 0))
+    return dx
+
+
+def _wgrad_splits(m, n, k):
+    tiles = math.ceil(m / 128) * math.ceil(n / (128 if n > 64 else (64 if n > 32 else 32)))
+    ktiles = math.ceil(k / 64)
+    s = max(1, min(math.ceil(2048 / tiles), max(1, ktiles // 4)))
+    return s
+
+
+def linear_wgrad(dy, x, pro=None, out=None):
+    """dw[N,K] (fp32) = dy[M,N]^T . x'[M,K]; x' = prologue(x) when pro = (scale, shift, gate, rows_per_img)."""
+    M, N = dy.shape
+    K = x.shape[1]
+    dw = out if out is not None else torch.zeros((N, K), dtype=torch.float32, device=dy.device)
+    p = None
+    if pro is not None:
+        p = (2, pro[0], pro[1], pro[2], pro[3], K)
+    gemm(dy, x, dw, N, K, M, dy.stride(0), x.stride(0), dw.stride(0), a_kmajor=1, b_kmajor=1, c_f32=1, c_atomic=1,
+         splits=_wgrad_splits(N, K, M), pro=p)
+    return dw
+
+
+def colsum(x, out=None, accumulate=False):
+    """out[c] (+)= sum_m x[m,c]  (bf16 in, fp32 out)"""
+    M, Cn = x.shape
+    rows = L.load().mc_colsum_rows(M, Cn)
+    part = empty((rows, Cn), torch.float32, x)
+    if out is None:
+        out = empty((Cn,), torch.float32, x)
+        accumulate = False
+    L.call("mc_colsum_bf16", _p(x), M, Cn, x.stride(0), _p(part), _p(out), int(accumulate), _st())
+    return out
+
+
+def cast_bf16(src, out=None):
+    src = src.contiguous()
+    dst = out if out is not None else empty(src.shape, BF16, src)
+    L.call("mc_cast_f32_bf16", _p(src), _p(dst), src.numel(), _st())
+    return dst
+
+
+def cast_f32(src):
+    src = src.contiguous()
+    dst = empty(src.shape, torch.float32, src)
+    L.call("mc_cast_bf16_f32", _p(src), _p(dst), src.numel(), _st())
+    return dst
+
+
+def transpose_f32(src):
+    rows, cols = src.shape
+    dst = empty((cols, rows), torch.float32, src)
+    L.call("mc_transpose_f32", _p(src.contiguous()), _p(dst), rows, cols, _st())
+    return dst
+
+
+# ------------------------------------------------------------------------------------------- stem
+def stem_weight_prep(w):
+    c0 = w.shape[0]
+    out = empty((c0, 32), BF16, w)
+    L.call("mc_stem_weight_prep", _p(w.contiguous()), _p(out), c0, _st())
+    return out
+
+
+def stem_im2col(x, pad_l, pad_t, oh, ow):
+    """x: fp32 [n,3,h,w] with ANY strides (NCHW or a permuted NHWC view) -> bf16 patches [n*oh*ow, 32]."""
+    n, c, h, w = x.shape
+    assert c == 3 and x.dtype == torch.float32
+    out = empty((n * oh * ow, 32), BF16, x)
+    sn, sc, sh, sw = x.stride()
+    L.call("mc_stem_im2col", _p(x), sn, sc, sh, sw, n, h, w, pad_l, pad_t, oh, ow, _p(out), _st())
+    return out
+
+
+# ------------------------------------------------------------------------------------------- depthwise
+def _dw_args(n, h, w, c, k, stride, pad_l, pad_t, oh, ow):
+    a = L.DwconvArgs()
+    a.n, a.h, a.w, a.c, a.k, a.stride, a.pad_l, a.pad_t, a.oh, a.ow = n, h, w, c, k, stride, pad_l, pad_t, oh, ow
+    return a
+
+
+def dwconv_fwd(x, w_kkc, n, h, w, c, k, stride, pad_l, pad_t, oh, ow, pro=None, stats=False):
+    a = _dw_args(n, h, w, c, k, stride, pad_l, pad_t, oh, ow)
+    y = empty((n * oh * ow, c), BF16, x)
+    a.x, a.out, a.w_kkc = _p(x), _p(y), _p(w_kkc)
+    if pro is not None:
+        a.pro_scale, a.pro_shift = _p(pro[0]), _p(pro[1])
+    part = None
+    if stats:
+        rows = L.load().mc_dwconv_stat_rows(C.byref(a))
+        part = empty((rows, 2, c), torch.float32, x)
+        a.stat_partials = _p(part)
+    L.call("mc_dwconv_fwd", C.byref(a), _st())
+    return (y, part) if stats else y
+
+
+def dwconv_bwd_data(dy, w_kkc, n, h, w, c, k, stride, pad_l, pad_t, oh, ow, w_kkc_flipped=None):
+    """dx [n*h*w, c].  stride 1 runs the LDS-tiled forward kernel on the flipped filter; stride 2 the gather kernel."""
+    if stride == 1 and w_kkc_flipped is not None:
+        return dwconv_fwd(dy, w_kkc_flipped, n, oh, ow, c, k, 1, k - 1 - pad_l, k - 1 - pad_t, h, w)
+    a = _dw_args(n, h, w, c, k, stride, pad_l, pad_t, oh, ow)
+    dx = empty((n * h * w, c), BF16, dy)
+    a.dy, a.out, a.w_kkc = _p(dy), _p(dx), _p(w_kkc)
+    L.call("mc_dwconv_bwd_data", C.byref(a), _st())
+    return dx
+
+
+def dwconv_bwd_weight(x, dy, n, h, w, c, k, stride, pad_l, pad_t, oh, ow, pro=None):
+    a = _dw_args(n, h, w, c, k, stride, pad_l, pad_t, oh, ow)
+    dw = torch.zeros((k * k, c), dtype=torch.float32, device=x.device)
+    a.x, a.dy, a.out = _p(x), _p(dy), _p(dw)
+    if pro is not None:
+        a.pro_scale, a.pro_shift = _p(pro[0]), _p(pro[1])
+    L.call("mc_dwconv_bwd_weight", C.byref(a), _st())
+    return dw
+
+
+# ------------------------------------------------------------------------------------------- BN family
+class BNStats:
+    """Per-layer saved statistics of one training-mode BatchNorm call."""
+    __slots__ = ("mean", "invstd", "scale", "shift", "count")
+
+
+def bn_finalize(partials, count, gamma, beta, running_mean, running_var, momentum, eps, update_running):
+    rows, _, c = partials.shape
+    buf = empty((4, c), torch.float32, partials)
+    L.call("mc_bn_finalize", _p(partials), rows, c, float(count), _p(gamma), _p(beta), _p(running_mean),
+           _p(running_var), momentum, eps, int(update_running), _p(buf[0]), _p(buf[1]), _p(buf[2]), _p(buf[3]), _st())
+    s = BNStats()
+    s.mean, s.invstd, s.scale, s.shift, s.count = buf[0], buf[1], buf[2], buf[3], float(count)
+    return s
+
+
+def bn_eval_coeffs(gamma, beta, running_mean, running_var, eps):
+    c = gamma.shape[0]
+    buf = empty((4, c), torch.float32, gamma)
+    L.call("mc_bn_eval_coeffs", _p(gamma), _p(beta), _p(running_mean), _p(running_var), eps, c, _p(buf[2]), _p(buf[3]), _st())
+    s = BNStats()
+    s.mean, s.invstd, s.scale, s.shift, s.count = None, None, buf[2], buf[3], 0.0
+    return s
+
+
+def _bnact(x, n_img, hw, c, scale, shift, act):
+    a = L.BnactArgs()
+    a.x, a.n_img, a.hw, a.c = _p(x), n_img, hw, c
+    a.scale, a.shift, a.act = _p(scale), _p(shift), act
+    return a
+
+
+def bnact_apply(x, n_img, hw, c, scale, shift, act, rowscale=None, res=None):
+    a = _bnact(x, n_img, hw, c, scale, shift, act)
+    out = empty((n_img * hw, c), BF16, x)
+    a.rowscale, a.res, a.out = _p(rowscale), _p(res), _p(out)
+    L.call("mc_bnact_apply", C.byref(a), _st())
+    return out
+
+
+def bnact_pool(x, n_img, hw, c, scale, shift, act):
+    a = _bnact(x, n_img, hw, c, scale, shift, act)
+    pooled = empty((n_img, c), torch.float32, x)
+    a.pooled = _p(pooled)
+    L.call("mc_bnact_pool", C.byref(a), _st())
+    return pooled
+
+
+def bnact_se_dgate(x, g, n_img, hw, c, scale, shift, act):
+    a = _bnact(x, n_img, hw, c, scale, shift, act)
+    dgate = empty((n_img, c), torch.float32, x)
+    a.g, a.dgate = _p(g), _p(dgate)
+    L.call("mc_bnact_se_dgate", C.byref(a), _st())
+    return dgate
+
+
+def bnact_bwd(x, n_img, hw, c, stats, gamma, act, g=None, mul=None, add=None, rowscale=None):
+    """Backward through y = act(BN_train(x)) (* rowscale).  Returns (dx bf16, dgamma, dbeta)."""
+    a = _bnact(x, n_img, hw, c, stats.scale, stats.shift, act)
+    a.g, a.mul, a.add, a.rowscale = _p(g), _p(mul), _p(add), _p(rowscale)
+    a.mean, a.invstd = _p(stats.mean), _p(stats.invstd)
+    rows = L.load().mc_bnact_rows(C.byref(a))
+    part = empty((rows, 2, c), torch.float32, x)
+    a.partials = _p(part)
+    L.call("mc_bnact_bwd_reduce", C.byref(a), _st())
+    buf = empty((5, c), torch.float32, x)        # dgamma, dbeta, coefA, coefB, coefC
+    L.call("mc_bn_bwd_finalize", _p(part), rows, c, float(n_img * hw), _p(gamma), _p(stats.mean), _p(stats.invstd),
+           _p(buf[0]), _p(buf[1]), _p(buf[2]), _st())
+    dx = empty((n_img * hw, c), BF16, x)
+    a.coef, a.dx = _p(buf[2]), _p(dx)
+    L.call("mc_bnact_bwd_apply", C.byref(a), _st())
+    return dx, buf[0], buf[1]
+
+
+# ------------------------------------------------------------------------------------------- SE / dropout
+def se_fwd(pooled, w1, b1, w2, b2):
+    n, c = pooled.shape
+    cs = w1.shape[0]
+    gate = empty((n, c), torch.float32, pooled)
+    L.call("mc_se_fwd", _p(pooled), _p(w1), _p(b1), _p(w2), _p(b2), n, c, cs, _p(gate), _st())
+    return gate
+
+
+def se_bwd(pooled, gate, dgate, w1, b1, w2, b2):
+    n, c = pooled.shape
+    cs = w1.shape[0]
+    dpooled = empty((n, c), torch.float32, pooled)
+    dw1 = torch.zeros((cs, c), dtype=torch.float32, device=pooled.device)
+    db1 = torch.zeros((cs,), dtype=torch.float32, device=pooled.device)
+    dw2 = torch.zeros((c, cs), dtype=torch.float32, device=pooled.device)
+    db2 = torch.zeros((c,), dtype=torch.float32, device=pooled.device)
+    ws = empty((n, c + 2 * cs), torch.float32, pooled)
+    L.call("mc_se_bwd", _p(pooled), _p(gate), _p(dgate), _p(w1), _p(b1), _p(w2), _p(b2), n, c, cs, _p(dpooled),
+           _p(dw1), _p(db1), _p(dw2), _p(db2), _p(ws), _st())
+    return dpooled, dw1, db1, dw2, db2
+
+
+def dropout_f32(x, p, seed, stream_id):
+    if p <= 0.0:
+        return x
+    y = torch.empty_like(x)
+    L.call("mc_dropout_f32", _p(x), _p(y), x.numel(), float(p), int(seed), int(stream_id), _st())
+    return y
+
+
+# ------------------------------------------------------------------------------------------- BERT pieces
+def bert_embed_fwd(ids, tt, word, pos, typ, gamma, beta, eps, p, seed, sid):
+    b, t = ids.shape
+    h = word.shape[1]
+    y = empty((b * t, h), BF16, word)
+    mean = empty((b * t,), torch.float32, word)
+    rstd = empty((b * t,), torch.float32, word)
+    L.call("mc_bert_embed_fwd", _p(ids), _p(tt), _p(word), _p(pos), _p(typ), _p(gamma), _p(beta), eps, b, t, h,
+           float(p), int(seed), int(sid), _p(y), _p(mean), _p(rstd), _st())
+    return y, mean, rstd
+
+
+def bert_embed_bwd(dy, ids, tt, word, pos, typ, gamma, mean, rstd, p, seed, sid):
+    b, t = ids.shape
+    h = word.shape[1]
+    dword, dpos, dtyp = torch.zeros_like(word), torch.zeros_like(pos), torch.zeros_like(typ)
+    dgamma, dbeta = torch.zeros_like(gamma), torch.zeros_like(gamma)
+    L.call("mc_bert_embed_bwd", _p(dy), _p(ids), _p(tt), _p(word), _p(pos), _p(typ), _p(gamma), _p(mean), _p(rstd),
+           b, t, h, float(p), int(seed), int(sid), _p(dword), _p(dpos), _p(dtyp), _p(dgamma), _p(dbeta), _st())
+    return dword, dpos, dtyp, dgamma, dbeta
+
+
+def add_ln_fwd(x, res, gamma, beta, eps, p, seed, sid):
+    rows, h = x.shape
+    y = empty((rows, h), BF16, x)
+    mean = empty((rows,), torch.float32, x)
+    rstd = empty((rows,), torch.float32, x)
+    L.call("mc_add_ln_fwd", _p(x), _p(res), _p(gamma), _p(beta), eps, rows, h, float(p), int(seed), int(sid), _p(y),
+           _p(mean), _p(rstd), _st())
+    return y, mean, rstd
+
+
+def add_ln_bwd(dy, x, res, gamma, mean, rstd, p, seed, sid):
+    rows, h = x.shape
+    dx, dres = empty((rows, h), BF16, x), empty((rows, h), BF16, x)
+    dgamma, dbeta = torch.zeros_like(gamma), torch.zeros_like(gamma)
+    L.call("mc_add_ln_bwd", _p(dy), _p(x), _p(res), _p(gamma), _p(mean), _p(rstd), rows, h, float(p), int(seed),
+           int(sid), _p(dx), _p(dres), _p(dgamma), _p(dbeta), _st())
+    return dx, dres, dgamma, dbeta
+
+
+def softmax_fwd(scores, p, seed, sid):
+    t = scores.shape[-1]
+    rows = scores.numel() // t
+    probs = empty(scores.shape, BF16, scores)
+    pd = empty(scores.shape, BF16, scores) if p > 0 else probs
+    L.call("mc_softmax_fwd", _p(scores), rows, t, float(p), int(seed), int(sid), _p(probs), _p(pd), _st())
+    return probs, pd
+
+
+def softmax_bwd(probs, dpd, p, seed, sid, alpha):
+    t = probs.shape[-1]
+    rows = probs.numel() // t
+    ds = empty(probs.shape, BF16, probs)
+    L.call("mc_softmax_bwd", _p(probs), _p(dpd), rows, t, float(p), int(seed), int(sid), float(alpha), _p(ds), _st())
+    return ds
+
+
+def gelu_fwd(x):
+    y = torch.empty_like(x)
+    L.call("mc_gelu_fwd", _p(x), _p(y), x.numel(), _st())
+    return y
+
+
+def gelu_bwd(dy, x):
+    dx = torch.empty_like(x)
+    L.call("mc_gelu_bwd", _p(dy), _p(x), _p(dx), x.numel(), _st())
+    return dx
+
+
+def mask_bias(mask):
+    out = empty(mask.shape, torch.float32, mask)
+    L.call("mc_mask_bias", _p(mask), _p(out), mask.numel(), _st())
+    return out
+
+
+def eos_gather(hid, mask, b, t, h):
+    out = empty((b, h), torch.float32, hid)
+    L.call("mc_eos_gather", _p(hid), _p(mask), b, t, h, _p(out), _st())
+    return out
+
+
+def eos_scatter(dout, mask, b, t, h):
+    dh = empty((b * t, h), BF16, dout)
+    L.call("mc_eos_scatter", _p(dout), _p(mask), b, t, h, _p(dh), _st())
+    return dh
+
+
+# ------------------------------------------------------------------------------------------- heads / loss
+def sgemm(a, ars, acs, b, brs, bcs, c, ldc, m, n, k, alpha=1.0, beta=0.0, bias=None):
+    L.call("mc_sgemm", _p(a), ars, acs, _p(b), brs, bcs, _p(c), ldc, m, n, k, float(alpha), float(beta), _p(bias), _st())
+
+
+def l2norm_fwd(x):
+    rows, d = x.shape
+    y = torch.empty_like(x)
+    norm = empty((rows,), torch.float32, x)
+    L.call("mc_l2norm_fwd", _p(x), rows, d, _p(y), _p(norm), _st())
+    return y, norm
+
+
+def l2norm_bwd(dy, y, norm):
+    rows, d = y.shape
+    dx = torch.empty_like(y)
+    L.call("mc_l2norm_bwd", _p(dy.contiguous()), _p(y), _p(norm), rows, d, _p(dx), _st())
+    return dx
+
+
+def ce_fwd_bwd(logits, label_offset, w, loss_out):
+    rows, n = logits.shape
+    L.call("mc_ce_fwd_bwd", _p(logits), rows, n, int(label_offset), float(w), _p(loss_out), _st())

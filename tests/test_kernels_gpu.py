@@ -1,0 +1,468 @@
+"""Op-level parity of every HIP kernel (through the C ABI) against plain PyTorch fp32 references of the
+same op, on seeded inputs.  GPU only (`pytest -m gpu`).
+
+Tolerances: kernels compute in fp32 from bf16 operands and round the result once to bf16, so the bound is
+bf16 round-off: max-abs error <= 1e-2 * max|ref| (2^-8 = 3.9e-3 per rounding) unless noted; fp32-in/fp32-out
+kernels are held to 1e-4.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+if not torch.cuda.is_available():
+    pytest.skip("needs a HIP device", allow_module_level=True)
+
+import mammo_clip_amd  # noqa: E402,F401
+from mammo_clip_amd import ops  # noqa: E402
+
+DEV = torch.device("cuda:0")
+BF = torch.bfloat16
+
+
+def rnd(*shape, seed=0, scale=1.0, dtype=BF):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(DEV).to(dtype)
+
+
+def relerr(got, ref):
+    got, ref = got.float(), ref.float()
+    return float((got - ref).abs().max() / (ref.abs().max() + 1e-12))
+
+
+def check(got, ref, tol, what=""):
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    assert torch.isfinite(got.float()).all(), what + ": non-finite"
+    e = relerr(got, ref)
+    assert e <= tol, f"{what}: rel err {e:.3e} > {tol}"
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("M,N,K", [(300, 144, 24), (1000, 24, 144), (257, 40, 240), (129, 1408, 352),
+                                   (512, 768, 768), (77, 16, 16), (4096, 304, 1824), (130, 64, 48)])
+def test_gemm_nt(M, N, K):
+    x, w = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5)
+    y = ops.linear_fwd(x, w)
+    check(y, x.float() @ w.float().T, 1e-2, "nt")
+
+
+def test_gemm_nt_asymmetric_identity():
+    # A = I catches an output transpose (cdna guide: always test with asymmetric B)
+    n = 128
+    a = torch.eye(n, device=DEV).to(BF)
+    b = (torch.arange(n * n, device=DEV).reshape(n, n) % 61).float().to(BF)
+    y = ops.linear_fwd(a, b)
+    check(y, b.float().T, 1e-6, "identity")
+
+
+def test_gemm_bias_gelu_residual_stats():
+    M, N, K = 700, 3072, 768
+    x, w = rnd(M, K, seed=3), rnd(N, K, seed=4, scale=K ** -0.5)
+    bias = rnd(N, seed=5, dtype=torch.float32)
+    y = ops.linear_fwd(x, w, bias=bias, act=1)
+    check(y, F.gelu(x.float() @ w.float().T + bias), 1e-2, "bias+gelu")
+    res = rnd(M, 768, seed=6)
+    w2 = rnd(768, N, seed=7, scale=N ** -0.5)
+    y2 = ops.linear_fwd(y, w2, bias=bias[:768].contiguous(), residual=res)
+    ref2 = (y.float() @ w2.float().T + bias[:768]).to(BF).float() + res.float()
+    check(y2, ref2, 1e-2, "residual")
+    y3, part = ops.linear_fwd(x, w, stats=True)
+    s = part.double().sum(0)
+    yf = y3.float().double()
+    check(s[0].float(), yf.sum(0).float(), 1e-4, "colsum")
+    check(s[1].float(), (yf * yf).sum(0).float(), 1e-4, "colsumsq")
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 24, 144), (1000, 240, 40), (513, 352, 1408), (64, 768, 3072)])
+def test_gemm_dgrad_nn(M, N, K):
+    dy, w = rnd(M, N, seed=8), rnd(N, K, seed=9, scale=N ** -0.5)
+    res = rnd(M, K, seed=10)
+    dx = ops.linear_dgrad(dy, w, residual=res)
+    ref = (dy.float() @ w.float()).to(BF).float() + res.float()
+    check(dx, ref, 1e-2, "dgrad")
+
+
+@pytest.mark.parametrize("M,N,K", [(5000, 144, 24), (3000, 24, 144), (70000, 240, 40), (1392, 1824, 304), (999, 48, 32)])
+def test_gemm_wgrad_tn(M, N, K):
+    dy, x = rnd(M, N, seed=11), rnd(M, K, seed=12)
+    dw = ops.linear_wgrad(dy, x)
+    check(dw, dy.float().T @ x.float(), 2e-3, "wgrad")
+
+
+def test_gemm_prologue_a_and_b():
+    n_img, hw, Cc, N = 3, 50, 144, 24
+    M = n_img * hw
+    d = rnd(M, Cc, seed=13)
+    scale, shift = rnd(Cc, seed=14, dtype=torch.float32) * 0.5 + 1.0, rnd(Cc, seed=15, dtype=torch.float32) * 0.3
+    gate = torch.sigmoid(rnd(n_img, Cc, seed=16, dtype=torch.float32))
+    w = rnd(N, Cc, seed=17, scale=Cc ** -0.5)
+    a1 = (F.silu(d.float() * scale + shift).view(n_img, hw, Cc) * gate[:, None, :]).view(M, Cc).to(BF).float()
+    y = ops.linear_fwd(d, w, pro=(scale, shift, gate, hw))
+    check(y, a1 @ w.float().T, 1e-2, "prologue A")
+    dy = rnd(M, N, seed=18)
+    dw = ops.linear_wgrad(dy, d, pro=(scale, shift, gate, hw))
+    check(dw, dy.float().T @ a1, 2e-3, "prologue B")
+    y2 = ops.linear_fwd(d, w, pro=(scale, shift, None, hw))
+    check(y2, F.silu(d.float() * scale + shift).to(BF).float() @ w.float().T, 1e-2, "prologue A no gate")
+
+
+def test_gemm_batched_attention_shapes():
+    b, nh, T, hd = 2, 3, 64, 64
+    H = nh * hd
+    qkv = rnd(b * T, 3 * H, seed=19)
+    maskb = torch.zeros(b, T, device=DEV)
+    maskb[1, 40:] = -3.0e38
+    scores = torch.empty(b, nh, T, T, device=DEV, dtype=torch.float32)
+    ops.gemm(qkv, qkv[:, H:], scores, T, T, hd, 3 * H, 3 * H, T, c_f32=1, batch=b * nh, nb2=nh,
+             sA=(T * 3 * H, hd), sB=(T * 3 * H, hd), sC=(nh * T * T, T * T), bias=maskb, bias_stride1=T, alpha=0.125)
+    q = qkv[:, :H].float().view(b, T, nh, hd).permute(0, 2, 1, 3)
+    k = qkv[:, H:2 * H].float().view(b, T, nh, hd).permute(0, 2, 1, 3)
+    v = qkv[:, 2 * H:].float().view(b, T, nh, hd).permute(0, 2, 1, 3)
+    ref = q @ k.transpose(-1, -2) * 0.125 + maskb[:, None, None, :]
+    check(scores.clamp_min(-1e4), ref.clamp_min(-1e4), 1e-4, "qk^T")
+    assert float(scores[1, :, :, 40:].max()) < -1e37
+    probs = torch.softmax(ref, -1).to(BF)
+    ctx = torch.empty(b * T, H, device=DEV, dtype=BF)
+    ops.gemm(probs, qkv[:, 2 * H:], ctx, T, hd, T, T, 3 * H, H, b_kmajor=1, batch=b * nh, nb2=nh,
+             sA=(nh * T * T, T * T), sB=(T * 3 * H, hd), sC=(T * H, hd))
+    refctx = (probs.float() @ v).permute(0, 2, 1, 3).reshape(b * T, H)
+    check(ctx, refctx, 1e-2, "pv")
+    # dV = P^T dO  (a_kmajor + b_kmajor), written into the v-columns of a [b*T, 3H] buffer
+    do = rnd(b * T, H, seed=20)
+    dqkv = torch.zeros(b * T, 3 * H, device=DEV, dtype=BF)
+    ops.gemm(probs, do, dqkv[:, 2 * H:], T, hd, T, T, H, 3 * H, a_kmajor=1, b_kmajor=1, batch=b * nh, nb2=nh,
+             sA=(nh * T * T, T * T), sB=(T * H, hd), sC=(T * 3 * H, hd))
+    dov = do.float().view(b, T, nh, hd).permute(0, 2, 1, 3)
+    refdv = (probs.float().transpose(-1, -2) @ dov).permute(0, 2, 1, 3).reshape(b * T, H)
+    check(dqkv[:, 2 * H:], refdv, 1e-2, "dv")
+    assert float(dqkv[:, :2 * H].abs().max()) == 0.0
+
+
+# ------------------------------------------------------------------------------------------------ stem
+@pytest.mark.parametrize("nhwc_view", [False, True])
+def test_stem_im2col_gemm(nhwc_view):
+    n, h, w, c0 = 2, 37, 30, 48
+    g = torch.Generator().manual_seed(21)
+    if nhwc_view:
+        x = torch.randn(n, h, w, 3, generator=g).to(DEV).permute(0, 3, 1, 2)   # trainer_ddp.py:288-291
+    else:
+        x = torch.randn(n, 3, h, w, generator=g).to(DEV)
+    wt = rnd(c0, 3, 3, 3, seed=22, dtype=torch.float32)
+    pad = (0, 1, 0, 1)
+    oh, ow = (h + 1 - 3) // 2 + 1, (w + 1 - 3) // 2 + 1
+    patches = ops.stem_im2col(x, pad[0], pad[2], oh, ow)
+    wb = ops.stem_weight_prep(wt)
+    y = ops.linear_fwd(patches, wb)
+    ref = F.conv2d(F.pad(x.to(BF).float(), pad), wt.to(BF).float(), None, 2)
+    check(y.view(n, oh, ow, c0).permute(0, 3, 1, 2), ref, 1e-2, "stem")
+
+
+# ------------------------------------------------------------------------------------------------ depthwise
+DW_CASES = [(3, 1, (1, 1, 1, 1), 2, 19, 23, 48), (5, 1, (2, 2, 2, 2), 2, 17, 9, 240), (3, 2, (0, 1, 0, 1), 2, 20, 18, 144),
+            (5, 2, (1, 2, 1, 2), 1, 21, 19, 40), (3, 2, (1, 1, 1, 1), 2, 9, 9, 72), (5, 2, (2, 2, 2, 2), 1, 15, 15, 16),
+            (5, 1, (2, 2, 2, 2), 1, 40, 33, 16)]
+
+
+def _dw_ref(x_nhwc, w, k, s, pad, pro):
+    n, h, wd, c = x_nhwc.shape
+    xin = x_nhwc.float()
+    if pro is not None:
+        xin = F.silu(xin * pro[0] + pro[1]).to(BF).float()
+    xin = xin.permute(0, 3, 1, 2)
+    return F.conv2d(F.pad(xin, pad), w, None, s, 0, 1, c)
+
+
+@pytest.mark.parametrize("k,s,pad,n,h,w,c", DW_CASES)
+@pytest.mark.parametrize("use_pro", [False, True])
+def test_dwconv_fwd(k, s, pad, n, h, w, c, use_pro):
+    x = rnd(n, h, w, c, seed=23)
+    wt = rnd(c, 1, k, k, seed=24, dtype=torch.float32) * 0.3
+    pro = None
+    if use_pro:
+        pro = (rnd(c, seed=25, dtype=torch.float32) * 0.3 + 1.0, rnd(c, seed=26, dtype=torch.float32) * 0.3)
+    ref = _dw_ref(x, wt, k, s, pad, pro)
+    oh, ow = ref.shape[2], ref.shape[3]
+    w_kkc = wt.view(c, k * k).t().contiguous()
+    y, part = ops.dwconv_fwd(x.view(-1, c), w_kkc, n, h, w, c, k, s, pad[0], pad[2], oh, ow, pro=pro, stats=True)
+    check(y.view(n, oh, ow, c).permute(0, 3, 1, 2), ref, 1e-2, "dw fwd")
+    st = part.double().sum(0)
+    yf = y.float().double()
+    check(st[0].float(), yf.sum(0).float(), 1e-4, "dw colsum")
+    check(st[1].float(), (yf * yf).sum(0).float(), 1e-4, "dw colsumsq")
+
+
+@pytest.mark.parametrize("k,s,pad,n,h,w,c", DW_CASES)
+def test_dwconv_bwd(k, s, pad, n, h, w, c):
+    x = rnd(n, h, w, c, seed=27)
+    wt = rnd(c, 1, k, k, seed=28, dtype=torch.float32) * 0.3
+    pro = (rnd(c, seed=29, dtype=torch.float32) * 0.3 + 1.0, rnd(c, seed=30, dtype=torch.float32) * 0.3)
+    a = F.silu(x.float() * pro[0] + pro[1]).to(BF).float().permute(0, 3, 1, 2).requires_grad_(True)
+    wr = wt.clone().requires_grad_(True)
+    y = F.conv2d(F.pad(a, pad), wr, None, s, 0, 1, c)
+    oh, ow = y.shape[2], y.shape[3]
+    dy = rnd(n, oh, ow, c, seed=31)
+    y.backward(dy.float().permute(0, 3, 1, 2))
+    w_kkc = wt.view(c, k * k).t().contiguous()
+    w_flip = wt.flip(2, 3).reshape(c, k * k).t().contiguous()
+    dx = ops.dwconv_bwd_data(dy.view(-1, c), w_kkc, n, h, w, c, k, s, pad[0], pad[2], oh, ow)
+    check(dx.view(n, h, w, c).permute(0, 3, 1, 2), a.grad, 1e-2, "dw bwd data (gather)")
+    if s == 1:
+        dx2 = ops.dwconv_bwd_data(dy.view(-1, c), w_kkc, n, h, w, c, k, s, pad[0], pad[2], oh, ow, w_kkc_flipped=w_flip)
+        check(dx2.view(n, h, w, c).permute(0, 3, 1, 2), a.grad, 1e-2, "dw bwd data (flipped fwd)")
+    dw = ops.dwconv_bwd_weight(x.view(-1, c), dy.view(-1, c), n, h, w, c, k, s, pad[0], pad[2], oh, ow, pro=pro)
+    check(dw.t().reshape(c, 1, k, k), wr.grad, 2e-3, "dw bwd weight")
+
+
+# ------------------------------------------------------------------------------------------------ BN family
+@pytest.mark.parametrize("n_img,hw,c", [(3, 50, 48), (2, 333, 240), (4, 9, 3072), (1, 1000, 16)])
+def test_bn_train_fwd_bwd(n_img, hw, c):
+    M = n_img * hw
+    x = rnd(M, c, seed=32) * 1.5 + 0.3
+    gamma = rnd(c, seed=33, dtype=torch.float32) * 0.2 + 1.0
+    beta = rnd(c, seed=34, dtype=torch.float32) * 0.2
+    rm0, rv0 = rnd(c, seed=35, dtype=torch.float32) * 0.1, torch.rand(c, device=DEV) + 0.5
+    # statistics via the GEMM epilogue path are tested elsewhere; here use column sums directly
+    xf = x.float()
+    part = torch.stack([xf.sum(0), (xf * xf).sum(0)])[None].contiguous()
+    rm, rv = rm0.clone(), rv0.clone()
+    st = ops.bn_finalize(part, M, gamma, beta, rm, rv, 0.01, 1e-3, True)
+    rm_ref, rv_ref = rm0.clone(), rv0.clone()
+    xr = xf.clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    z = F.batch_norm(xr, rm_ref, rv_ref, gr, br, True, 0.01, 1e-3)
+    check(rm, rm_ref, 1e-4, "running mean")
+    check(rv, rv_ref, 1e-4, "running var")
+    check(st.scale * xf + st.shift, z.detach(), 1e-4, "bn affine")
+    # forward apply with SiLU + rowscale + residual
+    rs = torch.tensor([1.25, 0.0, 1.25, 1.25][:n_img], device=DEV)
+    res = rnd(M, c, seed=36)
+    out = ops.bnact_apply(x, n_img, hw, c, st.scale, st.shift, 1, rowscale=rs, res=res)
+    ref = (F.silu(z.detach()).view(n_img, hw, c) * rs[:, None, None]).view(M, c) + res.float()
+    check(out, ref, 1e-2, "bnact apply")
+    pooled = ops.bnact_pool(x, n_img, hw, c, st.scale, st.shift, 1)
+    check(pooled, F.silu(z.detach()).view(n_img, hw, c).mean(1), 1e-4, "bnact pool")
+    # backward: y = silu(z) ; upstream = g*mul + add
+    g = rnd(M, c, seed=37)
+    mul = torch.sigmoid(rnd(n_img, c, seed=38, dtype=torch.float32))
+    add = rnd(n_img, c, seed=39, dtype=torch.float32) * 0.01
+    up = (g.float().view(n_img, hw, c) * mul[:, None, :] + add[:, None, :]).view(M, c)
+    F.silu(z).backward(up)
+    dx, dgamma, dbeta = ops.bnact_bwd(x, n_img, hw, c, st, gamma, 1, g=g, mul=mul, add=add)
+    check(dx, xr.grad, 1.5e-2, "bn bwd dx")
+    check(dgamma, gr.grad, 2e-3, "bn bwd dgamma")
+    check(dbeta, br.grad, 2e-3, "bn bwd dbeta")
+    dgate = ops.bnact_se_dgate(x, g, n_img, hw, c, st.scale, st.shift, 1)
+    check(dgate, (g.float() * F.silu(z.detach())).view(n_img, hw, c).sum(1), 1e-4, "se dgate")
+
+
+def test_bn_bwd_plain_rowscale_and_broadcast():
+    n_img, hw, c = 3, 77, 40
+    M = n_img * hw
+    x = rnd(M, c, seed=40)
+    gamma, beta = rnd(c, seed=41, dtype=torch.float32) * 0.2 + 1.0, rnd(c, seed=42, dtype=torch.float32) * 0.2
+    xf = x.float()
+    part = torch.stack([xf.sum(0), (xf * xf).sum(0)])[None].contiguous()
+    st = ops.bn_finalize(part, M, gamma, beta, None, None, 0.01, 1e-3, False)
+    xr, gr, br = xf.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    z = F.batch_norm(xr, None, None, gr, br, True, 0.01, 1e-3)
+    rs = torch.tensor([1.25, 0.0, 1.25], device=DEV)
+    g = rnd(M, c, seed=43)
+    (z.view(n_img, hw, c) * rs[:, None, None]).backward(g.float().view(n_img, hw, c))
+    dx, dgamma, dbeta = ops.bnact_bwd(x, n_img, hw, c, st, gamma, 0, g=g, rowscale=rs)
+    check(dx, xr.grad, 1.5e-2, "bn2 bwd dx")
+    check(dgamma, gr.grad, 2e-3, "bn2 dgamma")
+    check(dbeta, br.grad, 2e-3, "bn2 dbeta")
+    # head: pooled-mean broadcast gradient
+    xr.grad = None; gr.grad = None; br.grad = None
+    z = F.batch_norm(xr, None, None, gr, br, True, 0.01, 1e-3)
+    dpool = rnd(n_img, c, seed=44, dtype=torch.float32)
+    F.silu(z).view(n_img, hw, c).mean(1).backward(dpool)
+    dx, dgamma, dbeta = ops.bnact_bwd(x, n_img, hw, c, st, gamma, 1, add=dpool / hw)
+    check(dx, xr.grad, 1.5e-2, "head bwd dx")
+    check(dgamma, gr.grad, 2e-3, "head dgamma")
+
+
+def test_bn_eval_coeffs():
+    c = 48
+    gamma, beta = rnd(c, seed=45, dtype=torch.float32), rnd(c, seed=46, dtype=torch.float32)
+    rm, rv = rnd(c, seed=47, dtype=torch.float32), torch.rand(c, device=DEV) + 0.5
+    st = ops.bn_eval_coeffs(gamma, beta, rm, rv, 1e-3)
+    x = rnd(10, c, seed=48, dtype=torch.float32)
+    check(x * st.scale + st.shift, F.batch_norm(x, rm, rv, gamma, beta, False, 0.0, 1e-3), 1e-5, "eval coeffs")
+
+
+@pytest.mark.parametrize("n,c,cs", [(3, 48, 12), (2, 3072, 128), (5, 144, 6)])
+def test_se_fwd_bwd(n, c, cs):
+    pooled = rnd(n, c, seed=49, dtype=torch.float32).requires_grad_(True)
+    w1 = (rnd(cs, c, seed=50, dtype=torch.float32) * c ** -0.5).requires_grad_(True)
+    b1 = (rnd(cs, seed=51, dtype=torch.float32) * 0.1).requires_grad_(True)
+    w2 = (rnd(c, cs, seed=52, dtype=torch.float32) * cs ** -0.5).requires_grad_(True)
+    b2 = (rnd(c, seed=53, dtype=torch.float32) * 0.1).requires_grad_(True)
+    gate_ref = torch.sigmoid(F.linear(F.silu(F.linear(pooled, w1, b1)), w2, b2))
+    gate = ops.se_fwd(pooled.detach(), w1.detach(), b1.detach(), w2.detach(), b2.detach())
+    check(gate, gate_ref.detach(), 1e-5, "se gate")
+    dgate = rnd(n, c, seed=54, dtype=torch.float32)
+    gate_ref.backward(dgate)
+    dp, dw1, db1, dw2, db2 = ops.se_bwd(pooled.detach(), gate, dgate, w1.detach(), b1.detach(), w2.detach(), b2.detach())
+    for got, ref, nm in [(dp, pooled.grad, "dpooled"), (dw1, w1.grad, "dw1"), (db1, b1.grad, "db1"),
+                         (dw2, w2.grad, "dw2"), (db2, b2.grad, "db2")]:
+        check(got, ref, 1e-4, "se " + nm)
+
+
+def test_misc_cast_transpose_colsum_dropout():
+    x = rnd(1000, 7, seed=55, dtype=torch.float32)
+    assert torch.equal(ops.cast_bf16(x), x.to(BF))
+    assert torch.equal(ops.cast_f32(x.to(BF)), x.to(BF).float())
+    assert torch.equal(ops.transpose_f32(x), x.t().contiguous())
+    m = rnd(5000, 240, seed=56)
+    check(ops.colsum(m), m.float().sum(0), 1e-4, "colsum")
+    m2 = rnd(33, 3072, seed=57)
+    check(ops.colsum(m2), m2.float().sum(0), 1e-4, "colsum wide")
+    v = torch.ones(200000, device=DEV)
+    d1, d2 = ops.dropout_f32(v, 0.4, 1234, 7), ops.dropout_f32(v, 0.4, 1234, 7)
+    assert torch.equal(d1, d2)
+    keep = float((d1 > 0).float().mean())
+    assert abs(keep - 0.6) < 0.01, keep
+    assert abs(float(d1.max()) - 1 / 0.6) < 1e-5
+    assert not torch.equal(d1, ops.dropout_f32(v, 0.4, 1234, 8))
+
+
+# ------------------------------------------------------------------------------------------------ BERT pieces
+def test_bert_embed_fwd_bwd():
+    b, t, h, vocab = 3, 16, 64, 50
+    g = torch.Generator().manual_seed(58)
+    ids = torch.randint(0, vocab, (b, t), generator=g).to(DEV)
+    tt = torch.zeros_like(ids)
+    tt[0, 5:] = 1
+    word = rnd(vocab, h, seed=59, dtype=torch.float32).requires_grad_(True)
+    pos = rnd(32, h, seed=60, dtype=torch.float32).requires_grad_(True)
+    typ = rnd(2, h, seed=61, dtype=torch.float32).requires_grad_(True)
+    gamma = (rnd(h, seed=62, dtype=torch.float32) * 0.1 + 1).requires_grad_(True)
+    beta = (rnd(h, seed=63, dtype=torch.float32) * 0.1).requires_grad_(True)
+    ref = F.layer_norm(word[ids] + pos[torch.arange(t, device=DEV)][None] + typ[tt], (h,), gamma, beta, 1e-12)
+    y, mean, rstd = ops.bert_embed_fwd(ids, tt, word.detach(), pos.detach(), typ.detach(), gamma.detach(), beta.detach(),
+                                       1e-12, 0.0, 1, 0)
+    check(y.view(b, t, h), ref.detach(), 1e-2, "embed fwd")
+    dy = rnd(b * t, h, seed=64)
+    ref.backward(dy.float().view(b, t, h))
+    dword, dpos, dtyp, dgamma, dbeta = ops.bert_embed_bwd(dy, ids, tt, word.detach(), pos.detach(), typ.detach(),
+                                                          gamma.detach(), mean, rstd, 0.0, 1, 0)
+    for got, refg, nm in [(dword, word.grad, "dword"), (dpos, pos.grad, "dpos"), (dtyp, typ.grad, "dtype"),
+                          (dgamma, gamma.grad, "dgamma"), (dbeta, beta.grad, "dbeta")]:
+        check(got, refg, 2e-3, "embed " + nm)
+
+
+@pytest.mark.parametrize("rows,h", [(37, 64), (300, 768)])
+def test_add_ln_fwd_bwd(rows, h):
+    x, res = rnd(rows, h, seed=65), rnd(rows, h, seed=66)
+    gamma = (rnd(h, seed=67, dtype=torch.float32) * 0.1 + 1).requires_grad_(True)
+    beta = (rnd(h, seed=68, dtype=torch.float32) * 0.1).requires_grad_(True)
+    xr, rr = x.float().requires_grad_(True), res.float().requires_grad_(True)
+    ref = F.layer_norm(xr + rr, (h,), gamma, beta, 1e-12)
+    y, mean, rstd = ops.add_ln_fwd(x, res, gamma.detach(), beta.detach(), 1e-12, 0.0, 1, 0)
+    check(y, ref.detach(), 1e-2, "add_ln fwd")
+    dy = rnd(rows, h, seed=69)
+    ref.backward(dy.float())
+    dx, dres, dgamma, dbeta = ops.add_ln_bwd(dy, x, res, gamma.detach(), mean, rstd, 0.0, 1, 0)
+    check(dx, xr.grad, 1.5e-2, "add_ln dx")
+    check(dres, rr.grad, 1.5e-2, "add_ln dres")
+    check(dgamma, gamma.grad, 2e-3, "add_ln dgamma")
+    check(dbeta, beta.grad, 2e-3, "add_ln dbeta")
+
+
+def test_add_ln_dropout_consistency():
+    rows, h, p = 64, 768, 0.1
+    x, res = rnd(rows, h, seed=70), torch.zeros(rows, h, device=DEV, dtype=BF)
+    gamma, beta = torch.ones(h, device=DEV), torch.zeros(h, device=DEV)
+    y1, m1, r1 = ops.add_ln_fwd(x, res, gamma, beta, 1e-12, p, 99, 3)
+    y2, _, _ = ops.add_ln_fwd(x, res, gamma, beta, 1e-12, p, 99, 3)
+    assert torch.equal(y1, y2)
+    # the mask used by backward equals the forward mask: d/dx of sum(dres) only flows through kept elements
+    dy = rnd(rows, h, seed=71)
+    dx, dres, _, _ = ops.add_ln_bwd(dy, x, res, gamma, m1, r1, p, 99, 3)
+    ratio = dx.float() / dres.float().clamp_min(1e-30).where(dres.float().abs() > 1e-3, torch.ones_like(dres.float()))
+    kept = (dx.float().abs() > 0) | (dres.float().abs() <= 1e-3)
+    frac = float(((dx.float().abs() > 0) & (dres.float().abs() > 1e-3)).float().sum() / (dres.float().abs() > 1e-3).float().sum())
+    assert abs(frac - 0.9) < 0.02, frac
+    sel = (dx.float().abs() > 0) & (dres.float().abs() > 1e-3)
+    assert float((ratio[sel] - 1 / 0.9).abs().max()) < 2e-2
+    assert kept.any()
+
+
+def test_softmax_fwd_bwd():
+    rows, t = 300, 256
+    s = rnd(rows, t, seed=72, dtype=torch.float32) * 3
+    s[:, 200:] = -3.0e38
+    sr = s.clone().requires_grad_(True)
+    ref = torch.softmax(sr, -1)
+    probs, pd = ops.softmax_fwd(s, 0.0, 1, 0)
+    assert pd.data_ptr() == probs.data_ptr()
+    check(probs, ref.detach(), 1e-2, "softmax")
+    dp = rnd(rows, t, seed=73, dtype=torch.float32)
+    ref.backward(dp)
+    ds = ops.softmax_bwd(ref.detach().to(BF), dp, 0.0, 1, 0, 0.125)
+    refds = sr.grad * 0.125
+    # reference computed from the bf16-rounded probabilities the kernel sees
+    pb = ref.detach().to(BF).float()
+    refds2 = pb * (dp - (pb * dp).sum(-1, keepdim=True)) * 0.125
+    check(ds, refds2, 1e-2, "softmax bwd")
+    assert relerr(ds, refds) < 5e-2
+    probs2, pd2 = ops.softmax_fwd(s, 0.1, 5, 2)
+    nz = float((pd2[:, :200].float() > 0).float().mean())
+    assert abs(nz - 0.9) < 0.02, nz
+
+
+def test_gelu_mask_eos():
+    x = rnd(100, 3072, seed=74)
+    check(ops.gelu_fwd(x), F.gelu(x.float()), 1e-2, "gelu")
+    xr = x.float().requires_grad_(True)
+    dy = rnd(100, 3072, seed=75)
+    F.gelu(xr).backward(dy.float())
+    check(ops.gelu_bwd(dy, x), xr.grad, 1e-2, "gelu bwd")
+    b, t, h = 4, 16, 64
+    lens = torch.tensor([16, 3, 9, 1], device=DEV)
+    mask = (torch.arange(t, device=DEV)[None] < lens[:, None]).long()
+    mb = ops.mask_bias(mask)
+    assert float(mb[0].abs().max()) == 0 and float(mb[1, 3]) < -1e38
+    hid = rnd(b * t, h, seed=76)
+    out = ops.eos_gather(hid, mask, b, t, h)
+    ref = hid.view(b, t, h).float()[torch.arange(b, device=DEV), lens - 1]
+    assert torch.equal(out, ref)
+    dh = ops.eos_scatter(ref, mask, b, t, h).view(b, t, h).float()
+    assert torch.equal(dh[torch.arange(b, device=DEV), lens - 1], ref.to(BF).float())
+    assert float(dh.abs().sum()) == pytest.approx(float(ref.to(BF).float().abs().sum()), rel=1e-5)
+
+
+# ------------------------------------------------------------------------------------------------ heads / loss
+def test_sgemm_l2norm_ce():
+    b, d, n = 12, 512, 48
+    a, bm = rnd(b, d, seed=77, dtype=torch.float32), rnd(n, d, seed=78, dtype=torch.float32)
+    c = torch.empty(b, n, device=DEV)
+    ops.sgemm(a, d, 1, bm, 1, d, c, n, b, n, d, alpha=14.0)         # a @ bm.T * 14
+    check(c, 14.0 * a @ bm.T, 1e-5, "sgemm nt")
+    c2 = torch.ones(d, n, device=DEV)
+    ops.sgemm(a, 1, d, c, n, 1, c2, n, d, n, b, alpha=1.0, beta=0.5)   # a.T @ c + 0.5
+    check(c2, a.T @ c + 0.5, 1e-5, "sgemm tn + beta")
+    bias = rnd(n, seed=79, dtype=torch.float32)
+    c3 = torch.empty(b, n, device=DEV)
+    ops.sgemm(a, d, 1, bm, 1, d, c3, n, b, n, d, bias=bias)
+    check(c3, a @ bm.T + bias, 1e-5, "sgemm bias")
+    ar = a.clone().requires_grad_(True)
+    yref = ar / ar.norm(dim=1, keepdim=True)
+    y, nrm = ops.l2norm_fwd(a)
+    check(y, yref.detach(), 1e-5, "l2norm")
+    dy = rnd(b, d, seed=80, dtype=torch.float32)
+    yref.backward(dy)
+    check(ops.l2norm_bwd(dy, y, nrm), ar.grad, 1e-4, "l2norm bwd")
+    logits = (rnd(b, n, seed=81, dtype=torch.float32) * 3).requires_grad_(True)
+    labels = torch.arange(b, device=DEV) + 24
+    lref = 0.25 * F.cross_entropy(logits, labels)
+    lref.backward()
+    buf = logits.detach().clone()
+    loss = torch.zeros(1, device=DEV)
+    ops.ce_fwd_bwd(buf, 24, 0.25, loss)
+    check(loss[0], lref.detach(), 1e-5, "ce loss")
+    check(buf, logits.grad, 1e-4, "ce dlogits")
