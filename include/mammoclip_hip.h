@@ -141,6 +141,7 @@ typedef struct mc_bnact_args {
     const mc_bf16* g;
     const float* mul;
     const float* add;
+    float add_scale;         /* add is multiplied by this (0 is read as 1), e.g. 1/hw for pooled gradients */
     const float* mean;
     const float* invstd;
     float* partials;         /* bwd_reduce: float[mc_bnact_rows()][2][c] = (sum dz, sum dz*xhat) */
@@ -217,16 +218,20 @@ int mc_eos_scatter(const float* dout, const long long* mask, int b, int t, int h
 /* ------------------------------------------------------------------------------------------------
  * fp32 small GEMM with arbitrary strides: C[m,n] = alpha * sum_k A[m*ars + k*acs] * B[k*brs + n*bcs] + beta*C + bias[n]
  * [ref: model/modules/projection.py:23-29 (LinearProjectionHead); loss/breast_clip.py:46-100 (logits)] */
+/* alpha_dev (optional): device scalar multiplied into alpha (e.g. the learnable logit scale) */
 int mc_sgemm(const float* a, long long ars, long long acs, const float* b, long long brs, long long bcs,
              float* c, long long ldc, int m, int n, int k, float alpha, float beta, const float* bias,
-             void* stream);
+             const float* alpha_dev, void* stream);
+/* y[i] = x[i] * (*scalar_dev) * alpha */
+int mc_scale_f32(const float* x, const float* scalar_dev, float alpha, float* y, long long n, void* stream);
 /* y = x / ||x||_2 per row (no epsilon) [ref: model/clip.py:90-91]; bwd: dx = (dy - y*(y.dy)) / ||x|| */
 int mc_l2norm_fwd(const float* x, int rows, int d, float* y, float* norm, void* stream);
 int mc_l2norm_bwd(const float* dy, const float* y, const float* norm, int rows, int d, float* dx, void* stream);
 /* mean cross-entropy over rows of logits [rows, n] with labels row + label_offset, weight w:
- * loss_out[0] += w * mean_r (lse_r - logit[r, label]);  dlogits = w/rows * (softmax - onehot)  (in place)
+ * loss_out[0] += w * mean_r CE_r (label smoothing `smoothing`);  dlogits = w/rows * (softmax - target)  (in place)
  * [ref: loss/breast_clip.py:50-100 (F.cross_entropy with labels + rank*batch)] */
-int mc_ce_fwd_bwd(float* logits, int rows, int n, int label_offset, float w, float* loss_out, void* stream);
+int mc_ce_fwd_bwd(float* logits, int rows, int n, int label_offset, float w, float smoothing, float* loss_out,
+                  void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,112 @@
+"""BreastClip: image encoder + text encoder + projection heads + L2 normalisation [ref: model/clip.py:14-114].
+Same constructor, attributes (image_encoder, text_encoder, image_projection, text_projection, projection,
+logit_scale, text_pooling) and ``forward(batch, device) -> dict`` contract as the reference."""
+import logging
+import math
+from typing import Dict
+
+import torch
+from torch import nn
+
+from .. import _tokens
+from ... import ops
+from .modules import load_image_encoder, load_projection_head, load_text_encoder
+
+log = logging.getLogger(__name__)
+
+
+class _EosPoolFn(torch.autograd.Function):
+    """features[b] = hidden[b, attention_mask[b].sum() - 1]  [ref: clip.py:65-68]"""
+
+    @staticmethod
+    def forward(ctx, hid, mask):
+        b, t, h = hid.shape
+        ctx.shape = (b, t, h)
+        ctx.save_for_backward(mask)
+        return ops.eos_gather(hid.contiguous(), mask, b, t, h)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (mask,) = ctx.saved_tensors
+        b, t, h = ctx.shape
+        return ops.eos_scatter(dout.contiguous(), mask, b, t, h).view(b, t, h), None
+
+
+class _L2NormFn(torch.autograd.Function):
+    """x / ||x||_2 per row, no epsilon [ref: clip.py:90-91]"""
+
+    @staticmethod
+    def forward(ctx, x):
+        y, norm = ops.l2norm_fwd(x.contiguous())
+        ctx.save_for_backward(y, norm)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        y, norm = ctx.saved_tensors
+        return ops.l2norm_bwd(dy, y, norm)
+
+
+class BreastClip(nn.Module):
+    def __init__(self, model_config: Dict, all_loss_config: Dict, tokenizer=None):
+        super().__init__()
+        self.tokenizer = tokenizer
+        self.image_encoder = load_image_encoder(model_config["image_encoder"])
+        vocab = tokenizer.vocab_size if tokenizer is not None else None
+        self.text_encoder = load_text_encoder(model_config["text_encoder"], vocab_size=vocab)
+        self.text_pooling = model_config["text_encoder"]["pooling"]
+        self.model_config = model_config
+        self.loss_config = {k: v for k, v in all_loss_config.items()}
+        self.projection = "projection_head" in model_config
+        if self.projection:
+            self.image_projection = load_projection_head(self.image_encoder.out_dim, model_config["projection_head"])
+            self.text_projection = load_projection_head(self.text_encoder.out_dim, model_config["projection_head"])
+        else:
+            assert self.image_encoder.out_dim == self.text_encoder.out_dim, \
+                "Without 'projection_head', embedding_dim of the image and text encoder must be the same."
+        self.temperature = model_config["temperature"] if "temperature" in model_config else None
+        if self.temperature:
+            self.logit_scale = nn.Parameter(torch.ones([]) * math.log(1 / self.temperature))
+        else:
+            self.logit_scale = torch.tensor(1, dtype=torch.float32)
+            log.warning("[Mammo-CLIP] missing temperature scaling factor")
+
+    def encode_image(self, image):
+        feats = self.image_encoder(image)
+        if self.model_config["image_encoder"]["model_type"].lower() == "cnn":
+            return feats
+        return feats[:, 0]
+
+    def encode_image_normalized(self, image):
+        emb = self.encode_image(image)
+        emb = self.image_projection(emb) if self.projection else emb
+        return _L2NormFn.apply(emb)
+
+    def encode_text(self, text_tokens):
+        hid = self.text_encoder(text_tokens)
+        if self.text_pooling == "eos":
+            return _EosPoolFn.apply(hid, text_tokens["attention_mask"])
+        if self.text_pooling == "bos":
+            return hid[:, 0].float()
+        if self.text_pooling == "mean":
+            m = text_tokens["attention_mask"].unsqueeze(-1).expand(hid.size()).float()
+            return torch.sum(hid.float() * m, dim=1) / torch.clamp(m.sum(dim=1), min=1e-9)
+        raise NotImplementedError("Not supported pooling method : %s", self.text_pooling)
+
+    def forward(self, batch, device=None):
+        device = batch["images"].device if device is None else device
+        img = self.encode_image(batch["images"].to(device))
+        txt = self.encode_text(_tokens.to_device(batch["text_tokens"], device))
+        img_e = self.image_projection(img) if self.projection else img
+        txt_e = self.text_projection(txt) if self.projection else txt
+        img_e, txt_e = _L2NormFn.apply(img_e), _L2NormFn.apply(txt_e)
+        out = {"image_embeddings": img_e, "text_embeddings": txt_e,
+               "labels": torch.arange(img_e.shape[0], device=device), "logit_scale": self.logit_scale.exp()}
+        if "text_tokens2" in batch and "image_views" in batch:
+            txt2 = self.encode_text(_tokens.to_device(batch["text_tokens2"], device))
+            txt2_e = self.text_projection(txt2) if self.projection else txt      # [ref quirk: clip.py:105]
+            out["text_embeddings2"] = _L2NormFn.apply(txt2_e)
+            view = self.encode_image(batch["image_views"].to(device))
+            view_e = self.image_projection(view) if self.projection else view
+            out["image_view_embeddings"] = _L2NormFn.apply(view_e)
+        return out

@@ -1,0 +1,461 @@
+"""EfficientNet-B2/B5 image encoder on hand-written gfx950 kernels.
+
+Mirrors the public surface of the reference module of the same name (class names ``EfficientNet`` /
+``MBConvBlock``, ``from_name`` / ``from_pretrained``, ``extract_features``, ``forward`` incl. the
+``{"image": x}`` dict form, and -- crucially -- the ``state_dict`` key layout ``_conv_stem.weight``,
+``_bn0.*``, ``_blocks.{i}._expand_conv.weight`` ...; reference: model/modules/efficientnet_custom.py and
+efficient_net_custom_utils.py), but nothing below is a translation of it:
+
+  * activations live in HBM as NHWC bf16 ``[n*h*w, c]``; every 1x1 conv is one MFMA GEMM over pixels
+  * training-mode BatchNorm statistics come out of the producing kernel's epilogue, the BN+SiLU of the
+    expand conv is applied while the depthwise kernel stages its LDS halo tile, the BN+SiLU+SE-gate of the
+    depthwise output is applied while the project GEMM stages its A operand: the activated expanded
+    tensors never exist in HBM, forward or backward (they are recomputed from the saved conv outputs)
+  * one ``torch.autograd.Function`` per stem / MBConv block / head, with a hand-derived backward
+
+Parameters are ordinary fp32 ``nn.Parameter``s held in ``nn.Conv2d`` / ``nn.BatchNorm2d`` containers (their
+``forward`` is never called) so optimizers, DDP and ``load_state_dict(strict=True)`` of reference
+checkpoints work unchanged.
+"""
+import math
+from collections import namedtuple
+from typing import List, Optional
+
+import torch
+from torch import nn
+
+from .... import ops
+
+BN_MOMENTUM = 0.01      # 1 - batch_norm_momentum 0.99 [ref: efficientnet_custom.py:53, efficient_net_custom_utils.py:520]
+BN_EPS = 1e-3           # [ref: efficient_net_custom_utils.py:521]
+
+VALID_MODELS = tuple(f"efficientnet-b{i}" for i in range(9)) + ("efficientnet-l2",)
+
+# (width, depth, nominal resolution, dropout) [ref: efficient_net_custom_utils.py:457-479]
+_COEFFS = {
+    "efficientnet-b0": (1.0, 1.0, 224, 0.2), "efficientnet-b1": (1.0, 1.1, 240, 0.2),
+    "efficientnet-b2": (1.1, 1.2, 260, 0.3), "efficientnet-b3": (1.2, 1.4, 300, 0.3),
+    "efficientnet-b4": (1.4, 1.8, 380, 0.4), "efficientnet-b5": (1.6, 2.2, 456, 0.4),
+    "efficientnet-b6": (1.8, 2.6, 528, 0.5), "efficientnet-b7": (2.0, 3.1, 600, 0.5),
+    "efficientnet-b8": (2.2, 3.6, 672, 0.5), "efficientnet-l2": (4.3, 5.3, 800, 0.5),
+}
+# repeats, kernel, stride, expand, in, out  (se_ratio 0.25 everywhere) [ref: efficient_net_custom_utils.py:502-510]
+_STAGES = ((1, 3, 1, 1, 32, 16), (2, 3, 2, 6, 16, 24), (2, 5, 2, 6, 24, 40), (3, 3, 2, 6, 40, 80),
+           (3, 5, 1, 6, 80, 112), (4, 5, 2, 6, 112, 192), (1, 3, 1, 6, 192, 320))
+
+GlobalParams = namedtuple("GlobalParams", ["width_coefficient", "depth_coefficient", "image_size", "dropout_rate",
+                                           "num_classes", "batch_norm_momentum", "batch_norm_epsilon",
+                                           "drop_connect_rate", "depth_divisor", "min_depth", "include_top"])
+BlockArgs = namedtuple("BlockArgs", ["num_repeat", "kernel_size", "stride", "expand_ratio", "input_filters",
+                                     "output_filters", "se_ratio", "id_skip"])
+
+
+def _scaled_width(filters, gp):
+    if not gp.width_coefficient:
+        return filters
+    f = filters * gp.width_coefficient
+    div = gp.depth_divisor
+    out = max(gp.min_depth or div, int(f + div / 2) // div * div)
+    return int(out + div) if out < 0.9 * f else int(out)
+
+
+def _scaled_depth(repeats, gp):
+    return int(math.ceil(gp.depth_coefficient * repeats)) if gp.depth_coefficient else repeats
+
+
+def _static_pad(size_hw, k, s):
+    """(left, right, top, bottom) frozen for the NOMINAL feature-map size [ref: efficient_net_custom_utils.py:262-272]."""
+    ih, iw = size_hw
+    ph = max((math.ceil(ih / s) - 1) * s + k - ih, 0)
+    pw = max((math.ceil(iw / s) - 1) * s + k - iw, 0)
+    return (pw // 2, pw - pw // 2, ph // 2, ph - ph // 2)
+
+
+def _down(size_hw, s):
+    return (int(math.ceil(size_hw[0] / s)), int(math.ceil(size_hw[1] / s)))
+
+
+def _out_extent(i, lo, hi, k, s):
+    return (i + lo + hi - k) // s + 1
+
+
+class _Seeds:
+    """Counter-based RNG bookkeeping: every stochastic site gets (seed, stream id); re-running a forward with
+    the same seed regenerates identical dropout / drop-connect masks (used by backward)."""
+    base = 0x5EED
+
+    def __init__(self):
+        self.seed = _Seeds.base
+        self.calls = 0
+
+    def next(self):
+        self.calls += 1
+        return self.seed * 1000003 + self.calls
+
+
+# ================================================================================================
+#                                      autograd functions
+# ================================================================================================
+def _bn_stats(partials, count, bn: nn.BatchNorm2d, training: bool):
+    if training:
+        st = ops.bn_finalize(partials, count, bn.weight, bn.bias, bn.running_mean, bn.running_var, BN_MOMENTUM, BN_EPS,
+                             bn.track_update)
+        if bn.track_update:
+            bn.num_batches_tracked += 1
+        return st
+    return ops.bn_eval_coeffs(bn.weight, bn.bias, bn.running_mean, bn.running_var, BN_EPS)
+
+
+class _StemFn(torch.autograd.Function):
+    """_conv_stem (3x3 s2, static pad) + _bn0 + swish [ref: efficientnet_custom.py:273]."""
+
+    @staticmethod
+    def forward(ctx, x, w, gamma, beta, mod):
+        n, _, h, wd = x.shape
+        l, r, t, b = mod.stem_pad
+        oh, ow = _out_extent(h, t, b, 3, 2), _out_extent(wd, l, r, 3, 2)
+        c0 = w.shape[0]
+        patches = ops.stem_im2col(x, l, t, oh, ow)
+        wb = ops.stem_weight_prep(w)
+        training = mod.training
+        e, part = ops.linear_fwd(patches, wb, stats=True)
+        st = _bn_stats(part, n * oh * ow, mod._bn0, training)
+        y = ops.bnact_apply(e, n, oh * ow, c0, st.scale, st.shift, 1)
+        ctx.mod, ctx.st, ctx.geo = mod, st, (n, h, wd, oh, ow, c0)
+        ctx.save_for_backward(x, e)
+        mod._geo = (n, oh, ow)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, e = ctx.saved_tensors
+        n, h, wd, oh, ow, c0 = ctx.geo
+        mod = ctx.mod
+        de, dgamma, dbeta = ops.bnact_bwd(e, n, oh * ow, c0, ctx.st, mod._bn0.weight, 1, g=dy.contiguous())
+        l, r, t, b = mod.stem_pad
+        patches = ops.stem_im2col(x, l, t, oh, ow)                 # recomputed, not stored
+        dw = ops.linear_wgrad(de, patches)                         # [c0, 32]
+        return None, dw[:, :27].reshape(c0, 3, 3, 3), dgamma, dbeta, None
+
+
+class _MBConvFn(torch.autograd.Function):
+    """One MBConvBlock, forward + hand-derived backward [ref: efficientnet_custom.py:91-132]."""
+
+    @staticmethod
+    def forward(ctx, x, rowscale, blk, n, h, w, *params):
+        a = blk.args
+        training = blk.training
+        k, s = a.k, a.s
+        l, r, t, b = a.pad
+        oh, ow = _out_extent(h, t, b, k, s), _out_extent(w, l, r, k, s)
+        hw, ohw = h * w, oh * ow
+        saved = {}
+        if a.expand != 1:
+            we = ops.cast_bf16(blk._expand_conv.weight.view(a.cexp, a.cin))
+            e, part0 = ops.linear_fwd(x, we, stats=True)
+            st0 = _bn_stats(part0, n * hw, blk._bn0, training)
+            dw_in, pro0 = e, (st0.scale, st0.shift)
+            saved.update(we=we, e=e, st0=st0)
+        else:
+            dw_in, pro0 = x, None
+        wkkc = ops.transpose_f32(blk._depthwise_conv.weight.view(a.cexp, k * k))
+        d, part1 = ops.dwconv_fwd(dw_in, wkkc, n, h, w, a.cexp, k, s, l, t, oh, ow, pro=pro0, stats=True)
+        st1 = _bn_stats(part1, n * ohw, blk._bn1, training)
+        pooled = ops.bnact_pool(d, n, ohw, a.cexp, st1.scale, st1.shift, 1)
+        gate = ops.se_fwd(pooled, blk._se_reduce.weight.view(a.cse, a.cexp), blk._se_reduce.bias,
+                          blk._se_expand.weight.view(a.cexp, a.cse), blk._se_expand.bias)
+        wp = ops.cast_bf16(blk._project_conv.weight.view(a.cout, a.cexp))
+        p, part2 = ops.linear_fwd(d, wp, stats=True, pro=(st1.scale, st1.shift, gate, ohw))
+        st2 = _bn_stats(part2, n * ohw, blk._bn2, training)
+        y = ops.bnact_apply(p, n, ohw, a.cout, st2.scale, st2.shift, 0,
+                            rowscale=rowscale if a.skip else None, res=x if a.skip else None)
+        saved.update(x=x, d=d, p=p, wkkc=wkkc, wp=wp, st1=st1, st2=st2, pooled=pooled, gate=gate,
+                     rowscale=rowscale if a.skip else None, geo=(n, h, w, oh, ow))
+        ctx.blk, ctx.saved = blk, saved
+        blk._out_geo = (n, oh, ow)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        blk, sv = ctx.blk, ctx.saved
+        a = blk.args
+        n, h, w, oh, ow = sv["geo"]
+        hw, ohw = h * w, oh * ow
+        k, s = a.k, a.s
+        l, r, t, b = a.pad
+        dy = dy.contiguous()
+        x, d, p = sv["x"], sv["d"], sv["p"]
+        st1, st2, gate, pooled = sv["st1"], sv["st2"], sv["gate"], sv["pooled"]
+        # y = bn2(p) * rowscale + x
+        dp, dg2, db2 = ops.bnact_bwd(p, n, ohw, a.cout, st2, blk._bn2.weight, 0, g=dy, rowscale=sv["rowscale"])
+        # project 1x1: p = A1 . wp^T, A1 = silu(bn1(d)) * gate   (A1 is recomputed inside the wgrad GEMM)
+        da1 = ops.linear_dgrad(dp, sv["wp"])
+        dwp = ops.linear_wgrad(dp, d, pro=(st1.scale, st1.shift, gate, ohw))
+        # squeeze-excite
+        dgate = ops.bnact_se_dgate(d, da1, n, ohw, a.cexp, st1.scale, st1.shift, 1)
+        dpooled, dw1, db1, dw2, dbse2 = ops.se_bwd(pooled, gate, dgate, blk._se_reduce.weight.view(a.cse, a.cexp),
+                                                   blk._se_reduce.bias, blk._se_expand.weight.view(a.cexp, a.cse),
+                                                   blk._se_expand.bias)
+        # bn1 + swish: upstream of swish output = dA1 * gate + dpooled / (oh*ow)
+        dd, dg1, db1n = ops.bnact_bwd(d, n, ohw, a.cexp, st1, blk._bn1.weight, 1, g=da1, mul=gate, add=dpooled,
+                                      add_scale=1.0 / ohw)
+        del da1
+        # depthwise
+        if a.expand != 1:
+            st0 = sv["st0"]
+            dw_in, pro0 = sv["e"], (st0.scale, st0.shift)
+        else:
+            dw_in, pro0 = x, None
+        dwdw = ops.dwconv_bwd_weight(dw_in, dd, n, h, w, a.cexp, k, s, l, t, oh, ow, pro=pro0)
+        wflip = sv["wkkc"].flip(0).contiguous() if s == 1 else None     # tap order reversed = 180 degree rotation
+        da0 = ops.dwconv_bwd_data(dd, sv["wkkc"], n, h, w, a.cexp, k, s, l, t, oh, ow, w_kkc_flipped=wflip)
+        del dd
+        grads = {}
+        if a.expand != 1:
+            de, dg0, db0 = ops.bnact_bwd(sv["e"], n, hw, a.cexp, st0, blk._bn0.weight, 1, g=da0)
+            del da0
+            dx = ops.linear_dgrad(de, sv["we"], residual=dy if a.skip else None)
+            dwe = ops.linear_wgrad(de, x)
+            grads["_expand_conv.weight"] = dwe.view(a.cexp, a.cin, 1, 1)
+            grads["_bn0.weight"], grads["_bn0.bias"] = dg0, db0
+        else:
+            dx = da0
+            if a.skip:
+                dx = ops.bnact_apply(da0, n, hw, a.cin, blk._ones, blk._zeros, 0, res=dy)
+        grads["_depthwise_conv.weight"] = ops.transpose_f32(dwdw).view(a.cexp, 1, k, k)
+        grads["_bn1.weight"], grads["_bn1.bias"] = dg1, db1n
+        grads["_se_reduce.weight"], grads["_se_reduce.bias"] = dw1.view(a.cse, a.cexp, 1, 1), db1
+        grads["_se_expand.weight"], grads["_se_expand.bias"] = dw2.view(a.cexp, a.cse, 1, 1), dbse2
+        grads["_project_conv.weight"] = dwp.view(a.cout, a.cexp, 1, 1)
+        grads["_bn2.weight"], grads["_bn2.bias"] = dg2, db2
+        ctx.saved = None
+        return (dx, None, None, None, None, None) + tuple(grads[nm] for nm in blk._param_names)
+
+
+class _HeadFn(torch.autograd.Function):
+    """_conv_head (1x1) + _bn1 + swish + global average pool [ref: efficientnet_custom.py:283, 307-309]."""
+
+    @staticmethod
+    def forward(ctx, x, w, gamma, beta, mod, n, h, wd):
+        cin, cout = w.shape[1], w.shape[0]
+        wb = ops.cast_bf16(w.view(cout, cin))
+        e, part = ops.linear_fwd(x, wb, stats=True)
+        st = _bn_stats(part, n * h * wd, mod._bn1, mod.training)
+        pooled = ops.bnact_pool(e, n, h * wd, cout, st.scale, st.shift, 1)
+        ctx.mod, ctx.st, ctx.geo = mod, st, (n, h, wd, cin, cout)
+        ctx.save_for_backward(x, e, wb)
+        mod._head_cache = (e, st, n, h, wd, cout)
+        return pooled
+
+    @staticmethod
+    def backward(ctx, dpooled):
+        x, e, wb = ctx.saved_tensors
+        n, h, wd, cin, cout = ctx.geo
+        mod = ctx.mod
+        de, dgamma, dbeta = ops.bnact_bwd(e, n, h * wd, cout, ctx.st, mod._bn1.weight, 1, add=dpooled.contiguous(),
+                                          add_scale=1.0 / (h * wd))
+        dx = ops.linear_dgrad(de, wb)
+        dw = ops.linear_wgrad(de, x)
+        return dx, dw.view(cout, cin, 1, 1), dgamma, dbeta, None, None, None, None
+
+
+class _DropoutFn(torch.autograd.Function):
+    """nn.Dropout on the pooled features [ref: efficientnet_custom.py:310-312]; Philox mask, regenerated in backward."""
+
+    @staticmethod
+    def forward(ctx, x, p, seed, sid):
+        ctx.cfg = (p, seed, sid)
+        return ops.dropout_f32(x.contiguous(), p, seed, sid)
+
+    @staticmethod
+    def backward(ctx, dy):
+        p, seed, sid = ctx.cfg
+        return ops.dropout_f32(dy.contiguous(), p, seed, sid), None, None, None
+
+
+# ================================================================================================
+#                                           modules
+# ================================================================================================
+class _BN(nn.BatchNorm2d):
+    """Parameter/buffer container with the reference's BatchNorm2d keys; arithmetic happens in HIP kernels."""
+
+    def __init__(self, c):
+        super().__init__(c, momentum=BN_MOMENTUM, eps=BN_EPS)
+        self.track_update = True          # engine may switch running-stat updates off for re-forward passes
+
+    def forward(self, x):                 # pragma: no cover
+        raise RuntimeError("BatchNorm arithmetic runs inside the fused HIP kernels, not here")
+
+
+class _Conv(nn.Conv2d):
+    """Parameter container (OIHW fp32) mirroring Conv2dStaticSamePadding's keys."""
+
+    def __init__(self, cin, cout, k, stride=1, groups=1, bias=False):
+        super().__init__(cin, cout, k, stride, 0, 1, groups, bias)
+
+    def forward(self, x):                 # pragma: no cover
+        raise RuntimeError("convolutions run inside the HIP kernels, not here")
+
+
+_Geo = namedtuple("_Geo", ["idx", "expand", "k", "s", "cin", "cexp", "cout", "cse", "pad", "skip"])
+
+
+class MBConvBlock(nn.Module):
+    """Mobile inverted residual bottleneck with squeeze-excite [ref: efficientnet_custom.py:36-140]."""
+
+    def __init__(self, block_args: BlockArgs, global_params: GlobalParams, image_size=None, idx: int = 0):
+        super().__init__()
+        self._block_args = block_args
+        a = block_args
+        s = a.stride if isinstance(a.stride, int) else a.stride[0]
+        cin, cexp = a.input_filters, a.input_filters * a.expand_ratio
+        cse = max(1, int(a.input_filters * a.se_ratio))
+        self.has_se = True
+        self.id_skip = a.id_skip
+        if a.expand_ratio != 1:
+            self._expand_conv = _Conv(cin, cexp, 1)
+            self._bn0 = _BN(cexp)
+        self._depthwise_conv = _Conv(cexp, cexp, a.kernel_size, s, groups=cexp)
+        self._bn1 = _BN(cexp)
+        self._se_reduce = _Conv(cexp, cse, 1, bias=True)
+        self._se_expand = _Conv(cse, cexp, 1, bias=True)
+        self._project_conv = _Conv(cexp, a.output_filters, 1)
+        self._bn2 = _BN(a.output_filters)
+        self.args = _Geo(idx, a.expand_ratio, a.kernel_size, s, cin, cexp, a.output_filters, cse,
+                         _static_pad(image_size, a.kernel_size, s),
+                         bool(a.id_skip and s == 1 and cin == a.output_filters))
+        self._param_names = [n for n, _ in self.named_parameters()]
+        self.register_buffer("_ones", torch.ones(cin), persistent=False)
+        self.register_buffer("_zeros", torch.zeros(cin), persistent=False)
+
+    def forward(self, inputs, n, h, w, rowscale=None):
+        params = [p for _, p in self.named_parameters()]
+        return _MBConvFn.apply(inputs, rowscale, self, n, h, w, *params)
+
+
+class EfficientNet(nn.Module):
+    """[ref: efficientnet_custom.py:143-411]"""
+
+    def __init__(self, blocks_args: List[BlockArgs] = None, global_params: GlobalParams = None):
+        super().__init__()
+        assert isinstance(blocks_args, list) and len(blocks_args) > 0
+        self._global_params, self._blocks_args = global_params, blocks_args
+        gp = global_params
+        size = (gp.image_size, gp.image_size) if isinstance(gp.image_size, int) else tuple(gp.image_size)
+        c0 = _scaled_width(32, gp)
+        self._conv_stem = _Conv(3, c0, 3, 2)
+        self._bn0 = _BN(c0)
+        self.stem_pad = _static_pad(size, 3, 2)
+        size = _down(size, 2)
+        self._blocks = nn.ModuleList([])
+        for ba in blocks_args:
+            ba = ba._replace(input_filters=_scaled_width(ba.input_filters, gp),
+                             output_filters=_scaled_width(ba.output_filters, gp),
+                             num_repeat=_scaled_depth(ba.num_repeat, gp))
+            s = ba.stride if isinstance(ba.stride, int) else ba.stride[0]
+            self._blocks.append(MBConvBlock(ba, gp, size, idx=len(self._blocks)))
+            size = _down(size, s)
+            if ba.num_repeat > 1:
+                ba = ba._replace(input_filters=ba.output_filters, stride=1)
+            for _ in range(ba.num_repeat - 1):
+                self._blocks.append(MBConvBlock(ba, gp, size, idx=len(self._blocks)))
+        head_out = _scaled_width(1280, gp)
+        self._conv_head = _Conv(ba.output_filters, head_out, 1)
+        self._bn1 = _BN(head_out)
+        self._dropout_p = gp.dropout_rate if gp.include_top else 0.0
+        self.out_dim = head_out
+        self.rng = _Seeds()
+        self.register_buffer("_ones_b", torch.ones(1), persistent=False)
+
+    # ---------------------------------------------------------------------------- construction API
+    @classmethod
+    def from_name(cls, model_name, in_channels=3, **override_params):
+        cls._check_model_name_is_valid(model_name)
+        if in_channels != 3:
+            raise NotImplementedError("the gfx950 stem kernel is specialised for 3 input channels")
+        w, d, res, p = _COEFFS[model_name]
+        gp = GlobalParams(width_coefficient=w, depth_coefficient=d, image_size=res, dropout_rate=p, num_classes=1000,
+                          batch_norm_momentum=0.99, batch_norm_epsilon=BN_EPS, drop_connect_rate=0.2, depth_divisor=8,
+                          min_depth=None, include_top=True)
+        if override_params:
+            gp = gp._replace(**override_params)
+        blocks = [BlockArgs(r, k, s, e, i, o, 0.25, True) for (r, k, s, e, i, o) in _STAGES]
+        return cls(blocks, gp)
+
+    @classmethod
+    def from_pretrained(cls, model_name, weights_path=None, advprop=False, in_channels=3, num_classes=1000,
+                        **override_params):
+        """Builds the network; ImageNet weights are loaded only from a local ``weights_path`` (the reference
+        downloads them, efficient_net_custom_utils.py:584-615 -- there is no network on the target boxes)."""
+        model = cls.from_name(model_name, num_classes=num_classes, **override_params)
+        if isinstance(weights_path, str):
+            sd = torch.load(weights_path, map_location="cpu")
+            sd.pop("_fc.weight", None)
+            sd.pop("_fc.bias", None)
+            ret = model.load_state_dict(sd, strict=False)
+            assert not ret.unexpected_keys, ret.unexpected_keys
+        return model
+
+    @classmethod
+    def get_image_size(cls, model_name):
+        cls._check_model_name_is_valid(model_name)
+        return _COEFFS[model_name][2]
+
+    @classmethod
+    def _check_model_name_is_valid(cls, model_name):
+        if model_name not in VALID_MODELS:
+            raise ValueError("model_name should be one of: " + ", ".join(VALID_MODELS))
+
+    def set_swish(self, memory_efficient=True):
+        """No-op: the swish is always the fused, recompute-in-backward form."""
+
+    # ---------------------------------------------------------------------------- forward
+    def _drop_connect_scales(self, n, device, seed):
+        """keep/keep_prob per (block, sample) [ref: efficient_net_custom_utils.py:129-154]; rate = 0.2*idx/len."""
+        rate = self._global_params.drop_connect_rate
+        out = []
+        nb = len(self._blocks)
+        for i, blk in enumerate(self._blocks):
+            p = rate * float(i) / nb if rate else 0.0
+            if not (self.training and p > 0.0 and blk.args.skip):
+                out.append(None)
+                continue
+            out.append(ops.dropout_f32(self._ones_b.expand(n).contiguous(), p, seed, 1000 + i))
+        return out
+
+    def _features_nhwc(self, inputs):
+        if not inputs.is_cuda:
+            raise RuntimeError("mammo_clip_amd.EfficientNet runs only on a HIP device (no CPU fallback)")
+        x = inputs if inputs.dtype == torch.float32 else inputs.float()
+        seed = self.rng.next()
+        self._last_seed = seed
+        y = _StemFn.apply(x, self._conv_stem.weight, self._bn0.weight, self._bn0.bias, self)
+        n, h, w = self._geo
+        scales = self._drop_connect_scales(n, x.device, seed)
+        for blk, rs in zip(self._blocks, scales):
+            y = blk(y, n, h, w, rs)
+            n, h, w = blk._out_geo
+        return y, n, h, w
+
+    def extract_features(self, inputs):
+        """Final feature map after head conv + BN + swish, NCHW fp32 (API parity; not on the training hot path)."""
+        y, n, h, w = self._features_nhwc(inputs)
+        _HeadFn.apply(y, self._conv_head.weight, self._bn1.weight, self._bn1.bias, self, n, h, w)
+        e, st, n, h, w, cout = self._head_cache
+        fmap = ops.bnact_apply(e, n, h * w, cout, st.scale, st.shift, 1)
+        return ops.cast_f32(fmap).view(n, h, w, cout).permute(0, 3, 1, 2)
+
+    def forward(self, inputs):
+        """[ref: efficientnet_custom.py:287-313]: pooled features [b, out_dim] (fp32); the dict form
+        ``{"image": x}`` returns (pooled, raw_feature_map)."""
+        want_map = isinstance(inputs, dict) and "image" in inputs
+        x = inputs["image"] if want_map else inputs
+        y, n, h, w = self._features_nhwc(x)
+        pooled = _HeadFn.apply(y, self._conv_head.weight, self._bn1.weight, self._bn1.bias, self, n, h, w)
+        if self.training and self._dropout_p > 0.0:
+            pooled = _DropoutFn.apply(pooled, self._dropout_p, self._last_seed, 999)
+        if want_map:
+            e, st, n, h, w, cout = self._head_cache
+            fmap = ops.bnact_apply(e, n, h * w, cout, st.scale, st.shift, 1)
+            return pooled, ops.cast_f32(fmap).view(n, h, w, cout).permute(0, 3, 1, 2)
+        return pooled

@@ -1,0 +1,274 @@
+"""BioClinicalBERT text encoder on hand-written gfx950 kernels.
+
+Mirrors ``HuggingfaceTextEncoder`` (reference: model/modules/text_encoder.py:5-49): same constructor
+arguments, ``out_dim`` attribute, ``forward(tokens) -> last_hidden_state [b, T, H]`` and the same
+``state_dict`` keys as ``transformers.BertModel`` (``text_encoder.embeddings.word_embeddings.weight`` ...
+``text_encoder.encoder.layer.{i}.attention.self.query.weight`` ... ``text_encoder.pooler.dense.*``), so
+released checkpoints load with ``strict=True``.  The reference delegates the arithmetic to the third-party
+``transformers`` package; here it is one autograd Function per encoder layer built from MFMA GEMMs (fused
+QKV projection, batched-strided attention matmuls without any transposes) plus wave-per-row LayerNorm /
+softmax kernels.  The pooler is a parameter container only (the reference never uses it, text_encoder.py:49).
+"""
+from typing import Dict
+
+import torch
+from torch import nn
+
+from .... import ops
+
+# Bio_ClinicalBERT = BERT-base-cased shape
+BERT_BASE = dict(vocab_size=28996, hidden_size=768, num_hidden_layers=12, num_attention_heads=12,
+                 intermediate_size=3072, max_position_embeddings=512, type_vocab_size=2, layer_norm_eps=1e-12,
+                 hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1)
+
+
+class BertConfigLite:
+    def __init__(self, **kw):
+        cfg = dict(BERT_BASE)
+        cfg.update(kw)
+        for k, v in cfg.items():
+            setattr(self, k, v)
+
+
+class _EmbedFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, word, pos, typ, gamma, beta, ids, tt, eps, p, seed, sid):
+        y, mean, rstd = ops.bert_embed_fwd(ids, tt, word, pos, typ, gamma, beta, eps, p, seed, sid)
+        ctx.cfg = (p, seed, sid)
+        ctx.save_for_backward(word, pos, typ, gamma, ids, tt, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        word, pos, typ, gamma, ids, tt, mean, rstd = ctx.saved_tensors
+        p, seed, sid = ctx.cfg
+        dword, dpos, dtyp, dgamma, dbeta = ops.bert_embed_bwd(dy.contiguous(), ids, tt, word, pos, typ, gamma, mean, rstd,
+                                                              p, seed, sid)
+        dword[0].zero_()       # nn.Embedding(padding_idx=0) never accumulates a gradient for the [PAD] row
+        return dword, dpos, dtyp, dgamma, dbeta, None, None, None, None, None, None
+
+
+class _LayerFn(torch.autograd.Function):
+    """One BertLayer: self-attention + output LayerNorm + FFN + output LayerNorm, forward and backward."""
+
+    @staticmethod
+    def forward(ctx, x, maskb, lyr, b, t, seed, *params):
+        att, H, nh = lyr.attention, lyr.hidden, lyr.heads
+        hd = H // nh
+        M = b * t
+        pa, ph = (lyr.p_attn, lyr.p_hidden) if lyr.training else (0.0, 0.0)
+        sid = 16 * lyr.index
+        sq, sk, sv = att.self.query, att.self.key, att.self.value
+        wqkv = torch.empty((3 * H, H), dtype=torch.bfloat16, device=x.device)
+        ops.cast_bf16(sq.weight, out=wqkv[:H])
+        ops.cast_bf16(sk.weight, out=wqkv[H:2 * H])
+        ops.cast_bf16(sv.weight, out=wqkv[2 * H:])
+        bqkv = torch.empty((3 * H,), dtype=torch.float32, device=x.device)
+        bqkv[:H].copy_(sq.bias); bqkv[H:2 * H].copy_(sk.bias); bqkv[2 * H:].copy_(sv.bias)   # D2D copies
+        qkv = ops.linear_fwd(x, wqkv, bias=bqkv)
+        scores = torch.empty((b, nh, t, t), dtype=torch.float32, device=x.device)
+        ops.gemm(qkv, qkv[:, H:], scores, t, t, hd, 3 * H, 3 * H, t, c_f32=1, batch=b * nh, nb2=nh,
+                 sA=(t * 3 * H, hd), sB=(t * 3 * H, hd), sC=(nh * t * t, t * t), bias=maskb, bias_stride1=t,
+                 alpha=hd ** -0.5)
+        probs, pd = ops.softmax_fwd(scores, pa, seed, sid)
+        del scores
+        ctxv = torch.empty((M, H), dtype=torch.bfloat16, device=x.device)
+        ops.gemm(pd, qkv[:, 2 * H:], ctxv, t, hd, t, t, 3 * H, H, b_kmajor=1, batch=b * nh, nb2=nh,
+                 sA=(nh * t * t, t * t), sB=(t * 3 * H, hd), sC=(t * H, hd))
+        wo = ops.cast_bf16(att.output.dense.weight)
+        ao = ops.linear_fwd(ctxv, wo, bias=att.output.dense.bias)
+        a, mean1, rstd1 = ops.add_ln_fwd(ao, x, att.output.LayerNorm.weight, att.output.LayerNorm.bias, lyr.eps, ph, seed,
+                                         sid + 1)
+        wi = ops.cast_bf16(lyr.intermediate.dense.weight)
+        h1 = ops.linear_fwd(a, wi, bias=lyr.intermediate.dense.bias)
+        hg = ops.gelu_fwd(h1)
+        w2 = ops.cast_bf16(lyr.output.dense.weight)
+        o = ops.linear_fwd(hg, w2, bias=lyr.output.dense.bias)
+        del hg
+        y, mean2, rstd2 = ops.add_ln_fwd(o, a, lyr.output.LayerNorm.weight, lyr.output.LayerNorm.bias, lyr.eps, ph, seed,
+                                         sid + 2)
+        ctx.lyr, ctx.cfg = lyr, (b, t, seed, pa, ph, sid)
+        ctx.sv = dict(x=x, qkv=qkv, probs=probs, pd=pd, ctxv=ctxv, ao=ao, a=a, h1=h1, o=o, wqkv=wqkv, wo=wo, wi=wi, w2=w2,
+                      ln1=(mean1, rstd1), ln2=(mean2, rstd2))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lyr, sv = ctx.lyr, ctx.sv
+        b, t, seed, pa, ph, sid = ctx.cfg
+        att, H, nh = lyr.attention, lyr.hidden, lyr.heads
+        hd = H // nh
+        x, qkv, probs, pd, a = sv["x"], sv["qkv"], sv["probs"], sv["pd"], sv["a"]
+        dy = dy.contiguous()
+        g = {}
+        # y = LN2(dropout(o) + a)
+        do, da_res, g["output.LayerNorm.weight"], g["output.LayerNorm.bias"] = ops.add_ln_bwd(
+            dy, sv["o"], a, lyr.output.LayerNorm.weight, sv["ln2"][0], sv["ln2"][1], ph, seed, sid + 2)
+        hg = ops.gelu_fwd(sv["h1"])                                  # recomputed
+        g["output.dense.weight"] = ops.linear_wgrad(do, hg)
+        g["output.dense.bias"] = ops.colsum(do)
+        dhg = ops.linear_dgrad(do, sv["w2"])
+        del hg, do
+        dh1 = ops.gelu_bwd(dhg, sv["h1"])
+        del dhg
+        g["intermediate.dense.weight"] = ops.linear_wgrad(dh1, a)
+        g["intermediate.dense.bias"] = ops.colsum(dh1)
+        da = ops.linear_dgrad(dh1, sv["wi"], residual=da_res)
+        del dh1, da_res
+        # a = LN1(dropout(ao) + x)
+        dao, dx_res, g["attention.output.LayerNorm.weight"], g["attention.output.LayerNorm.bias"] = ops.add_ln_bwd(
+            da, sv["ao"], x, att.output.LayerNorm.weight, sv["ln1"][0], sv["ln1"][1], ph, seed, sid + 1)
+        g["attention.output.dense.weight"] = ops.linear_wgrad(dao, sv["ctxv"])
+        g["attention.output.dense.bias"] = ops.colsum(dao)
+        dctx = ops.linear_dgrad(dao, sv["wo"])
+        del dao
+        # attention core
+        dpd = torch.empty((b, nh, t, t), dtype=torch.float32, device=x.device)
+        ops.gemm(dctx, qkv[:, 2 * H:], dpd, t, t, hd, H, 3 * H, t, c_f32=1, batch=b * nh, nb2=nh,
+                 sA=(t * H, hd), sB=(t * 3 * H, hd), sC=(nh * t * t, t * t))
+        dqkv = torch.empty((b * t, 3 * H), dtype=torch.bfloat16, device=x.device)
+        ops.gemm(pd, dctx, dqkv[:, 2 * H:], t, hd, t, t, H, 3 * H, a_kmajor=1, b_kmajor=1, batch=b * nh, nb2=nh,
+                 sA=(nh * t * t, t * t), sB=(t * H, hd), sC=(t * 3 * H, hd))                       # dV = Pd^T dO
+        ds = ops.softmax_bwd(probs, dpd, pa, seed, sid, hd ** -0.5)
+        del dpd
+        ops.gemm(ds, qkv[:, H:], dqkv, t, hd, t, t, 3 * H, 3 * H, b_kmajor=1, batch=b * nh, nb2=nh,
+                 sA=(nh * t * t, t * t), sB=(t * 3 * H, hd), sC=(t * 3 * H, hd))                   # dQ = dS K
+        ops.gemm(ds, qkv, dqkv[:, H:], t, hd, t, t, 3 * H, 3 * H, a_kmajor=1, b_kmajor=1, batch=b * nh, nb2=nh,
+                 sA=(nh * t * t, t * t), sB=(t * 3 * H, hd), sC=(t * 3 * H, hd))                   # dK = dS^T Q
+        del ds
+        dwqkv = ops.linear_wgrad(dqkv, x)
+        dbqkv = ops.colsum(dqkv)
+        dx = ops.linear_dgrad(dqkv, sv["wqkv"], residual=dx_res)
+        for i, nm in enumerate(("query", "key", "value")):
+            g[f"attention.self.{nm}.weight"] = dwqkv[i * H:(i + 1) * H]
+            g[f"attention.self.{nm}.bias"] = dbqkv[i * H:(i + 1) * H]
+        ctx.sv = None
+        return (dx, None, None, None, None, None) + tuple(g[nm] for nm in lyr._param_names)
+
+
+# ---------------------------------------------------------------------------------------------- containers
+class _Self(nn.Module):
+    def __init__(self, H):
+        super().__init__()
+        self.query, self.key, self.value = nn.Linear(H, H), nn.Linear(H, H), nn.Linear(H, H)
+
+
+class _SelfOutput(nn.Module):
+    def __init__(self, H, eps):
+        super().__init__()
+        self.dense = nn.Linear(H, H)
+        self.LayerNorm = nn.LayerNorm(H, eps=eps)
+
+
+class _Attention(nn.Module):
+    def __init__(self, H, eps):
+        super().__init__()
+        self.self = _Self(H)
+        self.output = _SelfOutput(H, eps)
+
+
+class _Intermediate(nn.Module):
+    def __init__(self, H, I):
+        super().__init__()
+        self.dense = nn.Linear(H, I)
+
+
+class _Output(nn.Module):
+    def __init__(self, H, I, eps):
+        super().__init__()
+        self.dense = nn.Linear(I, H)
+        self.LayerNorm = nn.LayerNorm(H, eps=eps)
+
+
+class BertLayerHIP(nn.Module):
+    def __init__(self, cfg, index):
+        super().__init__()
+        H, I = cfg.hidden_size, cfg.intermediate_size
+        self.attention = _Attention(H, cfg.layer_norm_eps)
+        self.intermediate = _Intermediate(H, I)
+        self.output = _Output(H, I, cfg.layer_norm_eps)
+        self.hidden, self.heads, self.eps, self.index = H, cfg.num_attention_heads, cfg.layer_norm_eps, index
+        self.p_attn, self.p_hidden = cfg.attention_probs_dropout_prob, cfg.hidden_dropout_prob
+        self._param_names = [n for n, _ in self.named_parameters()]
+
+    def forward(self, x, maskb, b, t, seed):
+        return _LayerFn.apply(x, maskb, self, b, t, seed, *[p for _, p in self.named_parameters()])
+
+
+class _Embeddings(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        H = cfg.hidden_size
+        self.word_embeddings = nn.Embedding(cfg.vocab_size, H, padding_idx=0)
+        self.position_embeddings = nn.Embedding(cfg.max_position_embeddings, H)
+        self.token_type_embeddings = nn.Embedding(cfg.type_vocab_size, H)
+        self.LayerNorm = nn.LayerNorm(H, eps=cfg.layer_norm_eps)
+
+
+class _Encoder(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.layer = nn.ModuleList([BertLayerHIP(cfg, i) for i in range(cfg.num_hidden_layers)])
+
+
+class _Pooler(nn.Module):
+    def __init__(self, H):
+        super().__init__()
+        self.dense = nn.Linear(H, H)
+
+
+class BertModelHIP(nn.Module):
+    """``transformers.BertModel``-compatible parameter tree; forward returns ``{"last_hidden_state": [b,T,H]}``."""
+
+    supports_gradient_checkpointing = False
+
+    def __init__(self, cfg: BertConfigLite):
+        super().__init__()
+        self.config = cfg
+        self.embeddings = _Embeddings(cfg)
+        self.encoder = _Encoder(cfg)
+        self.pooler = _Pooler(cfg.hidden_size)
+        for m in self.modules():                      # BERT init: N(0, 0.02), zero bias, unit LayerNorm
+            if isinstance(m, (nn.Linear, nn.Embedding)):
+                nn.init.normal_(m.weight, 0.0, 0.02)
+                if isinstance(m, nn.Linear):
+                    nn.init.zeros_(m.bias)
+        self._calls = 0
+        self.rng_seed = 0xBE27
+
+    def forward(self, input_ids=None, attention_mask=None, token_type_ids=None, **_):
+        if not input_ids.is_cuda:
+            raise RuntimeError("mammo_clip_amd.BertModelHIP runs only on a HIP device (no CPU fallback)")
+        b, t = input_ids.shape
+        self._calls += 1
+        seed = self.rng_seed * 1000003 + self._calls
+        cfg = self.config
+        emb = self.embeddings
+        ids = input_ids.contiguous()
+        tt = token_type_ids.contiguous() if token_type_ids is not None else None
+        mask = attention_mask.contiguous() if attention_mask is not None else torch.ones_like(ids)
+        p = cfg.hidden_dropout_prob if self.training else 0.0
+        x = _EmbedFn.apply(emb.word_embeddings.weight, emb.position_embeddings.weight, emb.token_type_embeddings.weight,
+                           emb.LayerNorm.weight, emb.LayerNorm.bias, ids, tt, cfg.layer_norm_eps, p, seed, 15)
+        maskb = ops.mask_bias(mask)
+        for lyr in self.encoder.layer:
+            x = lyr(x, maskb, b, t, seed)
+        return {"last_hidden_state": x.view(b, t, cfg.hidden_size)}
+
+
+class HuggingfaceTextEncoder(nn.Module):
+    """[ref: model/modules/text_encoder.py:5-49]"""
+
+    def __init__(self, name: str = "bert-base-uncased", vocab_size: int = None, pretrained: bool = True,
+                 gradient_checkpointing: bool = False, cache_dir: str = "~/.cache/huggingface/hub",
+                 local_files_only: bool = False, trust_remote_code: bool = False, config: Dict = None):
+        super().__init__()
+        # The architecture is fixed to the BERT family (the only one the reference's pre-training configs
+        # use); weights come from load_state_dict of a reference / HF checkpoint -- nothing is downloaded.
+        self.text_encoder = BertModelHIP(BertConfigLite(**(config or {})))
+        self.name, self.pretrained = name, pretrained
+        self.out_dim = self.text_encoder.config.hidden_size
+
+    def forward(self, x):
+        out = self.text_encoder(**x)
+        return out["last_hidden_state"]

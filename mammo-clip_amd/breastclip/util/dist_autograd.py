@@ -1,0 +1,55 @@
+"""All-gather with autograd over RCCL/xGMI [ref: util/dist_autograd.py:5-27]: forward all_gather in rank order,
+backward reduce_scatter(SUM) of the per-rank gradients.
+
+MI355X note: the 4 embedding tensors of one step are gathered with ONE collective (``all_gather_fused`` below,
+[4,b,D] in -> [W,4,b,D] out) instead of four latency-bound ones; xGMI is point-to-point, messages are <= 1 MiB."""
+import torch
+import torch.distributed as dist
+
+
+def DistAutogradAllGatherFunction(partial=False):
+    class F(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, input):
+            ctx.save_for_backward(input)
+            output = [torch.zeros_like(input) for _ in range(dist.get_world_size())]
+            dist.all_gather(output, input.contiguous())
+            return tuple(output)
+
+        @staticmethod
+        def backward(ctx, *grads):
+            (input,) = ctx.saved_tensors
+            grad_out = torch.zeros_like(input)
+            if partial:
+                grad_out[:] = grads[dist.get_rank()]
+            else:
+                dist.reduce_scatter(grad_out, [g.contiguous() for g in grads], dist.ReduceOp.SUM)
+            return grad_out
+
+    return F
+
+
+class _FusedGather(torch.autograd.Function):
+    """stacked [k,b,D] -> [W,k,b,D] with one all_gather_into_tensor; backward one reduce_scatter_tensor."""
+
+    @staticmethod
+    def forward(ctx, stacked):
+        W = dist.get_world_size()
+        out = torch.empty((W,) + tuple(stacked.shape), dtype=stacked.dtype, device=stacked.device)
+        dist.all_gather_into_tensor(out, stacked.contiguous())
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        out = torch.empty(grad.shape[1:], dtype=grad.dtype, device=grad.device)
+        dist.reduce_scatter_tensor(out, grad.contiguous(), op=dist.ReduceOp.SUM)
+        return out
+
+
+def all_gather_fused(tensors):
+    """list of k local [b,D] tensors -> list of k gathered [W*b,D] tensors (rank order), one collective."""
+    stacked = torch.stack(tensors, 0)
+    g = _FusedGather.apply(stacked)                       # [W,k,b,D]
+    W, k, b, D = g.shape
+    g = g.permute(1, 0, 2, 3).reshape(k, W * b, D)
+    return [g[i] for i in range(k)]

@@ -154,10 +154,11 @@ __device__ __forceinline__ void bwd_dz8(const mc_bnact_args& p, long long pix, i
         for (int q = 0; q < 8; ++q) up[q] *= m[q];
     }
     if (p.add) {
+        const float asc = (p.add_scale == 0.f) ? 1.f : p.add_scale;
         float a[8];
         load8f(p.add + img * p.c + c8, a);
 #pragma unroll
-        for (int q = 0; q < 8; ++q) up[q] += a[q];
+        for (int q = 0; q < 8; ++q) up[q] += a[q] * asc;
     }
     float rs = p.rowscale ? p.rowscale[img] : 1.f;
 #pragma unroll

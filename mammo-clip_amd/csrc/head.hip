@@ -12,7 +12,9 @@ constexpr int TS = 32;
 __global__ __launch_bounds__(256) void sgemm_k(const float* __restrict__ a, long long ars, long long acs,
                                                const float* __restrict__ b, long long brs, long long bcs,
                                                float* __restrict__ c, long long ldc, int m, int n, int k, float alpha,
-                                               float beta, const float* __restrict__ bias) {
+                                               float beta, const float* __restrict__ bias,
+                                               const float* __restrict__ alpha_dev) {
+    if (alpha_dev) alpha *= alpha_dev[0];
     __shared__ float sa[TS][TS + 1], sb[TS][TS + 1];
     const int tx = threadIdx.x % 16, ty = threadIdx.x / 16;       // 16 x 16 threads, 2 x 2 outputs each
     const int m0 = blockIdx.y * TS, n0 = blockIdx.x * TS;
@@ -72,7 +74,7 @@ __global__ void l2norm_bwd_k(const float* __restrict__ dy, const float* __restri
 }
 
 // one wave per row: lse, loss contribution, dlogits in place
-__global__ void ce_fwd_bwd_k(float* __restrict__ logits, int rows, int n, int label_offset, float w,
+__global__ void ce_fwd_bwd_k(float* __restrict__ logits, int rows, int n, int label_offset, float w, float eps,
                              float* __restrict__ loss_out) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= rows) return;
@@ -80,17 +82,20 @@ __global__ void ce_fwd_bwd_k(float* __restrict__ logits, int rows, int n, int la
     float mx = -3.4e38f;
     for (int i = lane; i < n; i += 64) mx = fmaxf(mx, lr[i]);
     mx = wave_max(mx);
-    float s = 0.f;
-    for (int i = lane; i < n; i += 64) s += __expf(lr[i] - mx);
+    float s = 0.f, sx = 0.f;
+    for (int i = lane; i < n; i += 64) { s += __expf(lr[i] - mx); sx += lr[i]; }
     s = wave_sum(s);
+    sx = wave_sum(sx);
     const float lse = mx + __logf(s);
     const int label = row + label_offset;
     const float scale = w / (float)rows;
-    if (lane == 0) atomicAdd(loss_out, (lse - lr[label]) * scale);
+    // label smoothing eps: target = (1-eps) * onehot + eps / n   (torch F.cross_entropy semantics)
+    if (lane == 0) atomicAdd(loss_out, ((1.f - eps) * (lse - lr[label]) + eps * (lse - sx / (float)n)) * scale);
     const float inv = 1.f / s;
+    const float un = eps / (float)n;
     for (int i = lane; i < n; i += 64) {
         float pr = __expf(lr[i] - mx) * inv;
-        lr[i] = (pr - (i == label ? 1.f : 0.f)) * scale;
+        lr[i] = (pr - (i == label ? 1.f - eps : 0.f) - un) * scale;
     }
 }
 
@@ -98,11 +103,23 @@ __global__ void ce_fwd_bwd_k(float* __restrict__ logits, int rows, int n, int la
 
 extern "C" int mc_sgemm(const float* a, long long ars, long long acs, const float* b, long long brs, long long bcs,
                         float* c, long long ldc, int m, int n, int k, float alpha, float beta, const float* bias,
-                        void* stream) {
+                        const float* alpha_dev, void* stream) {
     MC_CHECK(a && b && c && m > 0 && n > 0 && k > 0, "sgemm: bad args");
     dim3 grid(mc_div_up(n, TS), mc_div_up(m, TS));
     hipLaunchKernelGGL(sgemm_k, grid, dim3(256), 0, (hipStream_t)stream, a, ars, acs, b, brs, bcs, c, ldc, m, n, k, alpha,
-                       beta, bias);
+                       beta, bias, alpha_dev);
+    MC_LAUNCH_CHECK();
+    return MC_OK;
+}
+__global__ void scale_f32_k(const float* __restrict__ x, const float* __restrict__ sd, float alpha, float* __restrict__ y,
+                            long long n) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    float s = alpha * (sd ? sd[0] : 1.f);
+    if (i < n) y[i] = x[i] * s;
+}
+extern "C" int mc_scale_f32(const float* x, const float* scalar_dev, float alpha, float* y, long long n, void* stream) {
+    MC_CHECK(x && y && n > 0, "scale: bad args");
+    hipLaunchKernelGGL(scale_f32_k, dim3(mc_div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, x, scalar_dev, alpha, y, n);
     MC_LAUNCH_CHECK();
     return MC_OK;
 }
@@ -118,11 +135,12 @@ extern "C" int mc_l2norm_bwd(const float* dy, const float* y, const float* norm,
     MC_LAUNCH_CHECK();
     return MC_OK;
 }
-extern "C" int mc_ce_fwd_bwd(float* logits, int rows, int n, int label_offset, float w, float* loss_out, void* stream) {
+extern "C" int mc_ce_fwd_bwd(float* logits, int rows, int n, int label_offset, float w, float smoothing, float* loss_out,
+                             void* stream) {
     MC_CHECK(logits && loss_out && rows > 0 && n > 0, "ce: bad args");
     MC_CHECK(label_offset >= 0 && label_offset + rows <= n, "ce: labels out of range");
     hipLaunchKernelGGL(ce_fwd_bwd_k, dim3(mc_div_up(rows, 4)), dim3(256), 0, (hipStream_t)stream, logits, rows, n,
-                       label_offset, w, loss_out);
+                       label_offset, w, smoothing, loss_out);
     MC_LAUNCH_CHECK();
     return MC_OK;
 }

@@ -49,7 +49,7 @@ class BnactArgs(C.Structure):
         ("scale", P), ("shift", P), ("act", I),
         ("rowscale", P), ("res", P), ("out", P),
         ("pooled", P),
-        ("g", P), ("mul", P), ("add", P), ("mean", P), ("invstd", P),
+        ("g", P), ("mul", P), ("add", P), ("add_scale", F), ("mean", P), ("invstd", P),
         ("partials", P), ("coef", P), ("dx", P), ("dgate", P),
     ]
 
@@ -92,10 +92,11 @@ _SIGS = {
     "mc_mask_bias": ([P, P, LL, P], I),
     "mc_eos_gather": ([P, P, I, I, I, P, P], I),
     "mc_eos_scatter": ([P, P, I, I, I, P, P], I),
-    "mc_sgemm": ([P, LL, LL, P, LL, LL, P, LL, I, I, I, F, F, P, P], I),
+    "mc_sgemm": ([P, LL, LL, P, LL, LL, P, LL, I, I, I, F, F, P, P, P], I),
+    "mc_scale_f32": ([P, P, F, P, LL, P], I),
     "mc_l2norm_fwd": ([P, I, I, P, P, P], I),
     "mc_l2norm_bwd": ([P, P, P, I, I, P, P], I),
-    "mc_ce_fwd_bwd": ([P, I, I, I, F, P, P], I),
+    "mc_ce_fwd_bwd": ([P, I, I, I, F, F, P, P], I),
 }
 
 EXPORTS = sorted(list(_SIGS.keys()) + ["mc_last_error"])

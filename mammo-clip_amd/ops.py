@@ -256,10 +256,11 @@ def bnact_se_dgate(x, g, n_img, hw, c, scale, shift, act):
     return dgate
 
 
-def bnact_bwd(x, n_img, hw, c, stats, gamma, act, g=None, mul=None, add=None, rowscale=None):
+def bnact_bwd(x, n_img, hw, c, stats, gamma, act, g=None, mul=None, add=None, rowscale=None, add_scale=1.0):
     """Backward through y = act(BN_train(x)) (* rowscale).  Returns (dx bf16, dgamma, dbeta)."""
     a = _bnact(x, n_img, hw, c, stats.scale, stats.shift, act)
     a.g, a.mul, a.add, a.rowscale = _p(g), _p(mul), _p(add), _p(rowscale)
+    a.add_scale = add_scale
     a.mean, a.invstd = _p(stats.mean), _p(stats.invstd)
     rows = L.load().mc_bnact_rows(C.byref(a))
     part = empty((rows, 2, c), torch.float32, x)
@@ -394,8 +395,15 @@ def eos_scatter(dout, mask, b, t, h):
 
 
 # ------------------------------------------------------------------------------------------- heads / loss
-def sgemm(a, ars, acs, b, brs, bcs, c, ldc, m, n, k, alpha=1.0, beta=0.0, bias=None):
-    L.call("mc_sgemm", _p(a), ars, acs, _p(b), brs, bcs, _p(c), ldc, m, n, k, float(alpha), float(beta), _p(bias), _st())
+def sgemm(a, ars, acs, b, brs, bcs, c, ldc, m, n, k, alpha=1.0, beta=0.0, bias=None, alpha_dev=None):
+    L.call("mc_sgemm", _p(a), ars, acs, _p(b), brs, bcs, _p(c), ldc, m, n, k, float(alpha), float(beta), _p(bias),
+           _p(alpha_dev), _st())
+
+
+def scale_f32(x, scalar_dev=None, alpha=1.0):
+    y = torch.empty_like(x)
+    L.call("mc_scale_f32", _p(x), _p(scalar_dev), float(alpha), _p(y), x.numel(), _st())
+    return y
 
 
 def l2norm_fwd(x):
@@ -413,6 +421,6 @@ def l2norm_bwd(dy, y, norm):
     return dx
 
 
-def ce_fwd_bwd(logits, label_offset, w, loss_out):
+def ce_fwd_bwd(logits, label_offset, w, loss_out, smoothing=0.0):
     rows, n = logits.shape
-    L.call("mc_ce_fwd_bwd", _p(logits), rows, n, int(label_offset), float(w), _p(loss_out), _st())
+    L.call("mc_ce_fwd_bwd", _p(logits), rows, n, int(label_offset), float(w), float(smoothing), _p(loss_out), _st())
