@@ -1,0 +1,113 @@
+"""Data-parallel training step for the contrastive pre-training hot path (one process per GPU, RCCL over xGMI).
+
+Reproduces the call order of the reference's hot loop [ref: trainer_ddp.py:279-308]: zero_grad(set_to_none) ->
+forward -> loss -> backward -> AdamW step -> scheduler step, with DDP-average gradient semantics (mean over ranks of
+the per-rank mean loss) -- but:
+  * gradients are reduced in a few large flat fp32 buckets launched from post-accumulate hooks while backward is
+    still running (xGMI is point-to-point: few large collectives, not hundreds of small ones),
+  * the loss dict stays on the device (no per-step .cpu() sync),
+  * BatchNorm running statistics are per-rank like in the reference between its buffer broadcasts; rank 0's buffers
+    are what ``state_dict()`` saves.
+"""
+import os
+from typing import Dict, List, Optional
+
+import torch
+import torch.distributed as dist
+
+
+class GradBuckets:
+    """Flat fp32 gradient buckets filled in reverse registration order (the order backward produces them)."""
+
+    def __init__(self, params: List[torch.nn.Parameter], bucket_bytes: int = 256 << 20):
+        self.params = [p for p in params if p.requires_grad]
+        self.bucket_of, self.buckets, self.pending, self.handles = {}, [], [], []
+        cur, cur_n = [], 0
+        for p in reversed(self.params):
+            cur.append(p)
+            cur_n += p.numel()
+            if cur_n * 4 >= bucket_bytes:
+                self._close(cur, cur_n)
+                cur, cur_n = [], 0
+        if cur:
+            self._close(cur, cur_n)
+        self.seen = set()
+        for p in self.params:
+            p.register_post_accumulate_grad_hook(self._hook)
+
+    def _close(self, plist, n):
+        dev = plist[0].device
+        flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        off, views = 0, []
+        for p in plist:
+            views.append(flat[off:off + p.numel()].view_as(p))
+            off += p.numel()
+        idx = len(self.buckets)
+        self.buckets.append((flat, plist, views))
+        for p in plist:
+            self.bucket_of[p] = idx
+
+    def begin(self):
+        self.pending = [len(plist) for (_, plist, _) in self.buckets]
+        self.handles = []
+        self.seen = set()
+
+    def _hook(self, p):
+        idx = self.bucket_of[p]
+        flat, plist, views = self.buckets[idx]
+        v = views[plist.index(p)]
+        v.copy_(p.grad)
+        p.grad = v
+        self.seen.add(p)
+        self.pending[idx] -= 1
+        if self.pending[idx] == 0:
+            self.handles.append(dist.all_reduce(flat, op=dist.ReduceOp.AVG, async_op=True))
+
+    def finish(self):
+        """Parameters that got no gradient (e.g. the unused BERT pooler) keep grad None, like under the reference's
+        DDP(find_unused_parameters=True); their bucket slots are zero-filled so the collective sizes stay static."""
+        for idx, (flat, plist, views) in enumerate(self.buckets):
+            if self.pending[idx] > 0:
+                for p, v in zip(plist, views):
+                    if p not in self.seen:
+                        v.zero_()
+                self.handles.append(dist.all_reduce(flat, op=dist.ReduceOp.AVG, async_op=True))
+        for h in self.handles:
+            h.wait()
+
+
+class Trainer:
+    def __init__(self, model, loss_func, optimizer, scheduler=None, device=None, bucket_mb: int = 256):
+        self.model, self.loss_func, self.optimizer, self.scheduler = model, loss_func, optimizer, scheduler
+        self.device = device
+        self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self.buckets = GradBuckets(list(model.parameters()), bucket_mb << 20) if self.world > 1 else None
+
+    def step(self, batch: Dict) -> Dict[str, torch.Tensor]:
+        self.model.train()
+        self.optimizer.zero_grad(set_to_none=True)
+        if self.buckets is not None:
+            self.buckets.begin()
+        outputs = self.model(batch, self.device)
+        loss_dict = self.loss_func(**outputs, is_train=True)
+        loss_dict["total"].backward()
+        if self.buckets is not None:
+            self.buckets.finish()
+        self.optimizer.step()
+        if self.scheduler is not None:
+            self.scheduler.step()
+        return {k: v.detach() for k, v in loss_dict.items()}
+
+
+def init_distributed():
+    """torchrun-style env (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*) -> (rank, local_rank, world, device)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    device = torch.device(f"cuda:{local}")
+    torch.cuda.set_device(device)
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", init_method="env://", world_size=world, rank=rank, device_id=device)
+    return rank, local, world, device
