@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""Headline benchmark: image-text pairs/s of the Mammo-CLIP contrastive pre-training step on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run)
+
+One "step" = one full training step of the hot path on one batch of synthetic data already resident in HBM:
+2 image views + 2 reports per pair through EfficientNet + BioClinicalBERT, projection, fused RCCL all-gather,
+symmetric InfoNCE (breast_clip loss), backward, gradient all-reduce, AdamW update, LR-schedule step.
+Default workload = BASELINE.json configs[2] (the largest single-GPU configuration of the metric's model):
+EfficientNet-B5 + BioClinicalBERT, 32 pairs per GPU, 1520x912 images, 256-token reports, bf16 compute.
+Per-GPU work is fixed as N grows (weak scaling: global batch = 32 N).
+
+The JSON line carries, besides the contract fields:
+  roofline     -- the dominant HBM-bound kernel class (depthwise / BN streaming kernels: see DESIGN.md), timed live with
+                  HIP events on the launch stream inside the timed steps; achieved = algorithmic bytes / time
+  cpu_baseline -- the CPU oracle (oracle/, torch-fp32 restatement of the reference) timed on this box's host cores
+                  on a bounded sample of the same workload (rank 0, N = 1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import types
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (encoder name, arch, per-GPU pairs, H, W, T)
+    "cfg1": ("tf_efficientnetv2-detect", "efficientnet-b2", 4, 224, 224, 64),
+    "cfg2": ("tf_efficientnetv2-detect", "efficientnet-b2", 64, 912, 912, 256),
+    "cfg3": ("tf_efficientnet_b5_ns-detect", "efficientnet-b5", 32, 1520, 912, 256),
+}
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+MFMA_PEAK_TFS = 2500.0         # dense bf16 MFMA peak
+
+STREAM_OPS = ("mc_dwconv_fwd", "mc_dwconv_bwd_weight", "mc_dwconv_bwd_data", "mc_bnact_apply", "mc_bnact_pool",
+              "mc_bnact_bwd_reduce", "mc_bnact_bwd_apply", "mc_bnact_se_dgate")
+
+
+def model_cfg(enc_name):
+    return {"name": "clip_custom", "temperature": 0.07,
+            "image_encoder": {"source": "cnn", "name": enc_name, "pretrained": True, "model_type": "cnn"},
+            "text_encoder": {"source": "huggingface", "name": "emilyalsentzer/Bio_ClinicalBERT", "pretrained": False,
+                             "gradient_checkpointing": False, "pooling": "eos", "cache_dir": "", "trust_remote_code": True},
+            "projection_head": {"name": "linear", "dropout": 0.1, "proj_dim": 512}}
+
+
+LOSS_CFG = {"breast_clip": dict(label_smoothing=0.0, i2i_weight=1.0, t2t_weight=0.5, loss_ratio=1.0)}
+
+
+def synth_batch_gpu(b, H, W, T, device, seed):
+    """Synthetic batch resident in HBM: images ~ N(0,1) in the trainer's [b,3,H,W] permuted-NHWC view
+    (trainer_ddp.py:288-291), full-length token rows ([CLS] ... [SEP]) as in SURVEY.md section 8d throughput runs."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    batch = {}
+    for k in ("images", "image_views"):
+        batch[k] = torch.randn((b, H, W, 3), generator=g, device=device).permute(0, 3, 1, 2)
+    for k in ("text_tokens", "text_tokens2"):
+        ids = torch.randint(1000, 28996, (b, T), generator=g, device=device)
+        ids[:, 0], ids[:, -1] = 101, 102
+        batch[k] = {"input_ids": ids, "token_type_ids": torch.zeros_like(ids), "attention_mask": torch.ones_like(ids)}
+    return batch
+
+
+def cpu_baseline(arch_name, H, W, T, budget_s=30.0):
+    """CPU oracle (port of the reference path), train-mode fwd + bwd on ONE pair-group sample, host cores of this box."""
+    from oracle import arch as oarch, bert as obert, clip as oclip, loss as oloss, weights as ow
+    cores = os.cpu_count() or 1
+    threads = min(cores, 64)
+    torch.set_num_threads(threads)
+    arch = oarch.build_arch(arch_name)
+    cfg = obert.BertShape()
+    b = 2                      # BatchNorm needs > 1 value per channel at the last stages
+    sd = ow.synth_state_dict(ow.clip_shapes(arch, cfg), seed=10)
+    sdg = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v) for k, v in sd.items()}
+    batch = ow.synth_batch(b, H, W, T, seed=10, full_length=True)
+    t0 = time.time()
+    out = oclip.forward(sdg, batch, arch, cfg, train=True, new_buffers={})
+    loss = oloss.breast_clip_rank(out["image_embeddings"], out["text_embeddings"], out["text_embeddings2"],
+                                  out["image_view_embeddings"], out["logit_scale"], 0, b)["loss"]
+    loss.backward()
+    dt = time.time() - t0
+    return {"value": round(b / dt, 4), "unit": "image-text pairs/s", "cores": threads, "kind": "port",
+            "sample": f"{b} pairs ({2*b} images {H}x{W} + {2*b} reports T={T}), one train-mode fwd+bwd of the oracle "
+                      f"(no optimizer step), {dt:.1f} s on {threads} threads of {cores} host cores"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=0, help="pairs per GPU (0 = workload default)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--op-profile", action="store_true", help="print a per-entry-point HIP-event breakdown (rank 0)")
+    args = ap.parse_args()
+
+    import mammo_clip_amd  # noqa: F401
+    from mammo_clip_amd import lib as L
+    from mammo_clip_amd import engine
+    from mammo_clip_amd.breastclip import util
+    from mammo_clip_amd.breastclip.loss import build_loss
+    from mammo_clip_amd.breastclip.model import build_model
+    from mammo_clip_amd.breastclip.optimizer import build_optimizer
+    from mammo_clip_amd.breastclip.scheduler import LinearWarmupCosineAnnealingLR
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the HIP path is the only path (no CPU fallback)")
+    L.load()
+    rank, local, world, device = engine.init_distributed()
+    assert world == args.gpus or (world == 1 and args.gpus == 1), f"launched with WORLD_SIZE={world} but --gpus {args.gpus}"
+    enc_name, arch_name, b, H, W, T = WORKLOADS[args.workload]
+    if args.batch:
+        b = args.batch
+    util.GlobalEnv.reset()
+    torch.manual_seed(10)
+    model = build_model(model_cfg(enc_name), LOSS_CFG, types.SimpleNamespace(vocab_size=28996)).to(device)
+    if world > 1:                                  # identical replicas: rank 0's random init everywhere
+        for t in list(model.parameters()) + list(model.buffers()):
+            dist.broadcast(t.data, 0)
+    loss_func = build_loss(LOSS_CFG)
+    opt = build_optimizer(model, {"name": "adamw", "config": {"lr": 5e-5, "weight_decay": 1e-4}})
+    sched = LinearWarmupCosineAnnealingLR(opt, total_steps=10000, warmup_steps=100)
+    trainer = engine.Trainer(model, loss_func, opt, sched, device)
+    batch = synth_batch_gpu(b, H, W, T, device, seed=10 + rank)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        ld = trainer.step(batch)
+    sync()
+    timer = L.OpTimer(only=None if args.op_profile else STREAM_OPS)
+    L.TIMER = timer
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ld = trainer.step(batch)
+    sync()
+    dt = time.perf_counter() - t0
+    L.TIMER = None
+    tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax)
+    loss_val = float(ld["total"])
+    summ = timer.summary()
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        pairs = b * world * args.steps / dt
+        sb = sum(v[2] for k, v in summ.items() if k in STREAM_OPS)
+        st = sum(v[1] for k, v in summ.items() if k in STREAM_OPS)
+        sc = sum(v[0] for k, v in summ.items() if k in STREAM_OPS)
+        ach = sb / (st * 1e-3) / 1e9 if st > 0 else 0.0
+        res = {
+            "metric": "image-text pairs/s (whole node), EN-B5+BioClinicalBERT contrastive pre-training step",
+            "value": round(pairs, 3), "unit": "image-text pairs/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {arch_name} + BioClinicalBERT(BERT-base), {b} pairs/GPU "
+                                   f"(2 views + 2 reports each), {H}x{W} images, {T}-token reports, breast_clip loss, "
+                                   f"AdamW; fwd+loss+bwd+optimizer; dropout/drop-connect on",
+                       "global_batch": b * world, "parallelism": f"dp{world}", "loss": round(loss_val, 5)},
+            "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                         "kernel": "depthwise-conv + BatchNorm/SiLU streaming kernels (" + ",".join(STREAM_OPS) + ")",
+                         "launches": sc, "ms_in_kernels_per_step": round(st / args.steps, 3),
+                         "algorithmic_bytes_per_step": int(sb / args.steps)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                res["cpu_baseline"] = cpu_baseline(arch_name, H, W, T)
+            except Exception as e:                # pragma: no cover
+                res["cpu_baseline"] = {"value": None, "error": repr(e)}
+        if args.op_profile:
+            rows = sorted(summ.items(), key=lambda kv: -kv[1][1])
+            tot = sum(v[1] for _, v in rows)
+            print(f"# per-entry-point HIP-event time over {args.steps} steps (sum {tot:.1f} ms, wall {dt*1e3:.1f} ms)", file=sys.stderr)
+            for k, (cnt, t_ms, by, fl) in rows:
+                print(f"# {k:24s} n={cnt:6d} {t_ms:10.2f} ms {100*t_ms/tot:5.1f}%  {by/(t_ms*1e6+1e-9):8.1f} GB/s "
+                      f"{fl/(t_ms*1e9+1e-9):8.1f} TFLOP/s", file=sys.stderr)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

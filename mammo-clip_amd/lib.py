@@ -134,6 +134,40 @@ def check(status: int, what: str = ""):
         raise MammoClipHipError(f"{what} failed (status {status}): {msg}")
 
 
+class OpTimer:
+    """Optional per-call HIP-event timing of C-ABI launches on torch's current stream (used by bench.py for the
+    live roofline measurement and for per-op breakdowns).  ``only`` restricts timing to a set of entry points."""
+
+    def __init__(self, only=None):
+        self.only = set(only) if only else None
+        self.records = []            # (name, start_event, end_event, (bytes, flops))
+        self.tag = None              # set by ops.* right before a call: algorithmic (bytes, flops) of that launch
+
+    def summary(self):
+        import torch
+        torch.cuda.synchronize()
+        out = {}
+        for name, e0, e1, tag in self.records:
+            ms = e0.elapsed_time(e1)
+            cnt, tot, by, fl = out.get(name, (0, 0.0, 0, 0))
+            out[name] = (cnt + 1, tot + ms, by + (tag[0] if tag else 0), fl + (tag[1] if tag else 0))
+        return out
+
+
+TIMER = None
+
+
 def call(name: str, *args):
     lib = load()
+    t = TIMER
+    if t is not None and (t.only is None or name in t.only):
+        import torch
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        status = getattr(lib, name)(*args)
+        e1.record()
+        t.records.append((name, e0, e1, t.tag))
+        t.tag = None
+        check(status, name)
+        return
     check(getattr(lib, name)(*args), name)

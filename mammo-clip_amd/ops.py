@@ -27,6 +27,12 @@ def _chk_dev(*ts):
             raise L.MammoClipHipError("mammo_clip_amd ops need tensors on a HIP device (there is no CPU fallback)")
 
 
+def _note(nbytes, flops=0):
+    """algorithmic HBM bytes / flops of the next launch (only looked at when bench.py installs a lib.OpTimer)"""
+    if L.TIMER is not None:
+        L.TIMER.tag = (int(nbytes), int(flops))
+
+
 def empty(shape, dtype, like):
     return torch.empty(shape, dtype=dtype, device=like.device)
 
@@ -51,6 +57,8 @@ def gemm(A, B, C_out, M, N, K, lda, ldb, ldc, a_kmajor=0, b_kmajor=0, c_f32=0, c
         a.pro_rows_per_img, a.pro_nch = pro[4], pro[5]
     a.stat_partials = _p(stat_partials)
     a.max_grid_m = max_grid_m
+    _note(batch * (2 * M * K + 2 * N * K + (4 if c_f32 else 2) * M * N + (2 * M * N if R is not None else 0)),
+          2 * batch * M * N * K)
     L.call("mc_gemm_bf16", C.byref(a), _st())
 
 
@@ -175,6 +183,7 @@ def dwconv_fwd(x, w_kkc, n, h, w, c, k, stride, pad_l, pad_t, oh, ow, pro=None, 
         rows = L.load().mc_dwconv_stat_rows(C.byref(a))
         part = empty((rows, 2, c), torch.float32, x)
         a.stat_partials = _p(part)
+    _note(2 * n * c * (h * w + oh * ow), 2 * n * c * oh * ow * k * k)
     L.call("mc_dwconv_fwd", C.byref(a), _st())
     return (y, part) if stats else y
 
@@ -186,6 +195,7 @@ def dwconv_bwd_data(dy, w_kkc, n, h, w, c, k, stride, pad_l, pad_t, oh, ow, w_kk
     a = _dw_args(n, h, w, c, k, stride, pad_l, pad_t, oh, ow)
     dx = empty((n * h * w, c), BF16, dy)
     a.dy, a.out, a.w_kkc = _p(dy), _p(dx), _p(w_kkc)
+    _note(2 * n * c * (h * w + oh * ow), 2 * n * c * oh * ow * k * k)
     L.call("mc_dwconv_bwd_data", C.byref(a), _st())
     return dx
 
@@ -196,6 +206,7 @@ def dwconv_bwd_weight(x, dy, n, h, w, c, k, stride, pad_l, pad_t, oh, ow, pro=No
     a.x, a.dy, a.out = _p(x), _p(dy), _p(dw)
     if pro is not None:
         a.pro_scale, a.pro_shift = _p(pro[0]), _p(pro[1])
+    _note(2 * n * c * (h * w + oh * ow), 2 * n * c * oh * ow * k * k)
     L.call("mc_dwconv_bwd_weight", C.byref(a), _st())
     return dw
 
@@ -236,6 +247,7 @@ def bnact_apply(x, n_img, hw, c, scale, shift, act, rowscale=None, res=None):
     a = _bnact(x, n_img, hw, c, scale, shift, act)
     out = empty((n_img * hw, c), BF16, x)
     a.rowscale, a.res, a.out = _p(rowscale), _p(res), _p(out)
+    _note(2 * n_img * hw * c * (3 if res is not None else 2))
     L.call("mc_bnact_apply", C.byref(a), _st())
     return out
 
@@ -244,6 +256,7 @@ def bnact_pool(x, n_img, hw, c, scale, shift, act):
     a = _bnact(x, n_img, hw, c, scale, shift, act)
     pooled = empty((n_img, c), torch.float32, x)
     a.pooled = _p(pooled)
+    _note(2 * n_img * hw * c)
     L.call("mc_bnact_pool", C.byref(a), _st())
     return pooled
 
@@ -252,6 +265,7 @@ def bnact_se_dgate(x, g, n_img, hw, c, scale, shift, act):
     a = _bnact(x, n_img, hw, c, scale, shift, act)
     dgate = empty((n_img, c), torch.float32, x)
     a.g, a.dgate = _p(g), _p(dgate)
+    _note(4 * n_img * hw * c)
     L.call("mc_bnact_se_dgate", C.byref(a), _st())
     return dgate
 
@@ -265,12 +279,14 @@ def bnact_bwd(x, n_img, hw, c, stats, gamma, act, g=None, mul=None, add=None, ro
     rows = L.load().mc_bnact_rows(C.byref(a))
     part = empty((rows, 2, c), torch.float32, x)
     a.partials = _p(part)
+    _note(2 * n_img * hw * c * (2 if g is not None else 1))
     L.call("mc_bnact_bwd_reduce", C.byref(a), _st())
     buf = empty((5, c), torch.float32, x)        # dgamma, dbeta, coefA, coefB, coefC
     L.call("mc_bn_bwd_finalize", _p(part), rows, c, float(n_img * hw), _p(gamma), _p(stats.mean), _p(stats.invstd),
            _p(buf[0]), _p(buf[1]), _p(buf[2]), _st())
     dx = empty((n_img * hw, c), BF16, x)
     a.coef, a.dx = _p(buf[2]), _p(dx)
+    _note(2 * n_img * hw * c * (3 if g is not None else 2))
     L.call("mc_bnact_bwd_apply", C.byref(a), _st())
     return dx, buf[0], buf[1]
 
