@@ -68,6 +68,8 @@ typedef struct mc_gemm_args {
     int pro_nch;
     float* stat_partials;
     int max_grid_m;          /* 0 = default */
+    float* splitk_ws;        /* optional float[splits*M*N]: split-K partial tiles are combined by a second kernel
+                                (C = sum, or C += sum when c_atomic) instead of per-element atomics */
 } mc_gemm_args;
 int mc_gemm_bf16(const mc_gemm_args* args, void* stream);
 int mc_gemm_stat_rows(const mc_gemm_args* args);

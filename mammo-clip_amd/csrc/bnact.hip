@@ -24,13 +24,21 @@ __global__ void bn_finalize_k(const float* __restrict__ partials, int rows, int 
                               float* __restrict__ rmean, float* __restrict__ rvar, float momentum, float eps,
                               int update, float* __restrict__ mean, float* __restrict__ invstd,
                               float* __restrict__ scale, float* __restrict__ shift) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= c) return;
+    // 256 threads = 16 row-lanes x 16 channels: coalesced 64-byte reads, row-lanes reduced through LDS
+    __shared__ double sh[2][16][17];
+    const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int i = blockIdx.x * 16 + cl;
     double s = 0.0, s2 = 0.0;
-    for (int r = 0; r < rows; ++r) {
-        s += (double)partials[((long long)r * 2) * c + i];
-        s2 += (double)partials[((long long)r * 2 + 1) * c + i];
-    }
+    if (i < c)
+        for (int r = rl; r < rows; r += 16) {
+            s += (double)partials[((long long)r * 2) * c + i];
+            s2 += (double)partials[((long long)r * 2 + 1) * c + i];
+        }
+    sh[0][rl][cl] = s; sh[1][rl][cl] = s2;
+    __syncthreads();
+    if (rl != 0 || i >= c) return;
+    s = 0.0; s2 = 0.0;
+    for (int r = 0; r < 16; ++r) { s += sh[0][r][cl]; s2 += sh[1][r][cl]; }
     double m = s / count;
     double var = s2 / count - m * m;
     if (var < 0.0) var = 0.0;
@@ -234,13 +242,20 @@ __global__ void bn_bwd_finalize_k(const float* __restrict__ partials, int rows, 
                                   const float* __restrict__ gamma, const float* __restrict__ mean,
                                   const float* __restrict__ invstd, float* __restrict__ dgamma,
                                   float* __restrict__ dbeta, float* __restrict__ coef) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= c) return;
+    __shared__ double sh[2][16][17];
+    const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int i = blockIdx.x * 16 + cl;
     double s0 = 0.0, s1 = 0.0;
-    for (int r = 0; r < rows; ++r) {
-        s0 += (double)partials[((long long)r * 2) * c + i];
-        s1 += (double)partials[((long long)r * 2 + 1) * c + i];
-    }
+    if (i < c)
+        for (int r = rl; r < rows; r += 16) {
+            s0 += (double)partials[((long long)r * 2) * c + i];
+            s1 += (double)partials[((long long)r * 2 + 1) * c + i];
+        }
+    sh[0][rl][cl] = s0; sh[1][rl][cl] = s1;
+    __syncthreads();
+    if (rl != 0 || i >= c) return;
+    s0 = 0.0; s1 = 0.0;
+    for (int r = 0; r < 16; ++r) { s0 += sh[0][r][cl]; s1 += sh[1][r][cl]; }
     dbeta[i] = (float)s0;
     dgamma[i] = (float)s1;
     double gi = (double)gamma[i] * (double)invstd[i];
@@ -365,7 +380,7 @@ extern "C" int mc_bn_finalize(const float* partials, int rows, int c, double cou
                               int update_running, float* mean, float* invstd, float* scale, float* shift, void* stream) {
     MC_CHECK(partials && gamma && beta && mean && invstd && scale && shift && rows > 0 && c > 0 && count > 0, "bn_finalize: bad args");
     MC_CHECK(!update_running || (running_mean && running_var), "bn_finalize: running buffers missing");
-    hipLaunchKernelGGL(bn_finalize_k, dim3(mc_div_up(c, 128)), dim3(128), 0, (hipStream_t)stream, partials, rows, c, count,
+    hipLaunchKernelGGL(bn_finalize_k, dim3(mc_div_up(c, 16)), dim3(256), 0, (hipStream_t)stream, partials, rows, c, count,
                        gamma, beta, running_mean, running_var, momentum, eps, update_running, mean, invstd, scale, shift);
     MC_LAUNCH_CHECK();
     return MC_OK;
@@ -453,7 +468,7 @@ extern "C" int mc_bn_bwd_finalize(const float* partials, int rows, int c, double
                                   const float* mean, const float* invstd, float* dgamma, float* dbeta, float* coef,
                                   void* stream) {
     MC_CHECK(partials && gamma && mean && invstd && dgamma && dbeta && coef && rows > 0 && c > 0, "bn_bwd_finalize: bad args");
-    hipLaunchKernelGGL(bn_bwd_finalize_k, dim3(mc_div_up(c, 128)), dim3(128), 0, (hipStream_t)stream, partials, rows, c,
+    hipLaunchKernelGGL(bn_bwd_finalize_k, dim3(mc_div_up(c, 16)), dim3(256), 0, (hipStream_t)stream, partials, rows, c,
                        count, gamma, mean, invstd, dgamma, dbeta, coef);
     MC_LAUNCH_CHECK();
     return MC_OK;

@@ -270,7 +270,21 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const mc_gemm_args p) {
 
         // ---------------- epilogue ----------------
         const float alpha = p.alpha;
-        if (p.c_f32) {
+        if (p.c_f32 && p.splits > 1 && p.splitk_ws) {
+            // split-K partial tile -> workspace [split][M][N] (plain stores; reduced by splitk_reduce_kernel)
+            float* Wp = p.splitk_ws + (long long)split * p.M * p.N;
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j) {
+                    int n = n0 + wn * WN + j * 16 + (lane & 15);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        long long m = m0 + wm * WM + i * 16 + (lane >> 4) * 4 + r;
+                        if (m < p.M && n < p.N) Wp[m * p.N + n] = acc[i][j][r] * alpha;
+                    }
+                }
+        } else if (p.c_f32) {
             float* C = reinterpret_cast<float*>(p.C) + coff;
 #pragma unroll
             for (int i = 0; i < FM; ++i)
@@ -365,11 +379,43 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const mc_gemm_args p) {
     }
 }
 
+// C[m,n] (+)= sum_s ws[s][m][n]  (deterministic split-K combine; replaces per-element atomics)
+__global__ void splitk_reduce_kernel(const float* __restrict__ ws, int splits, long long mn, int n, float* __restrict__ C,
+                                     long long ldc, int accumulate) {
+    long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= mn) return;
+    if (i + 4 <= mn && (n & 3) == 0) {
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = 0; k < splits; ++k) {
+            float4 v = *reinterpret_cast<const float4*>(ws + (long long)k * mn + i);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        long long m = i / n;
+        int c = (int)(i % n);
+        float* d = C + m * ldc + c;
+        if (accumulate) { d[0] += s.x; d[1] += s.y; d[2] += s.z; d[3] += s.w; }
+        else { d[0] = s.x; d[1] = s.y; d[2] = s.z; d[3] = s.w; }
+    } else {
+        for (long long j = i; j < mn && j < i + 4; ++j) {
+            float s = 0.f;
+            for (int k = 0; k < splits; ++k) s += ws[(long long)k * mn + j];
+            float* d = C + (j / n) * ldc + (j % n);
+            *d = accumulate ? *d + s : s;
+        }
+    }
+}
+
 template <int BM, int BN, int BK, int WGM, int WGN>
 int launch(const mc_gemm_args& p, int grid_m, hipStream_t st) {
     dim3 grid(mc_div_up(p.N, BN), grid_m, p.batch * p.splits);
     hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, BK, WGM, WGN>), grid, dim3(256), 0, st, p);
     MC_LAUNCH_CHECK();
+    if (p.splits > 1 && p.splitk_ws) {
+        long long mn = p.M * p.N;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(mc_div_up(mc_div_up(mn, 4), 256)), dim3(256), 0, st, p.splitk_ws,
+                           p.splits, mn, p.N, reinterpret_cast<float*>(p.C), p.ldc, p.c_atomic);
+        MC_LAUNCH_CHECK();
+    }
     return MC_OK;
 }
 
@@ -395,7 +441,8 @@ extern "C" int mc_gemm_bf16(const mc_gemm_args* a, void* stream) {
     if (p.batch <= 0) p.batch = 1;
     if (p.nb2 <= 0) p.nb2 = 1;
     if (p.splits <= 0) p.splits = 1;
-    MC_CHECK(p.splits == 1 || (p.c_f32 && p.c_atomic), "gemm: split-K needs fp32 atomic output");
+    MC_CHECK(p.splits == 1 || (p.c_f32 && (p.c_atomic || p.splitk_ws)), "gemm: split-K needs fp32 output + workspace or atomics");
+    MC_CHECK(!(p.splits > 1 && p.splitk_ws) || (p.batch == 1 && !p.bias), "gemm: workspace split-K is unbatched, no bias");
     MC_CHECK(!(p.stat_partials && (p.c_f32 || p.batch != 1 || p.splits != 1)), "gemm: stats need plain bf16 output");
     MC_CHECK(p.pro_operand == 0 || (p.pro_scale && p.pro_shift), "gemm: prologue needs scale/shift");
     MC_CHECK(p.pro_operand != 1 || !p.a_kmajor, "gemm: A prologue needs k-contiguous A");

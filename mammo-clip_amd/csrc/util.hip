@@ -135,10 +135,17 @@ __global__ __launch_bounds__(256) void colsum_partial_k(const bf16_t* __restrict
 }
 __global__ void colsum_final_k(const float* __restrict__ partials, int rows, int c, float* __restrict__ out,
                                int accumulate) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= c) return;
+    __shared__ double sh[16][17];
+    const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int i = blockIdx.x * 16 + cl;
     double s = 0.0;
-    for (int r = 0; r < rows; ++r) s += (double)partials[(long long)r * c + i];
+    if (i < c)
+        for (int r = rl; r < rows; r += 16) s += (double)partials[(long long)r * c + i];
+    sh[rl][cl] = s;
+    __syncthreads();
+    if (rl != 0 || i >= c) return;
+    s = 0.0;
+    for (int r = 0; r < 16; ++r) s += sh[r][cl];
     out[i] = accumulate ? out[i] + (float)s : (float)s;
 }
 
@@ -211,7 +218,7 @@ extern "C" int mc_colsum_bf16(const mc_bf16* x, long long m, int c, long long ld
     int rows = mc_colsum_rows(m, c);
     hipLaunchKernelGGL(colsum_partial_k, dim3(rows), dim3(256), 0, (hipStream_t)stream, x, m, c, ld, partials);
     MC_LAUNCH_CHECK();
-    hipLaunchKernelGGL(colsum_final_k, dim3(mc_div_up(c, 256)), dim3(256), 0, (hipStream_t)stream, partials, rows, c,
+    hipLaunchKernelGGL(colsum_final_k, dim3(mc_div_up(c, 16)), dim3(256), 0, (hipStream_t)stream, partials, rows, c,
                        out, accumulate);
     MC_LAUNCH_CHECK();
     return MC_OK;

@@ -31,6 +31,7 @@ class GemmArgs(C.Structure):
         ("pro_rows_per_img", LL), ("pro_nch", I),
         ("stat_partials", P),
         ("max_grid_m", I),
+        ("splitk_ws", P),
     ]
 
 
@@ -157,7 +158,7 @@ class OpTimer:
 TIMER = None
 
 
-def call(name: str, *args):
+def call(name: str, *args, kind=None):
     lib = load()
     t = TIMER
     if t is not None and (t.only is None or name in t.only):
@@ -166,7 +167,7 @@ def call(name: str, *args):
         e0.record()
         status = getattr(lib, name)(*args)
         e1.record()
-        t.records.append((name, e0, e1, t.tag))
+        t.records.append((name if kind is None else f"{name}:{kind}", e0, e1, t.tag))
         t.tag = None
         check(status, name)
         return

@@ -40,7 +40,7 @@ def empty(shape, dtype, like):
 # ------------------------------------------------------------------------------------------- GEMM
 def gemm(A, B, C_out, M, N, K, lda, ldb, ldc, a_kmajor=0, b_kmajor=0, c_f32=0, c_atomic=0, splits=1,
          batch=1, nb2=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), bias=None, bias_stride1=0, act=0, R=None, ldr=0,
-         alpha=1.0, pro=None, stat_partials=None, max_grid_m=0):
+         alpha=1.0, pro=None, stat_partials=None, max_grid_m=0, splitk_ws=None, kind=None):
     """pro = (operand, scale, shift, gate or None, rows_per_img, nch)"""
     a = L.GemmArgs()
     a.A, a.B, a.C = _p(A), _p(B), _p(C_out)
@@ -57,9 +57,10 @@ def gemm(A, B, C_out, M, N, K, lda, ldb, ldc, a_kmajor=0, b_kmajor=0, c_f32=0, c
         a.pro_rows_per_img, a.pro_nch = pro[4], pro[5]
     a.stat_partials = _p(stat_partials)
     a.max_grid_m = max_grid_m
+    a.splitk_ws = _p(splitk_ws)
     _note(batch * (2 * M * K + 2 * N * K + (4 if c_f32 else 2) * M * N + (2 * M * N if R is not None else 0)),
           2 * batch * M * N * K)
-    L.call("mc_gemm_bf16", C.byref(a), _st())
+    L.call("mc_gemm_bf16", C.byref(a), _st(), kind=kind)
 
 
 def gemm_stat_rows(M):
@@ -80,7 +81,7 @@ def linear_fwd(x, w, bias=None, act=0, residual=None, stats=False, pro=None, out
     if pro is not None:
         p = (1, pro[0], pro[1], pro[2], pro[3], K)
     gemm(x, w, y, M, N, K, x.stride(0), w.stride(0), y.stride(0), bias=bias, act=act, R=residual,
-         ldr=(residual.stride(0) if residual is not None else 0), pro=p, stat_partials=part)
+         ldr=(residual.stride(0) if residual is not None else 0), pro=p, stat_partials=part, kind="fwd")
     return (y, part) if stats else y
 
 
@@ -90,14 +91,14 @@ def linear_dgrad(dy, w, residual=None):
     K = w.shape[1]
     dx = empty((M, K), BF16, dy)
     gemm(dy, w, dx, M, K, N, dy.stride(0), w.stride(0), dx.stride(0), b_kmajor=1, R=residual,
-         ldr=(residual.stride(0) if residual is not None else 0))
+         ldr=(residual.stride(0) if residual is not None else 0), kind="dgrad")
     return dx
 
 
 def _wgrad_splits(m, n, k):
     tiles = math.ceil(m / 128) * math.ceil(n / (128 if n > 64 else (64 if n > 32 else 32)))
     ktiles = math.ceil(k / 64)
-    s = max(1, min(math.ceil(2048 / tiles), max(1, ktiles // 4)))
+    s = max(1, min(math.ceil(1024 / tiles), max(1, ktiles // 8)))
     return s
 
 
@@ -105,12 +106,14 @@ def linear_wgrad(dy, x, pro=None, out=None):
     """dw[N,K] (fp32) = dy[M,N]^T . x'[M,K]; x' = prologue(x) when pro = (scale, shift, gate, rows_per_img)."""
     M, N = dy.shape
     K = x.shape[1]
-    dw = out if out is not None else torch.zeros((N, K), dtype=torch.float32, device=dy.device)
+    dw = out if out is not None else empty((N, K), torch.float32, dy)
     p = None
     if pro is not None:
         p = (2, pro[0], pro[1], pro[2], pro[3], K)
-    gemm(dy, x, dw, N, K, M, dy.stride(0), x.stride(0), dw.stride(0), a_kmajor=1, b_kmajor=1, c_f32=1, c_atomic=1,
-         splits=_wgrad_splits(N, K, M), pro=p)
+    splits = _wgrad_splits(N, K, M)
+    ws = empty((splits, N, K), torch.float32, dy) if splits > 1 else None
+    gemm(dy, x, dw, N, K, M, dy.stride(0), x.stride(0), dw.stride(0), a_kmajor=1, b_kmajor=1, c_f32=1,
+         c_atomic=(1 if out is not None else 0), splits=splits, pro=p, splitk_ws=ws, kind="wgrad")
     return dw
 
 
