@@ -74,11 +74,62 @@ typedef struct mc_gemm_args {
 int mc_gemm_bf16(const mc_gemm_args* args, void* stream);
 int mc_gemm_stat_rows(const mc_gemm_args* args);
 
+/* Row-streaming variant for the HBM-bound 1x1 convolutions (small weight matrix, millions of pixels):
+ *   C[M,N] = pro(X)[M,K] . W[N,K]^T (+ R);  N <= 256, K <= 384 (mc_gemm_rows_supported), bf16 in/out.
+ * Weights live in LDS for the whole launch, each workgroup writes complete, contiguous output rows.
+ * The data gradient of a 1x1 conv is the same call with the transposed weight (mc_cast_transpose_f32_bf16).
+ * stat_partials (optional): float[mc_gemm_rows_blocks(M)][2][N] column sums / sums of squares of C. */
+typedef struct mc_gemm_rows_args {
+    const mc_bf16* X;
+    long long M;
+    int K;
+    long long ldx;
+    const mc_bf16* W;
+    int N;
+    long long ldw;
+    mc_bf16* C;
+    long long ldc;
+    const mc_bf16* R;
+    long long ldr;
+    const float* pro_scale;
+    const float* pro_shift;
+    const float* pro_gate;
+    long long pro_rows_per_img;
+    float* stat_partials;
+} mc_gemm_rows_args;
+int mc_gemm_rows_supported(int n, int k);
+int mc_gemm_rows_blocks(long long m);
+int mc_gemm_rows_bf16(const mc_gemm_rows_args* args, void* stream);
+
+/* Streaming weight gradient of the same layers: dW[N,K] (fp32) (+)= dY[M,N]^T . pro(X)[M,K]; both operands are
+ * staged row-major and read with gfx950's LDS transpose-read (ds_read_b64_tr_b16); no atomics.
+ * ws: float[mc_wgrad_rows_blocks(M) * N * K] scratch (per-workgroup partials, reduced by a second kernel). */
+typedef struct mc_wgrad_rows_args {
+    const mc_bf16* dY;
+    int N;
+    long long lddy;
+    const mc_bf16* X;
+    int K;
+    long long ldx;
+    long long M;
+    float* dW;               /* [N, K] contiguous */
+    float* ws;
+    int accumulate;
+    const float* pro_scale;  /* prologue on X: silu(x*scale[k] + shift[k]) * gate[(m / rows_per_img) * K + k] */
+    const float* pro_shift;
+    const float* pro_gate;
+    long long pro_rows_per_img;
+} mc_wgrad_rows_args;
+int mc_wgrad_rows_supported(int n, int k);
+int mc_wgrad_rows_blocks(long long m);
+int mc_wgrad_rows_bf16(const mc_wgrad_rows_args* args, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * small helpers */
 int mc_cast_f32_bf16(const float* src, mc_bf16* dst, long long n, void* stream);
 int mc_cast_bf16_f32(const mc_bf16* src, float* dst, long long n, void* stream);
 int mc_transpose_f32(const float* src, float* dst, int rows, int cols, void* stream); /* dst[c][r] = src[r][c] */
+int mc_cast_transpose_f32_bf16(const float* src, mc_bf16* dst, int rows, int cols, void* stream); /* dst[c][r] = bf16(src[r][c]) */
 /* stem weight [C0,3,3,3] fp32 (OIHW) -> bf16 [C0,32], k = cin*9 + kh*3 + kw, zero padded 27..31 */
 int mc_stem_weight_prep(const float* w, mc_bf16* out, int c0, void* stream);
 
@@ -171,7 +222,7 @@ int mc_colsum_bf16(const mc_bf16* x, long long m, int c, long long ld, float* pa
  * squeeze-excite MLP on pooled features [ref: efficientnet_custom.py:114-119]
  *   r = silu(w1 . pooled + b1);  gate = sigmoid(w2 . r + b2);  w1 [cs, c], w2 [c, cs] fp32 */
 int mc_se_fwd(const float* pooled, const float* w1, const float* b1, const float* w2, const float* b2,
-              int n, int c, int cs, float* gate, void* stream);
+              int n, int c, int cs, float* gate, float* ws /* float[n*cs] scratch */, void* stream);
 /* ws: float[n * (c + 2*cs)] scratch; dw*, db* are accumulated (+=) */
 int mc_se_bwd(const float* pooled, const float* gate, const float* dgate, const float* w1, const float* b1,
               const float* w2, const float* b2, int n, int c, int cs, float* dpooled, float* dw1, float* db1,

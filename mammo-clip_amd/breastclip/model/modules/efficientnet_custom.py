@@ -189,7 +189,8 @@ class _MBConvFn(torch.autograd.Function):
         # y = bn2(p) * rowscale + x
         dp, dg2, db2 = ops.bnact_bwd(p, n, ohw, a.cout, st2, blk._bn2.weight, 0, g=dy, rowscale=sv["rowscale"])
         # project 1x1: p = A1 . wp^T, A1 = silu(bn1(d)) * gate   (A1 is recomputed inside the wgrad GEMM)
-        da1 = ops.linear_dgrad(dp, sv["wp"])
+        wp_t = ops.cast_transpose_bf16(blk._project_conv.weight.view(a.cout, a.cexp))      # [cexp, cout]
+        da1 = ops.linear_dgrad(dp, sv["wp"], w_t=wp_t)
         dwp = ops.linear_wgrad(dp, d, pro=(st1.scale, st1.shift, gate, ohw))
         # squeeze-excite
         dgate = ops.bnact_se_dgate(d, da1, n, ohw, a.cexp, st1.scale, st1.shift, 1)
@@ -214,7 +215,8 @@ class _MBConvFn(torch.autograd.Function):
         if a.expand != 1:
             de, dg0, db0 = ops.bnact_bwd(sv["e"], n, hw, a.cexp, st0, blk._bn0.weight, 1, g=da0)
             del da0
-            dx = ops.linear_dgrad(de, sv["we"], residual=dy if a.skip else None)
+            we_t = ops.cast_transpose_bf16(blk._expand_conv.weight.view(a.cexp, a.cin))     # [cin, cexp]
+            dx = ops.linear_dgrad(de, sv["we"], residual=dy if a.skip else None, w_t=we_t)
             dwe = ops.linear_wgrad(de, x)
             grads["_expand_conv.weight"] = dwe.view(a.cexp, a.cin, 1, 1)
             grads["_bn0.weight"], grads["_bn0.bias"] = dg0, db0

@@ -265,68 +265,79 @@ __global__ void bn_bwd_finalize_k(const float* __restrict__ partials, int rows, 
 }
 
 // ---------------------------------------------------------------- squeeze-excite MLP
-__global__ __launch_bounds__(256) void se_fwd_k(const float* __restrict__ pooled, const float* __restrict__ w1,
-                                                const float* __restrict__ b1, const float* __restrict__ w2,
-                                                const float* __restrict__ b2, int c, int cs, float* __restrict__ gate) {
-    extern __shared__ float sh[];                      // r[cs]
-    const int img = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+// The MLP is tiny (c x c/24 weights) but sits on the critical path twice per block: spread it over many
+// workgroups (one wave per hidden unit / one thread per channel) instead of one workgroup per image.
+__global__ __launch_bounds__(256) void se_hidden_k(const float* __restrict__ pooled, const float* __restrict__ w1,
+                                                   const float* __restrict__ b1, int c, int cs,
+                                                   float* __restrict__ u_out, float* __restrict__ r_out) {
+    const int img = blockIdx.y, lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= cs) return;
     const float* pv = pooled + (long long)img * c;
-    for (int j = wave; j < cs; j += 4) {
-        float s = 0.f;
-        for (int i = lane; i < c; i += 64) s += w1[(long long)j * c + i] * pv[i];
-        s = wave_sum(s);
-        if (lane == 0) sh[j] = silu_f(s + b1[j]);
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < c; i += 256) {
-        float s = b2[i];
-        for (int j = 0; j < cs; ++j) s += w2[(long long)i * cs + j] * sh[j];
-        gate[(long long)img * c + i] = sigmoid_f(s);
+    float s = 0.f;
+    for (int i = lane; i < c; i += 64) s += w1[(long long)j * c + i] * pv[i];
+    s = wave_sum(s);
+    if (lane == 0) {
+        float u = s + b1[j];
+        if (u_out) u_out[(long long)img * cs + j] = u;
+        r_out[(long long)img * cs + j] = silu_f(u);
     }
 }
+__global__ __launch_bounds__(256) void se_gate_k(const float* __restrict__ r, const float* __restrict__ w2,
+                                                 const float* __restrict__ b2, int c, int cs, float* __restrict__ gate) {
+    extern __shared__ float sh[];
+    const int img = blockIdx.y;
+    for (int j = threadIdx.x; j < cs; j += 256) sh[j] = r[(long long)img * cs + j];
+    __syncthreads();
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= c) return;
+    float s = b2[i];
+    for (int j = 0; j < cs; ++j) s += w2[(long long)i * cs + j] * sh[j];
+    gate[(long long)img * c + i] = sigmoid_f(s);
+}
 
-// per image: ds = dgate*gate*(1-gate); r, du; dpooled.  ws layout per image: ds[c] | r[cs] | du[cs]
-__global__ __launch_bounds__(256) void se_bwd_k(const float* __restrict__ pooled, const float* __restrict__ gate,
-                                                const float* __restrict__ dgate, const float* __restrict__ w1,
-                                                const float* __restrict__ b1, const float* __restrict__ w2, int c,
-                                                int cs, float* __restrict__ dpooled, float* __restrict__ ws) {
-    extern __shared__ float sh[];                      // ds[c] | u[cs] | du[cs]
-    float* ds = sh;
-    float* u = sh + c;
-    float* du = u + cs;
-    const int img = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+// ws layout per image: ds[c] | r[cs] | du[cs] ; u is staged in the du slot between the two hidden kernels
+__global__ __launch_bounds__(256) void se_bwd_ds_k(const float* __restrict__ gate, const float* __restrict__ dgate, int c,
+                                                   int cs, float* __restrict__ ws) {
+    const int img = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= c) return;
+    float g = gate[(long long)img * c + i];
+    ws[(long long)img * (c + 2 * cs) + i] = dgate[(long long)img * c + i] * g * (1.f - g);
+}
+__global__ __launch_bounds__(256) void se_bwd_hidden_k(const float* __restrict__ pooled, const float* __restrict__ w1,
+                                                       const float* __restrict__ b1, const float* __restrict__ w2, int c,
+                                                       int cs, float* __restrict__ ws) {
+    const int img = blockIdx.y, lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= cs) return;
     const float* pv = pooled + (long long)img * c;
     float* wsi = ws + (long long)img * (c + 2 * cs);
-    for (int i = threadIdx.x; i < c; i += 256) {
-        float g = gate[(long long)img * c + i];
-        float d = dgate[(long long)img * c + i] * g * (1.f - g);
-        ds[i] = d;
-        wsi[i] = d;
+    float s = 0.f, d = 0.f;
+    for (int i = lane; i < c; i += 64) {
+        s += w1[(long long)j * c + i] * pv[i];
+        d += w2[(long long)i * cs + j] * wsi[i];
     }
-    for (int j = wave; j < cs; j += 4) {
-        float s = 0.f;
-        for (int i = lane; i < c; i += 64) s += w1[(long long)j * c + i] * pv[i];
-        s = wave_sum(s);
-        if (lane == 0) u[j] = s + b1[j];
+    s = wave_sum(s);
+    d = wave_sum(d);
+    if (lane == 0) {
+        float u = s + b1[j];
+        wsi[c + j] = silu_f(u);
+        wsi[c + cs + j] = d * silu_grad_f(u);
     }
+}
+__global__ __launch_bounds__(256) void se_bwd_dpool_k(const float* __restrict__ w1, int c, int cs,
+                                                      const float* __restrict__ ws, float* __restrict__ dpooled) {
+    extern __shared__ float sh[];
+    const int img = blockIdx.y;
+    const float* wsi = ws + (long long)img * (c + 2 * cs);
+    for (int j = threadIdx.x; j < cs; j += 256) sh[j] = wsi[c + cs + j];
     __syncthreads();
-    for (int j = wave; j < cs; j += 4) {
-        float s = 0.f;
-        for (int i = lane; i < c; i += 64) s += w2[(long long)i * cs + j] * ds[i];
-        s = wave_sum(s);
-        if (lane == 0) {
-            float d = s * silu_grad_f(u[j]);
-            du[j] = d;
-            wsi[c + j] = silu_f(u[j]);
-            wsi[c + cs + j] = d;
-        }
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < c; i += 256) {
-        float s = 0.f;
-        for (int j = 0; j < cs; ++j) s += w1[(long long)j * c + i] * du[j];
-        dpooled[(long long)img * c + i] = s;
-    }
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= c) return;
+    float s = 0.f;
+    for (int j = 0; j < cs; ++j) s += w1[(long long)j * c + i] * sh[j];
+    dpooled[(long long)img * c + i] = s;
 }
 
 // weight / bias gradients, reduced over the n images (no atomics)
@@ -474,9 +485,12 @@ extern "C" int mc_bn_bwd_finalize(const float* partials, int rows, int c, double
     return MC_OK;
 }
 extern "C" int mc_se_fwd(const float* pooled, const float* w1, const float* b1, const float* w2, const float* b2, int n,
-                         int c, int cs, float* gate, void* stream) {
-    MC_CHECK(pooled && w1 && b1 && w2 && b2 && gate && n > 0 && c > 0 && cs > 0, "se_fwd: bad args");
-    hipLaunchKernelGGL(se_fwd_k, dim3(n), dim3(256), cs * sizeof(float), (hipStream_t)stream, pooled, w1, b1, w2, b2, c, cs, gate);
+                         int c, int cs, float* gate, float* ws, void* stream) {
+    MC_CHECK(pooled && w1 && b1 && w2 && b2 && gate && ws && n > 0 && c > 0 && cs > 0, "se_fwd: bad args");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(se_hidden_k, dim3(mc_div_up(cs, 4), n), dim3(256), 0, st, pooled, w1, b1, c, cs, (float*)nullptr, ws);
+    MC_LAUNCH_CHECK();
+    hipLaunchKernelGGL(se_gate_k, dim3(mc_div_up(c, 256), n), dim3(256), cs * sizeof(float), st, ws, w2, b2, c, cs, gate);
     MC_LAUNCH_CHECK();
     return MC_OK;
 }
@@ -486,12 +500,15 @@ extern "C" int mc_se_bwd(const float* pooled, const float* gate, const float* dg
     MC_CHECK(pooled && gate && dgate && w1 && b1 && w2 && dpooled && dw1 && db1 && dw2 && db2 && ws, "se_bwd: null arg");
     MC_CHECK(n > 0 && c > 0 && cs > 0, "se_bwd: bad shape");
     (void)b2;
-    hipLaunchKernelGGL(se_bwd_k, dim3(n), dim3(256), (c + 2 * cs) * sizeof(float), (hipStream_t)stream, pooled, gate, dgate,
-                       w1, b1, w2, c, cs, dpooled, ws);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(se_bwd_ds_k, dim3(mc_div_up(c, 256), n), dim3(256), 0, st, gate, dgate, c, cs, ws);
+    MC_LAUNCH_CHECK();
+    hipLaunchKernelGGL(se_bwd_hidden_k, dim3(mc_div_up(cs, 4), n), dim3(256), 0, st, pooled, w1, b1, w2, c, cs, ws);
+    MC_LAUNCH_CHECK();
+    hipLaunchKernelGGL(se_bwd_dpool_k, dim3(mc_div_up(c, 256), n), dim3(256), cs * sizeof(float), st, w1, c, cs, ws, dpooled);
     MC_LAUNCH_CHECK();
     long long total = 2LL * c * cs + c + cs;
-    hipLaunchKernelGGL(se_wgrad_k, dim3(mc_div_up(total, 256)), dim3(256), 0, (hipStream_t)stream, pooled, ws, n, c, cs, dw1,
-                       db1, dw2, db2);
+    hipLaunchKernelGGL(se_wgrad_k, dim3(mc_div_up(total, 256)), dim3(256), 0, st, pooled, ws, n, c, cs, dw1, db1, dw2, db2);
     MC_LAUNCH_CHECK();
     return MC_OK;
 }

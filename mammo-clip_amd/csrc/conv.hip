@@ -36,21 +36,35 @@ __device__ __forceinline__ void stage_input(const mc_dwconv_args& p, unsigned ch
     const int cv = tid & 7;
     const int c = c0 + cv * 8;
     const int iy0 = oy0 * S - p.pad_t, ix0 = ox0 * S - p.pad_l;
-    for (int v = tid >> 3; v < C::IH_T * C::IW_T; v += 32) {
+    // issue ALL global loads of the halo tile first (independent, in flight together), then activate + store
+    constexpr int NV = (C::IH_T * C::IW_T + 31) / 32;
+    uint4 vals[NV];
+    unsigned inb = 0;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        int v = (tid >> 3) + i * 32;
         int ty = v / C::IW_T, tx = v % C::IW_T;
         int iy = iy0 + ty, ix = ix0 + tx;
-        uint4 val = make_uint4(0u, 0u, 0u, 0u);
-        if (c < p.c && iy >= 0 && iy < p.h && ix >= 0 && ix < p.w) {
-            val = *reinterpret_cast<const uint4*>(p.x + ((img * p.h + iy) * (long long)p.w + ix) * p.c + c);
-            if (has_pro) {
+        vals[i] = make_uint4(0u, 0u, 0u, 0u);
+        if (v < C::IH_T * C::IW_T && c < p.c && iy >= 0 && iy < p.h && ix >= 0 && ix < p.w) {
+            vals[i] = *reinterpret_cast<const uint4*>(p.x + ((img * p.h + iy) * (long long)p.w + ix) * p.c + c);
+            inb |= 1u << i;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        int v = (tid >> 3) + i * 32;
+        if (v < C::IH_T * C::IW_T) {
+            uint4 val = vals[i];
+            if (has_pro && ((inb >> i) & 1u)) {
                 float f[8];
                 unpack8(val, f);
 #pragma unroll
                 for (int q = 0; q < 8; ++q) f[q] = silu_f(f[q] * ps[q] + pt[q]);
                 val = pack8(f);
             }
+            *reinterpret_cast<uint4*>(tile + v * PIXB + cv * 16) = val;
         }
-        *reinterpret_cast<uint4*>(tile + v * PIXB + cv * 16) = val;
     }
 }
 

@@ -89,236 +89,233 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const mc_gemm_args p) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) { colsum[i] = 0.f; colsq[i] = 0.f; }
 
-    for (long long mt = blockIdx.y; mt < mtiles; mt += gridDim.y) {
+    uint4 ra[A_REGS], rb[B_REGS];
+
+    // ---- global -> registers (all loads of a tile are issued back to back; nothing waits here)
+    auto load_tiles = [&](long long m0, long long k0) {
+        if (!p.a_kmajor) {
+#pragma unroll
+            for (int i = 0; i < A_CH; ++i) {
+                int c = tid + i * 256;
+                int row = c / KCH, kc = c % KCH;
+                long long m = m0 + row, k = k0 + kc * 8;
+                uint4 v = zero4();
+                if (c < BM * KCH && m < p.M && k < kend) v = *reinterpret_cast<const uint4*>(A + m * p.lda + k);
+                ra[i] = v;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < A_CHT; ++i) {
+                int c = tid + i * 256;
+                int xc = c % (BM / 8), kp = c / (BM / 8);
+                long long m = m0 + xc * 8, k = k0 + 2 * kp;
+                uint4 v0 = zero4(), v1 = zero4();
+                if (c < KP * (BM / 8) && m < p.M) {
+                    if (k < kend) v0 = *reinterpret_cast<const uint4*>(A + k * p.lda + m);
+                    if (k + 1 < kend) v1 = *reinterpret_cast<const uint4*>(A + (k + 1) * p.lda + m);
+                }
+                ra[2 * i] = v0; ra[2 * i + 1] = v1;
+            }
+        }
+        if (!p.b_kmajor) {
+#pragma unroll
+            for (int i = 0; i < B_CH; ++i) {
+                int c = tid + i * 256;
+                int row = c / KCH, kc = c % KCH;
+                long long n = n0 + row, k = k0 + kc * 8;
+                uint4 v = zero4();
+                if (c < BN * KCH && n < p.N && k < kend) v = *reinterpret_cast<const uint4*>(B + n * p.ldb + k);
+                rb[i] = v;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < B_CHT; ++i) {
+                int c = tid + i * 256;
+                int xc = c % (BN / 8), kp = c / (BN / 8);
+                long long n = n0 + xc * 8, k = k0 + 2 * kp;
+                uint4 v0 = zero4(), v1 = zero4();
+                if (c < KP * (BN / 8) && n < p.N) {
+                    if (k < kend) v0 = *reinterpret_cast<const uint4*>(B + k * p.ldb + n);
+                    if (k + 1 < kend) v1 = *reinterpret_cast<const uint4*>(B + (k + 1) * p.ldb + n);
+                }
+                rb[2 * i] = v0; rb[2 * i + 1] = v1;
+            }
+        }
+    };
+
+    // ---- registers -> LDS (the fused BN+SiLU(+gate) prologue is applied here, after the loads have landed).
+    // k-major operands are transposed on the way in: a thread holds rows k, k+1 for 8 consecutive x and writes
+    // 8 dwords {x_j: (k, k+1)}.  The 16-byte slot inside the row is XOR-swizzled with (x >> 3) & 7 so the
+    // 32-lane write groups do not pile onto one bank; the fragment reader applies the same XOR.
+    auto store_tiles = [&](int buf, long long m0, long long k0) {
+        unsigned char* sA = smem + buf * STAGE_BYTES;
+        unsigned char* sB = sA + BM * ROWB;
+        if (!p.a_kmajor) {
+#pragma unroll
+            for (int i = 0; i < A_CH; ++i) {
+                int c = tid + i * 256;
+                if (c < BM * KCH) {
+                    int row = c / KCH, kc = c % KCH;
+                    uint4 v = ra[i];
+                    if (p.pro_operand == 1) {
+                        long long m = m0 + row, k = k0 + kc * 8;
+                        if (m < p.M && k < kend) v = apply_prologue(v, p, m, (int)k);
+                    }
+                    *reinterpret_cast<uint4*>(sA + row * ROWB + kc * 16) = v;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < A_CHT; ++i) {
+                int c = tid + i * 256;
+                if (c < KP * (BM / 8)) {
+                    int xc = c % (BM / 8), kp = c / (BM / 8);
+                    const uint32_t* w0 = reinterpret_cast<const uint32_t*>(&ra[2 * i]);
+                    const uint32_t* w1 = reinterpret_cast<const uint32_t*>(&ra[2 * i + 1]);
+                    int slot = ((kp >> 2) ^ (xc & 7)) & (KCH - 1);
+                    int boff = slot * 16 + (kp & 3) * 4;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        uint32_t a = w0[j >> 1], b = w1[j >> 1];
+                        uint32_t d = (j & 1) ? ((a >> 16) | (b & 0xffff0000u)) : ((a & 0xffffu) | (b << 16));
+                        *reinterpret_cast<uint32_t*>(sA + (xc * 8 + j) * ROWB + boff) = d;
+                    }
+                }
+            }
+        }
+        if (!p.b_kmajor) {
+#pragma unroll
+            for (int i = 0; i < B_CH; ++i) {
+                int c = tid + i * 256;
+                if (c < BN * KCH) {
+                    int row = c / KCH, kc = c % KCH;
+                    *reinterpret_cast<uint4*>(sB + row * ROWB + kc * 16) = rb[i];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < B_CHT; ++i) {
+                int c = tid + i * 256;
+                if (c < KP * (BN / 8)) {
+                    int xc = c % (BN / 8), kp = c / (BN / 8);
+                    uint4 v0 = rb[2 * i], v1 = rb[2 * i + 1];
+                    if (p.pro_operand == 2) {
+                        long long n = n0 + xc * 8, k = k0 + 2 * kp;
+                        if (n < p.N) {
+                            if (k < kend) v0 = apply_prologue(v0, p, k, (int)n);
+                            if (k + 1 < kend) v1 = apply_prologue(v1, p, k + 1, (int)n);
+                        }
+                    }
+                    const uint32_t* w0 = reinterpret_cast<const uint32_t*>(&v0);
+                    const uint32_t* w1 = reinterpret_cast<const uint32_t*>(&v1);
+                    int slot = ((kp >> 2) ^ (xc & 7)) & (KCH - 1);
+                    int boff = slot * 16 + (kp & 3) * 4;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        uint32_t a = w0[j >> 1], b = w1[j >> 1];
+                        uint32_t d = (j & 1) ? ((a >> 16) | (b & 0xffff0000u)) : ((a & 0xffffu) | (b << 16));
+                        *reinterpret_cast<uint32_t*>(sB + (xc * 8 + j) * ROWB + boff) = d;
+                    }
+                }
+            }
+        }
+    };
+
+    f32x4_t acc[FM][FN];
+
+    // operands are SWAPPED in the MFMA (D = Bfrag . Afrag^T) so that a lane ends up with 4 consecutive
+    // output COLUMNS of one output row: 8-byte LDS / 16-byte global stores in the epilogue instead of scalars.
+    auto compute = [&](int buf) {
+        const unsigned char* sA = smem + buf * STAGE_BYTES;
+        const unsigned char* sB = sA + BM * ROWB;
+#pragma unroll
+        for (int kk = 0; kk < BK / 32; ++kk) {
+            bf16x8_t af[FM], bfr[FN];
+            const int slot = kk * 4 + (lane >> 4);
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                int row = wm * WM + i * 16 + (lane & 15);
+                int s = p.a_kmajor ? ((slot ^ ((row >> 3) & 7)) & (KCH - 1)) : slot;
+                af[i] = *reinterpret_cast<const bf16x8_t*>(sA + row * ROWB + s * 16);
+            }
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                int row = wn * WN + j * 16 + (lane & 15);
+                int s = p.b_kmajor ? ((slot ^ ((row >> 3) & 7)) & (KCH - 1)) : slot;
+                bfr[j] = *reinterpret_cast<const bf16x8_t*>(sB + row * ROWB + s * 16);
+            }
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+        }
+    };
+    // acc[i][j][r]: row m = wm*WM + i*16 + (lane & 15), col n = wn*WN + j*16 + (lane >> 4)*4 + r
+
+    long long mt = blockIdx.y;
+    if (mt < mtiles && kbeg < kend) load_tiles(mt * BM, kbeg);
+    int buf = 0;
+    for (; mt < mtiles; mt += gridDim.y) {
         const long long m0 = mt * BM;
-        f32x4_t acc[FM][FN];
 #pragma unroll
         for (int i = 0; i < FM; ++i)
 #pragma unroll
             for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-        uint4 ra[A_REGS], rb[B_REGS];
-
-        auto load_tiles = [&](long long k0) {
-            // ---------------- A ----------------
-            if (!p.a_kmajor) {
-#pragma unroll
-                for (int i = 0; i < A_CH; ++i) {
-                    int c = tid + i * 256;
-                    int row = c / KCH, kc = c % KCH;
-                    long long m = m0 + row, k = k0 + kc * 8;
-                    uint4 v = zero4();
-                    if (c < BM * KCH && m < p.M && k < kend) {
-                        v = *reinterpret_cast<const uint4*>(A + m * p.lda + k);
-                        if (p.pro_operand == 1) v = apply_prologue(v, p, m, (int)k);
-                    }
-                    ra[i] = v;
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < A_CHT; ++i) {
-                    int c = tid + i * 256;
-                    int xc = c % (BM / 8), kp = c / (BM / 8);
-                    long long m = m0 + xc * 8, k = k0 + 2 * kp;
-                    uint4 v0 = zero4(), v1 = zero4();
-                    if (c < KP * (BM / 8) && m < p.M) {
-                        if (k < kend) v0 = *reinterpret_cast<const uint4*>(A + k * p.lda + m);
-                        if (k + 1 < kend) v1 = *reinterpret_cast<const uint4*>(A + (k + 1) * p.lda + m);
-                    }
-                    ra[2 * i] = v0; ra[2 * i + 1] = v1;
-                }
-            }
-            // ---------------- B ----------------
-            if (!p.b_kmajor) {
-#pragma unroll
-                for (int i = 0; i < B_CH; ++i) {
-                    int c = tid + i * 256;
-                    int row = c / KCH, kc = c % KCH;
-                    long long n = n0 + row, k = k0 + kc * 8;
-                    uint4 v = zero4();
-                    if (c < BN * KCH && n < p.N && k < kend)
-                        v = *reinterpret_cast<const uint4*>(B + n * p.ldb + k);
-                    rb[i] = v;
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < B_CHT; ++i) {
-                    int c = tid + i * 256;
-                    int xc = c % (BN / 8), kp = c / (BN / 8);
-                    long long n = n0 + xc * 8, k = k0 + 2 * kp;
-                    uint4 v0 = zero4(), v1 = zero4();
-                    if (c < KP * (BN / 8) && n < p.N) {
-                        if (k < kend) {
-                            v0 = *reinterpret_cast<const uint4*>(B + k * p.ldb + n);
-                            if (p.pro_operand == 2) v0 = apply_prologue(v0, p, k, (int)n);
-                        }
-                        if (k + 1 < kend) {
-                            v1 = *reinterpret_cast<const uint4*>(B + (k + 1) * p.ldb + n);
-                            if (p.pro_operand == 2) v1 = apply_prologue(v1, p, k + 1, (int)n);
-                        }
-                    }
-                    rb[2 * i] = v0; rb[2 * i + 1] = v1;
-                }
-            }
-        };
-
-        // k-major operands are transposed on the way into LDS: thread holds rows k, k+1 for 8
-        // consecutive x; it writes 8 dwords {x_j: (k, k+1)}.  The 16-byte slot index inside the row is
-        // XOR-swizzled with (x >> 3) & 7 so the 32-lane write groups (same k-pair, 16 x-chunks) do not
-        // pile onto one bank; the fragment reader applies the same XOR.
-        auto store_tiles = [&](int buf) {
-            unsigned char* sA = smem + buf * STAGE_BYTES;
-            unsigned char* sB = sA + BM * ROWB;
-            if (!p.a_kmajor) {
-#pragma unroll
-                for (int i = 0; i < A_CH; ++i) {
-                    int c = tid + i * 256;
-                    if (c < BM * KCH) {
-                        int row = c / KCH, kc = c % KCH;
-                        *reinterpret_cast<uint4*>(sA + row * ROWB + kc * 16) = ra[i];
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < A_CHT; ++i) {
-                    int c = tid + i * 256;
-                    if (c < KP * (BM / 8)) {
-                        int xc = c % (BM / 8), kp = c / (BM / 8);
-                        const uint32_t* w0 = reinterpret_cast<const uint32_t*>(&ra[2 * i]);
-                        const uint32_t* w1 = reinterpret_cast<const uint32_t*>(&ra[2 * i + 1]);
-                        int slot = ((kp >> 2) ^ (xc & 7)) & (KCH - 1);
-                        int boff = slot * 16 + (kp & 3) * 4;
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) {
-                            uint32_t a = w0[j >> 1], b = w1[j >> 1];
-                            uint32_t d = (j & 1) ? ((a >> 16) | (b & 0xffff0000u)) : ((a & 0xffffu) | (b << 16));
-                            *reinterpret_cast<uint32_t*>(sA + (xc * 8 + j) * ROWB + boff) = d;
-                        }
-                    }
-                }
-            }
-            if (!p.b_kmajor) {
-#pragma unroll
-                for (int i = 0; i < B_CH; ++i) {
-                    int c = tid + i * 256;
-                    if (c < BN * KCH) {
-                        int row = c / KCH, kc = c % KCH;
-                        *reinterpret_cast<uint4*>(sB + row * ROWB + kc * 16) = rb[i];
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < B_CHT; ++i) {
-                    int c = tid + i * 256;
-                    if (c < KP * (BN / 8)) {
-                        int xc = c % (BN / 8), kp = c / (BN / 8);
-                        const uint32_t* w0 = reinterpret_cast<const uint32_t*>(&rb[2 * i]);
-                        const uint32_t* w1 = reinterpret_cast<const uint32_t*>(&rb[2 * i + 1]);
-                        int slot = ((kp >> 2) ^ (xc & 7)) & (KCH - 1);
-                        int boff = slot * 16 + (kp & 3) * 4;
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) {
-                            uint32_t a = w0[j >> 1], b = w1[j >> 1];
-                            uint32_t d = (j & 1) ? ((a >> 16) | (b & 0xffff0000u)) : ((a & 0xffffu) | (b << 16));
-                            *reinterpret_cast<uint32_t*>(sB + (xc * 8 + j) * ROWB + boff) = d;
-                        }
-                    }
-                }
-            }
-        };
-
-        auto compute = [&](int buf) {
-            const unsigned char* sA = smem + buf * STAGE_BYTES;
-            const unsigned char* sB = sA + BM * ROWB;
-#pragma unroll
-            for (int kk = 0; kk < BK / 32; ++kk) {
-                bf16x8_t af[FM], bfr[FN];
-                const int slot = kk * 4 + (lane >> 4);
-#pragma unroll
-                for (int i = 0; i < FM; ++i) {
-                    int row = wm * WM + i * 16 + (lane & 15);
-                    int s = p.a_kmajor ? ((slot ^ ((row >> 3) & 7)) & (KCH - 1)) : slot;
-                    af[i] = *reinterpret_cast<const bf16x8_t*>(sA + row * ROWB + s * 16);
-                }
-#pragma unroll
-                for (int j = 0; j < FN; ++j) {
-                    int row = wn * WN + j * 16 + (lane & 15);
-                    int s = p.b_kmajor ? ((slot ^ ((row >> 3) & 7)) & (KCH - 1)) : slot;
-                    bfr[j] = *reinterpret_cast<const bf16x8_t*>(sB + row * ROWB + s * 16);
-                }
-#pragma unroll
-                for (int i = 0; i < FM; ++i)
-#pragma unroll
-                    for (int j = 0; j < FN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-            }
-        };
-
-        // ---------------- main loop ----------------
-        if (kbeg < kend) {
-            load_tiles(kbeg);
-            int buf = 0;
-            for (long long k0 = kbeg; k0 < kend; k0 += BK) {
-                store_tiles(buf);
-                __syncthreads();
-                if (k0 + BK < kend) load_tiles(k0 + BK);
-                compute(buf);
-                buf ^= 1;
-            }
+        for (long long k0 = kbeg; k0 < kend; k0 += BK) {
+            store_tiles(buf, m0, k0);
+            __syncthreads();
+            // prefetch: next K tile of this row block, or the first K tile of this workgroup's NEXT row block, so
+            // the loads are in flight during the MFMAs and the epilogue
+            if (k0 + BK < kend) load_tiles(m0, k0 + BK);
+            else if (mt + gridDim.y < mtiles) load_tiles((mt + gridDim.y) * BM, kbeg);
+            compute(buf);
+            buf ^= 1;
         }
         __syncthreads();   // all fragment reads done before smem is reused by the epilogue
 
         // ---------------- epilogue ----------------
         const float alpha = p.alpha;
-        if (p.c_f32 && p.splits > 1 && p.splitk_ws) {
-            // split-K partial tile -> workspace [split][M][N] (plain stores; reduced by splitk_reduce_kernel)
-            float* Wp = p.splitk_ws + (long long)split * p.M * p.N;
+        const int mrow = wm * WM + (lane & 15);
+        const int ncol = wn * WN + (lane >> 4) * 4;
+        if (p.c_f32) {
+            const bool to_ws = p.splits > 1 && p.splitk_ws;
+            float* C = to_ws ? p.splitk_ws + (long long)split * p.M * p.N : reinterpret_cast<float*>(p.C) + coff;
+            const long long ldc = to_ws ? p.N : p.ldc;
 #pragma unroll
-            for (int i = 0; i < FM; ++i)
-#pragma unroll
-                for (int j = 0; j < FN; ++j) {
-                    int n = n0 + wn * WN + j * 16 + (lane & 15);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        long long m = m0 + wm * WM + i * 16 + (lane >> 4) * 4 + r;
-                        if (m < p.M && n < p.N) Wp[m * p.N + n] = acc[i][j][r] * alpha;
-                    }
-                }
-        } else if (p.c_f32) {
-            float* C = reinterpret_cast<float*>(p.C) + coff;
-#pragma unroll
-            for (int i = 0; i < FM; ++i)
+            for (int i = 0; i < FM; ++i) {
+                long long m = m0 + mrow + i * 16;
+                if (m >= p.M) continue;
 #pragma unroll
                 for (int j = 0; j < FN; ++j) {
-                    int n = n0 + wn * WN + j * 16 + (lane & 15);
+                    int n = n0 + ncol + j * 16;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        long long m = m0 + wm * WM + i * 16 + (lane >> 4) * 4 + r;
-                        if (m < p.M && n < p.N) {
+                        if (n + r < p.N) {
                             float v = acc[i][j][r] * alpha;
-                            if (bias && split == 0) v += bias[n];
-                            if (p.c_atomic) atomicAdd(C + m * p.ldc + n, v);
-                            else C[m * p.ldc + n] = v;
+                            if (bias && split == 0) v += bias[n + r];
+                            if (p.c_atomic && !to_ws) atomicAdd(C + m * ldc + n + r, v);
+                            else C[m * ldc + n + r] = v;
                         }
                     }
                 }
+            }
         } else {
-            // registers -> LDS tile (bf16 of alpha*acc kept in fp32 until bias/act? no: bias/act are
-            // applied on the fp32 value here, then rounded once)
 #pragma unroll
             for (int i = 0; i < FM; ++i)
 #pragma unroll
                 for (int j = 0; j < FN; ++j) {
-                    int col = wn * WN + j * 16 + (lane & 15);
-                    int n = n0 + col;
-                    float bv = (bias && n < p.N) ? bias[n] : 0.f;
+                    int n = n0 + ncol + j * 16;
+                    float v[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        int row = wm * WM + i * 16 + (lane >> 4) * 4 + r;
-                        float v = acc[i][j][r] * alpha + bv;
-                        if (p.act == 1) v = gelu_f(v);
-                        *reinterpret_cast<bf16_t*>(smem + row * CROW + col * 2) = f2bf(v);
+                        float bv = (bias && n + r < p.N) ? bias[n + r] : 0.f;
+                        v[r] = acc[i][j][r] * alpha + bv;
+                        if (p.act == 1) v[r] = gelu_f(v[r]);
                     }
+                    uint2 pk = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+                    *reinterpret_cast<uint2*>(smem + (mrow + i * 16) * CROW + (ncol + j * 16) * 2) = pk;
                 }
             __syncthreads();
             bf16_t* C = reinterpret_cast<bf16_t*>(p.C) + coff;

@@ -1,0 +1,255 @@
+// Row-streaming bf16 MFMA GEMM for the HBM-bound pointwise convolutions of the early EfficientNet stages:
+//     C[M,N] = pro(X)[M,K] . W[N,K]^T  (+ R),   N <= 256, K <= 384,  M = pixels (millions)
+// [ref: efficientnet_custom.py:104 (_expand_conv), :122 (_project_conv) and their data gradients]
+//
+// These layers move ~10x more bytes than a roofline-balanced GEMM (arithmetic intensity 20-110 FLOP/B against a
+// ridge of ~310), so the kernel is built like a streaming kernel, not like a tiled GEMM:
+//   * the whole weight matrix is staged ONCE per workgroup into LDS, already in MFMA operand-fragment order
+//   * every wave owns whole output rows: it streams 32-row groups, loading the activation fragments straight
+//     from global memory into registers (16 B per lane, next group prefetched while the current one computes)
+//   * D = W_frag . X_frag^T (operands swapped) leaves each lane with 4 consecutive output columns of one row;
+//     the 16 x N result tile is transposed through a small per-wave LDS buffer and leaves as fully contiguous
+//     16-byte stores -- one workgroup writes complete cache lines, never a partial line shared with another XCD
+//   * optional fused BN+SiLU(+SE gate) prologue on the activations, optional per-column sum / sum-of-squares
+//     (training-mode BatchNorm statistics of the output) accumulated by persistent workgroups
+// No __syncthreads() in the main loop: waves run independently.
+#include "common.cuh"
+#include "../../include/mammoclip_hip.h"
+
+namespace {
+
+template <int FN, int KC>
+__global__ __launch_bounds__(256) void gemm_rows_kernel(const mc_gemm_rows_args p) {
+    constexpr int NP = FN * 16;                    // padded output width
+    constexpr int CROW = (NP + 8) * 2;             // staging row bytes
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* sW = smem;                                       // [KC][FN][64] x 16 B
+    float* sScale = reinterpret_cast<float*>(sW + KC * FN * 1024);  // [KC*32]
+    float* sShift = sScale + KC * 32;
+    unsigned char* sC = reinterpret_cast<unsigned char*>(sShift + KC * 32);   // [4 waves][16][CROW]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fn = (p.N + 15) >> 4;                // fragments actually used
+    const int kc_used = (p.K + 31) >> 5;
+    const bool has_pro = p.pro_scale != nullptr;
+
+    // ---- stage weights as MFMA A-operand fragments: frag (kc, f), lane (i = l&15, kg = l>>4) = W[f*16+i][kc*32+kg*8 ..+8]
+    for (int idx = tid; idx < KC * FN * 64; idx += 256) {
+        int l = idx & 63, f = (idx >> 6) % FN, kc = (idx >> 6) / FN;
+        int n = f * 16 + (l & 15), k = kc * 32 + (l >> 4) * 8;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (n < p.N && k < p.K) v = *reinterpret_cast<const uint4*>(p.W + (long long)n * p.ldw + k);
+        *reinterpret_cast<uint4*>(sW + (size_t)idx * 16) = v;
+    }
+    if (has_pro)
+        for (int k = tid; k < KC * 32; k += 256) {
+            sScale[k] = k < p.K ? p.pro_scale[k] : 0.f;
+            sShift[k] = k < p.K ? p.pro_shift[k] : 0.f;
+        }
+    __syncthreads();
+
+    unsigned char* myC = sC + wave * 16 * CROW;
+    const int mrow = lane & 15, kg = lane >> 4;
+    const long long ngroups = (p.M + 31) >> 5;
+    const long long gstride = (long long)gridDim.x * 4;
+    float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};   // lane owns columns lane*4 .. lane*4+3
+
+    uint4 xn[2][KC];                                // prefetched fragments of the NEXT group
+    auto load_group = [&](long long g) {
+#pragma unroll
+        for (int rg = 0; rg < 2; ++rg) {
+            long long m = g * 32 + rg * 16 + mrow;
+#pragma unroll
+            for (int kc = 0; kc < KC; ++kc) {
+                int k = kc * 32 + kg * 8;
+                uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                if (kc < kc_used && m < p.M && k < p.K) v = *reinterpret_cast<const uint4*>(p.X + m * p.ldx + k);
+                xn[rg][kc] = v;
+            }
+        }
+    };
+
+    long long g = (long long)blockIdx.x * 4 + wave;
+    if (g < ngroups) load_group(g);
+    for (; g < ngroups; g += gstride) {
+        uint4 xf[2][KC];
+#pragma unroll
+        for (int rg = 0; rg < 2; ++rg)
+#pragma unroll
+            for (int kc = 0; kc < KC; ++kc) xf[rg][kc] = xn[rg][kc];
+        if (g + gstride < ngroups) load_group(g + gstride);          // in flight during everything below
+
+        if (has_pro) {
+#pragma unroll
+            for (int rg = 0; rg < 2; ++rg) {
+                long long m = g * 32 + rg * 16 + mrow;
+                if (m < p.M) {
+                    const float* gate = p.pro_gate ? p.pro_gate + (m / p.pro_rows_per_img) * p.K : nullptr;
+#pragma unroll
+                    for (int kc = 0; kc < KC; ++kc) {
+                        int k = kc * 32 + kg * 8;
+                        if (kc < kc_used && k < p.K) {
+                            float f[8], s[8], t[8];
+                            unpack8(xf[rg][kc], f);
+                            load8f(sScale + k, s);
+                            load8f(sShift + k, t);
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) f[q] = silu_f(f[q] * s[q] + t[q]);
+                            if (gate) {
+                                float gv[8];
+                                load8f(gate + k, gv);
+#pragma unroll
+                                for (int q = 0; q < 8; ++q) f[q] *= gv[q];
+                            }
+                            xf[rg][kc] = pack8(f);
+                        }
+                    }
+                }
+            }
+        }
+
+        f32x4_t acc[2][FN];
+#pragma unroll
+        for (int rg = 0; rg < 2; ++rg)
+#pragma unroll
+            for (int f = 0; f < FN; ++f) acc[rg][f] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) {
+            if (kc < kc_used) {
+#pragma unroll
+                for (int f = 0; f < FN; ++f) {
+                    if (f < fn) {
+                        bf16x8_t wf = *reinterpret_cast<const bf16x8_t*>(sW + ((size_t)(kc * FN + f) * 64 + lane) * 16);
+                        acc[0][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                            wf, *reinterpret_cast<const bf16x8_t*>(&xf[0][kc]), acc[0][f], 0, 0, 0);
+                        acc[1][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                            wf, *reinterpret_cast<const bf16x8_t*>(&xf[1][kc]), acc[1][f], 0, 0, 0);
+                    }
+                }
+            }
+        }
+
+        // ---- epilogue per 16-row group: registers -> per-wave LDS tile -> contiguous global stores
+        const int cpr = p.N >> 3;                   // 16-byte chunks per output row
+        const int nchunks = 16 * cpr;
+#pragma unroll
+        for (int rg = 0; rg < 2; ++rg) {
+            const long long mbase = g * 32 + rg * 16;
+            if (mbase >= p.M) break;
+#pragma unroll
+            for (int f = 0; f < FN; ++f) {
+                if (f < fn) {
+                    uint2 pk = make_uint2(pack_bf2(acc[rg][f][0], acc[rg][f][1]), pack_bf2(acc[rg][f][2], acc[rg][f][3]));
+                    *reinterpret_cast<uint2*>(myC + mrow * CROW + (f * 16 + kg * 4) * 2) = pk;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (p.stat_partials && lane * 4 < p.N) {
+                const int rows = (p.M - mbase) < 16 ? (int)(p.M - mbase) : 16;
+                for (int r = 0; r < rows; ++r) {
+                    uint2 v = *reinterpret_cast<const uint2*>(myC + r * CROW + lane * 8);
+                    float a0 = bf_lo(v.x), a1 = bf_hi(v.x), a2 = bf_lo(v.y), a3 = bf_hi(v.y);
+                    ssum[0] += a0; ssum[1] += a1; ssum[2] += a2; ssum[3] += a3;
+                    ssq[0] += a0 * a0; ssq[1] += a1 * a1; ssq[2] += a2 * a2; ssq[3] += a3 * a3;
+                }
+            }
+            for (int c = lane; c < nchunks; c += 64) {
+                int row = c / cpr, c8 = c - row * cpr;
+                long long m = mbase + row;
+                if (m < p.M) {
+                    uint4 v = *reinterpret_cast<const uint4*>(myC + row * CROW + c8 * 16);
+                    if (p.R) {
+                        float a[8], b[8];
+                        unpack8(v, a);
+                        unpack8(*reinterpret_cast<const uint4*>(p.R + m * p.ldr + c8 * 8), b);
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) a[q] += b[q];
+                        v = pack8(a);
+                    }
+                    *reinterpret_cast<uint4*>(p.C + m * p.ldc + c8 * 8) = v;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+
+    if (p.stat_partials) {
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(sC);        // [4 waves][256 cols][2]
+        if (lane * 4 < NP) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                red[((wave * 256) + lane * 4 + q) * 2 + 0] = ssum[q];
+                red[((wave * 256) + lane * 4 + q) * 2 + 1] = ssq[q];
+            }
+        }
+        __syncthreads();
+        for (int c = tid; c < p.N; c += 256) {
+            float s = 0.f, s2 = 0.f;
+            for (int w = 0; w < 4; ++w) { s += red[(w * 256 + c) * 2]; s2 += red[(w * 256 + c) * 2 + 1]; }
+            float* dst = p.stat_partials + (long long)blockIdx.x * 2 * p.N;
+            dst[c] = s;
+            dst[p.N + c] = s2;
+        }
+    }
+}
+
+template <int FN, int KC> size_t lds_bytes() {
+    size_t staging = 4 * 16 * ((FN * 16 + 8) * 2);
+    size_t red = 4 * 256 * 2 * 4;
+    return (size_t)KC * FN * 1024 + 2 * KC * 32 * 4 + (staging > red ? staging : red);
+}
+
+template <int FN, int KC> int launch_rows(const mc_gemm_rows_args& p, int blocks, hipStream_t st) {
+    size_t lds = lds_bytes<FN, KC>();
+    static bool attr_set = false;
+    if (lds > 64 * 1024 && !attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_rows_kernel<FN, KC>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_rows_kernel<FN, KC>), dim3(blocks), dim3(256), lds, st, p);
+    MC_LAUNCH_CHECK();
+    return MC_OK;
+}
+
+template <int FN> int dispatch_kc(const mc_gemm_rows_args& p, int blocks, hipStream_t st) {
+    if (p.K <= 32) return launch_rows<FN, 1>(p, blocks, st);
+    if (p.K <= 64) return launch_rows<FN, 2>(p, blocks, st);
+    if (p.K <= 128) return launch_rows<FN, 4>(p, blocks, st);
+    if (p.K <= 256) return launch_rows<FN, 8>(p, blocks, st);
+    return launch_rows<FN, 12>(p, blocks, st);
+}
+
+}  // namespace
+
+extern "C" int mc_gemm_rows_supported(int n, int k) {
+    if (n <= 0 || k <= 0 || n > 256 || k > 384 || n % 8 || k % 8) return 0;
+    int fnp = n <= 32 ? 2 : (n <= 64 ? 4 : (n <= 128 ? 8 : 16));
+    int kcp = k <= 32 ? 1 : (k <= 64 ? 2 : (k <= 128 ? 4 : (k <= 256 ? 8 : 12)));
+    return fnp * kcp <= 64;                       // weight image <= 64 KiB of LDS
+}
+
+extern "C" int mc_gemm_rows_blocks(long long m) {
+    long long groups = (m + 31) / 32;
+    long long b = (groups + 3) / 4;
+    if (b > 512) b = 512;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+extern "C" int mc_gemm_rows_bf16(const mc_gemm_rows_args* a, void* stream) {
+    const mc_gemm_rows_args& p = *a;
+    MC_CHECK(p.X && p.W && p.C && p.M > 0 && p.N > 0 && p.K > 0, "gemm_rows: bad args");
+    MC_CHECK(mc_gemm_rows_supported(p.N, p.K), "gemm_rows: unsupported shape (see mc_gemm_rows_supported)");
+    MC_CHECK(p.ldx % 8 == 0 && p.ldw % 8 == 0 && p.ldc % 8 == 0, "gemm_rows: leading dims must be multiples of 8");
+    MC_CHECK(mc_aligned16(p.X) && mc_aligned16(p.W) && mc_aligned16(p.C), "gemm_rows: operands must be 16-byte aligned");
+    MC_CHECK(!p.R || (p.ldr % 8 == 0 && mc_aligned16(p.R)), "gemm_rows: bad residual");
+    MC_CHECK((p.pro_scale == nullptr) == (p.pro_shift == nullptr), "gemm_rows: prologue needs scale and shift");
+    MC_CHECK(!p.pro_gate || (p.pro_scale && p.pro_rows_per_img > 0), "gemm_rows: gate needs the BN prologue");
+    hipStream_t st = (hipStream_t)stream;
+    int blocks = mc_gemm_rows_blocks(p.M);
+    if (p.N <= 32) return dispatch_kc<2>(p, blocks, st);
+    if (p.N <= 64) return dispatch_kc<4>(p, blocks, st);
+    if (p.N <= 128) return dispatch_kc<8>(p, blocks, st);
+    return dispatch_kc<16>(p, blocks, st);
+}

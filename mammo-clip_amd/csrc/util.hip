@@ -44,6 +44,19 @@ __global__ void transpose_f32_k(const float* __restrict__ s, float* __restrict__
         if (r < rows && c < cols) d[(long long)c * rows + r] = tile[threadIdx.x][j];
     }
 }
+__global__ void cast_transpose_k(const float* __restrict__ s, bf16_t* __restrict__ d, int rows, int cols) {
+    __shared__ float tile[32][33];
+    int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+    for (int j = threadIdx.y; j < 32; j += blockDim.y) {
+        int r = by + j, c = bx + threadIdx.x;
+        if (r < rows && c < cols) tile[j][threadIdx.x] = s[(long long)r * cols + c];
+    }
+    __syncthreads();
+    for (int j = threadIdx.y; j < 32; j += blockDim.y) {
+        int c = bx + j, r = by + threadIdx.x;
+        if (r < rows && c < cols) d[(long long)c * rows + r] = f2bf(tile[threadIdx.x][j]);
+    }
+}
 __global__ void stem_weight_prep_k(const float* __restrict__ w, bf16_t* __restrict__ out, int c0) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < c0 * 32) {
@@ -173,6 +186,13 @@ extern "C" int mc_transpose_f32(const float* src, float* dst, int rows, int cols
     MC_CHECK(src && dst && rows > 0 && cols > 0, "transpose: bad args");
     dim3 grid(mc_div_up(cols, 32), mc_div_up(rows, 32));
     hipLaunchKernelGGL(transpose_f32_k, grid, dim3(32, 8), 0, (hipStream_t)stream, src, dst, rows, cols);
+    MC_LAUNCH_CHECK();
+    return MC_OK;
+}
+extern "C" int mc_cast_transpose_f32_bf16(const float* src, mc_bf16* dst, int rows, int cols, void* stream) {
+    MC_CHECK(src && dst && rows > 0 && cols > 0, "cast_transpose: bad args");
+    dim3 grid(mc_div_up(cols, 32), mc_div_up(rows, 32));
+    hipLaunchKernelGGL(cast_transpose_k, grid, dim3(32, 8), 0, (hipStream_t)stream, src, dst, rows, cols);
     MC_LAUNCH_CHECK();
     return MC_OK;
 }

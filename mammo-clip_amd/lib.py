@@ -35,6 +35,26 @@ class GemmArgs(C.Structure):
     ]
 
 
+class GemmRowsArgs(C.Structure):
+    _fields_ = [
+        ("X", P), ("M", LL), ("K", I), ("ldx", LL),
+        ("W", P), ("N", I), ("ldw", LL),
+        ("C", P), ("ldc", LL),
+        ("R", P), ("ldr", LL),
+        ("pro_scale", P), ("pro_shift", P), ("pro_gate", P), ("pro_rows_per_img", LL),
+        ("stat_partials", P),
+    ]
+
+
+class WgradRowsArgs(C.Structure):
+    _fields_ = [
+        ("dY", P), ("N", I), ("lddy", LL),
+        ("X", P), ("K", I), ("ldx", LL),
+        ("M", LL), ("dW", P), ("ws", P), ("accumulate", I),
+        ("pro_scale", P), ("pro_shift", P), ("pro_gate", P), ("pro_rows_per_img", LL),
+    ]
+
+
 class DwconvArgs(C.Structure):
     _fields_ = [
         ("x", P), ("dy", P), ("out", P), ("w_kkc", P),
@@ -59,6 +79,13 @@ _SIGS = {
     "mc_version": ([], I),
     "mc_gemm_bf16": ([C.POINTER(GemmArgs), P], I),
     "mc_gemm_stat_rows": ([C.POINTER(GemmArgs)], I),
+    "mc_gemm_rows_supported": ([I, I], I),
+    "mc_gemm_rows_blocks": ([LL], I),
+    "mc_gemm_rows_bf16": ([C.POINTER(GemmRowsArgs), P], I),
+    "mc_cast_transpose_f32_bf16": ([P, P, I, I, P], I),
+    "mc_wgrad_rows_supported": ([I, I], I),
+    "mc_wgrad_rows_blocks": ([LL], I),
+    "mc_wgrad_rows_bf16": ([C.POINTER(WgradRowsArgs), P], I),
     "mc_cast_f32_bf16": ([P, P, LL, P], I),
     "mc_cast_bf16_f32": ([P, P, LL, P], I),
     "mc_transpose_f32": ([P, P, I, I, P], I),
@@ -79,7 +106,7 @@ _SIGS = {
     "mc_bn_bwd_finalize": ([P, I, I, D, P, P, P, P, P, P, P], I),
     "mc_colsum_rows": ([LL, I], I),
     "mc_colsum_bf16": ([P, LL, I, LL, P, P, I, P], I),
-    "mc_se_fwd": ([P, P, P, P, P, I, I, I, P, P], I),
+    "mc_se_fwd": ([P, P, P, P, P, I, I, I, P, P, P], I),
     "mc_se_bwd": ([P, P, P, P, P, P, P, I, I, I, P, P, P, P, P, P, P], I),
     "mc_dropout_f32": ([P, P, LL, F, ULL, U, P], I),
     "mc_bert_embed_fwd": ([P, P, P, P, P, P, P, F, I, I, I, F, ULL, U, P, P, P, P], I),

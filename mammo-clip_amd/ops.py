@@ -69,11 +69,46 @@ def gemm_stat_rows(M):
     return L.load().mc_gemm_stat_rows(C.byref(a))
 
 
+ROWS_MIN_M = 8192       # below this the tiled kernel is as good
+
+
+def gemm_rows(x, w, y, residual=None, pro=None, stat_partials=None, kind=None):
+    a = L.GemmRowsArgs()
+    M, K = x.shape
+    N = w.shape[0]
+    a.X, a.M, a.K, a.ldx = _p(x), M, K, x.stride(0)
+    a.W, a.N, a.ldw = _p(w), N, w.stride(0)
+    a.C, a.ldc = _p(y), y.stride(0)
+    if residual is not None:
+        a.R, a.ldr = _p(residual), residual.stride(0)
+    if pro is not None:
+        a.pro_scale, a.pro_shift, a.pro_gate, a.pro_rows_per_img = _p(pro[0]), _p(pro[1]), _p(pro[2]), pro[3]
+    a.stat_partials = _p(stat_partials)
+    _note(2 * M * (K + N) + 2 * N * K + (2 * M * N if residual is not None else 0), 2 * M * N * K)
+    L.call("mc_gemm_rows_bf16", C.byref(a), _st(), kind=kind)
+
+
+def _rows_ok(M, N, K, bias, act):
+    return bias is None and act == 0 and M >= ROWS_MIN_M and L.load().mc_gemm_rows_supported(N, K)
+
+
+def cast_transpose_bf16(src2d):
+    """fp32 [rows, cols] -> bf16 [cols, rows]"""
+    rows, cols = src2d.shape
+    dst = empty((cols, rows), BF16, src2d)
+    L.call("mc_cast_transpose_f32_bf16", _p(src2d.contiguous()), _p(dst), rows, cols, _st())
+    return dst
+
+
 def linear_fwd(x, w, bias=None, act=0, residual=None, stats=False, pro=None, out=None):
     """y[M,N] = x[M,K] . w[N,K]^T (+bias)(act)(+residual).  stats -> also returns [rows,2,N] partials."""
     M, K = x.shape
     N = w.shape[0]
     y = out if out is not None else empty((M, N), BF16, x)
+    if _rows_ok(M, N, K, bias, act):
+        part = empty((L.load().mc_gemm_rows_blocks(M), 2, N), torch.float32, x) if stats else None
+        gemm_rows(x, w, y, residual=residual, pro=pro, stat_partials=part, kind="fwd_rows")
+        return (y, part) if stats else y
     part = None
     if stats:
         part = empty((gemm_stat_rows(M), 2, N), torch.float32, x)
@@ -85,11 +120,14 @@ def linear_fwd(x, w, bias=None, act=0, residual=None, stats=False, pro=None, out
     return (y, part) if stats else y
 
 
-def linear_dgrad(dy, w, residual=None):
-    """dx[M,K] = dy[M,N] . w[N,K]  (+ residual)"""
+def linear_dgrad(dy, w, residual=None, w_t=None):
+    """dx[M,K] = dy[M,N] . w[N,K]  (+ residual).  w_t = w^T [K,N] (bf16) enables the row-streaming kernel."""
     M, N = dy.shape
     K = w.shape[1]
     dx = empty((M, K), BF16, dy)
+    if w_t is not None and _rows_ok(M, K, N, None, 0):
+        gemm_rows(dy, w_t, dx, residual=residual, kind="dgrad_rows")
+        return dx
     gemm(dy, w, dx, M, K, N, dy.stride(0), w.stride(0), dx.stride(0), b_kmajor=1, R=residual,
          ldr=(residual.stride(0) if residual is not None else 0), kind="dgrad")
     return dx
@@ -107,6 +145,17 @@ def linear_wgrad(dy, x, pro=None, out=None):
     M, N = dy.shape
     K = x.shape[1]
     dw = out if out is not None else empty((N, K), torch.float32, dy)
+    if M >= ROWS_MIN_M and L.load().mc_wgrad_rows_supported(N, K):
+        a = L.WgradRowsArgs()
+        a.dY, a.N, a.lddy = _p(dy), N, dy.stride(0)
+        a.X, a.K, a.ldx, a.M = _p(x), K, x.stride(0), M
+        ws = empty((L.load().mc_wgrad_rows_blocks(M), N, K), torch.float32, dy)
+        a.dW, a.ws, a.accumulate = _p(dw), _p(ws), (1 if out is not None else 0)
+        if pro is not None:
+            a.pro_scale, a.pro_shift, a.pro_gate, a.pro_rows_per_img = _p(pro[0]), _p(pro[1]), _p(pro[2]), pro[3]
+        _note(2 * M * (N + K) + 4 * N * K, 2 * M * N * K)
+        L.call("mc_wgrad_rows_bf16", C.byref(a), _st(), kind="wgrad_rows")
+        return dw
     p = None
     if pro is not None:
         p = (2, pro[0], pro[1], pro[2], pro[3], K)
@@ -299,7 +348,8 @@ def se_fwd(pooled, w1, b1, w2, b2):
     n, c = pooled.shape
     cs = w1.shape[0]
     gate = empty((n, c), torch.float32, pooled)
-    L.call("mc_se_fwd", _p(pooled), _p(w1), _p(b1), _p(w2), _p(b2), n, c, cs, _p(gate), _st())
+    ws = empty((n, cs), torch.float32, pooled)
+    L.call("mc_se_fwd", _p(pooled), _p(w1), _p(b1), _p(w2), _p(b2), n, c, cs, _p(gate), _p(ws), _st())
     return gate
 
 

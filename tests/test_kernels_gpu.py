@@ -141,6 +141,60 @@ def test_gemm_batched_attention_shapes():
     assert float(dqkv[:, :2 * H].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("M,N,K", [(10000, 144, 24), (9001, 24, 48), (20000, 240, 40), (8200, 40, 240), (8192, 64, 384),
+                                   (30000, 16, 16), (12345, 64, 384), (9000, 96, 16)])
+def test_gemm_rows_streaming(M, N, K):
+    """row-streaming kernel (full-row ownership, LDS-resident weights): fwd with stats + residual, prologue, dgrad"""
+    x, w = rnd(M, K, seed=82), rnd(N, K, seed=83, scale=K ** -0.5)
+    res = rnd(M, N, seed=84)
+    assert ops._rows_ok(M, N, K, None, 0)
+    y, part = ops.linear_fwd(x, w, stats=True)
+    ref = x.float() @ w.float().T
+    check(y, ref, 1e-2, "rows fwd")
+    st = part.double().sum(0)
+    yf = y.float().double()
+    check(st[0].float(), yf.sum(0).float(), 1e-4, "rows colsum")
+    check(st[1].float(), (yf * yf).sum(0).float(), 1e-4, "rows colsumsq")
+    y2 = ops.linear_fwd(x, w, residual=res)
+    check(y2, ref.to(BF).float() + res.float(), 1e-2, "rows residual")
+    hw = 1000
+    n_img = (M + hw - 1) // hw
+    scale, shift = rnd(K, seed=85, dtype=torch.float32) * 0.5 + 1.0, rnd(K, seed=86, dtype=torch.float32) * 0.3
+    gate = torch.sigmoid(rnd(n_img, K, seed=87, dtype=torch.float32))
+    img = torch.arange(M, device=DEV) // hw
+    a1 = (F.silu(x.float() * scale + shift) * gate[img]).to(BF).float()
+    y3 = ops.linear_fwd(x, w, pro=(scale, shift, gate, hw))
+    check(y3, a1 @ w.float().T, 1e-2, "rows prologue")
+    # data gradient through the transposed weight: dx[M,K] = dy[M,N] . w[N,K]
+    dy = rnd(M, N, seed=88)
+    wf32 = w.float()
+    if ops._rows_ok(M, K, N, None, 0):
+        dx = ops.linear_dgrad(dy, w, w_t=ops.cast_transpose_bf16(wf32))
+        check(dx, dy.float() @ wf32, 1e-2, "rows dgrad")
+
+
+@pytest.mark.parametrize("M,N,K", [(10000, 144, 24), (9001, 24, 48), (20000, 240, 40), (8200, 40, 240), (8192, 64, 384),
+                                   (30000, 24, 24), (12345, 384, 64), (9000, 16, 96), (70001, 240, 64)])
+def test_wgrad_rows_streaming(M, N, K):
+    """streaming weight gradient (LDS transpose-reads): plain, with BN+SiLU+gate prologue on X, accumulate"""
+    import mammo_clip_amd.lib as L
+    assert L.load().mc_wgrad_rows_supported(N, K)
+    dy, x = rnd(M, N, seed=89), rnd(M, K, seed=90)
+    ref = dy.float().T @ x.float()
+    dw = ops.linear_wgrad(dy, x)
+    check(dw, ref, 2e-3, "wgrad rows")
+    dw2 = ops.linear_wgrad(dy, x, out=dw.clone())
+    check(dw2, 2 * ref, 2e-3, "wgrad rows accumulate")
+    hw = 777
+    n_img = (M + hw - 1) // hw
+    scale, shift = rnd(K, seed=91, dtype=torch.float32) * 0.5 + 1.0, rnd(K, seed=92, dtype=torch.float32) * 0.3
+    gate = torch.sigmoid(rnd(n_img, K, seed=93, dtype=torch.float32))
+    img = torch.arange(M, device=DEV) // hw
+    a1 = (F.silu(x.float() * scale + shift) * gate[img]).to(BF).float()
+    dw3 = ops.linear_wgrad(dy, x, pro=(scale, shift, gate, hw))
+    check(dw3, dy.float().T @ a1, 2e-3, "wgrad rows prologue")
+
+
 # ------------------------------------------------------------------------------------------------ stem
 @pytest.mark.parametrize("nhwc_view", [False, True])
 def test_stem_im2col_gemm(nhwc_view):
