@@ -36,16 +36,15 @@ __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint3
 __device__ __forceinline__ float bf_lo(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
 
-// round-to-nearest-even, NaN preserved (same rounding as torch's float -> bfloat16)
-__device__ __forceinline__ bf16_t f2bf(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)0x7fc0;
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
-}
+// fp32 -> bf16, round-to-nearest-even (same rounding as torch's float -> bfloat16): gfx950 has a packed hardware
+// convert (v_cvt_pk_bf16_f32) -- one instruction per two elements instead of ~6 integer ops per element.
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
 __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
-    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+    f32x2_t f = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, bf16x2_t));
 }
+__device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack_bf2(f, 0.f) & 0xffffu); }
 __device__ __forceinline__ void unpack8(const uint4& v, float* f) {
     f[0] = bf_lo(v.x); f[1] = bf_hi(v.x); f[2] = bf_lo(v.y); f[3] = bf_hi(v.y);
     f[4] = bf_lo(v.z); f[5] = bf_hi(v.z); f[6] = bf_lo(v.w); f[7] = bf_hi(v.w);
@@ -62,7 +61,8 @@ __device__ __forceinline__ void load8f(const float* p, float* f) {   // p 16-byt
     f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
 }
 
-__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// v_exp_f32 + v_rcp_f32 (1 ulp): no IEEE division sequence on the streaming paths
+__device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float silu_f(float x) { return x * sigmoid_f(x); }
 // d silu(z)/dz = s(1 + z(1-s))  (efficient_net_custom_utils.py:71-75)
 __device__ __forceinline__ float silu_grad_f(float z) {

@@ -18,8 +18,9 @@ constexpr int TOW = 16;
 
 template <int K, int S> struct DwCfg {
     static constexpr int TOH = (S == 1) ? 8 : 4;
-    static constexpr int R = (S == 1) ? 4 : 2;            // output pixels per thread (along W)
+    static constexpr int R = (S == 1 && K == 3) ? 4 : 2;  // output pixels per strip (along W)
     static constexpr int NSTRIP = TOW / R;
+    static constexpr int PASSES = TOH * NSTRIP * 8 / 256; // strips per thread
     static constexpr int IH_T = (TOH - 1) * S + K;
     static constexpr int IW_T = (TOW - 1) * S + K;
     static constexpr int NIN = (R - 1) * S + K;           // input vectors per filter row per strip
@@ -27,36 +28,47 @@ template <int K, int S> struct DwCfg {
     static constexpr int W_BYTES = K * K * TC * 4;
 };
 
-// stage the input halo tile (with optional BN+SiLU prologue) for spatial tile (img, ty, tx), channels c0..c0+63
+// halo tile staging, split so the global loads of the NEXT tile can be in flight while the current tile computes:
+// load_halo issues all 16-byte loads of the (IH_T x IW_T x 64-channel) tile back to back into registers,
+// store_halo applies the optional BN+SiLU prologue (in-range pixels only: zero padding stays zero) and writes LDS.
+template <int K, int S> struct Halo {
+    static constexpr int NV = (DwCfg<K, S>::IH_T * DwCfg<K, S>::IW_T + 31) / 32;
+    uint4 vals[NV];
+    unsigned inb;
+};
+
 template <int K, int S>
-__device__ __forceinline__ void stage_input(const mc_dwconv_args& p, unsigned char* tile, long long img, int oy0,
-                                            int ox0, int c0, const float* ps, const float* pt, bool has_pro) {
+__device__ __forceinline__ void load_halo(const mc_dwconv_args& p, Halo<K, S>& hl, long long img, int oy0, int ox0, int c0) {
     using C = DwCfg<K, S>;
     const int tid = threadIdx.x;
-    const int cv = tid & 7;
-    const int c = c0 + cv * 8;
+    const int c = c0 + (tid & 7) * 8;
     const int iy0 = oy0 * S - p.pad_t, ix0 = ox0 * S - p.pad_l;
-    // issue ALL global loads of the halo tile first (independent, in flight together), then activate + store
-    constexpr int NV = (C::IH_T * C::IW_T + 31) / 32;
-    uint4 vals[NV];
-    unsigned inb = 0;
+    hl.inb = 0;
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
+    for (int i = 0; i < Halo<K, S>::NV; ++i) {
         int v = (tid >> 3) + i * 32;
         int ty = v / C::IW_T, tx = v % C::IW_T;
         int iy = iy0 + ty, ix = ix0 + tx;
-        vals[i] = make_uint4(0u, 0u, 0u, 0u);
+        hl.vals[i] = make_uint4(0u, 0u, 0u, 0u);
         if (v < C::IH_T * C::IW_T && c < p.c && iy >= 0 && iy < p.h && ix >= 0 && ix < p.w) {
-            vals[i] = *reinterpret_cast<const uint4*>(p.x + ((img * p.h + iy) * (long long)p.w + ix) * p.c + c);
-            inb |= 1u << i;
+            hl.vals[i] = *reinterpret_cast<const uint4*>(p.x + ((img * p.h + iy) * (long long)p.w + ix) * p.c + c);
+            hl.inb |= 1u << i;
         }
     }
+}
+
+template <int K, int S>
+__device__ __forceinline__ void store_halo(unsigned char* tile, const Halo<K, S>& hl, const float* ps, const float* pt,
+                                           bool has_pro) {
+    using C = DwCfg<K, S>;
+    const int tid = threadIdx.x;
+    const int cv = tid & 7;
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
+    for (int i = 0; i < Halo<K, S>::NV; ++i) {
         int v = (tid >> 3) + i * 32;
         if (v < C::IH_T * C::IW_T) {
-            uint4 val = vals[i];
-            if (has_pro && ((inb >> i) & 1u)) {
+            uint4 val = hl.vals[i];
+            if (has_pro && ((hl.inb >> i) & 1u)) {
                 float f[8];
                 unpack8(val, f);
 #pragma unroll
@@ -69,6 +81,14 @@ __device__ __forceinline__ void stage_input(const mc_dwconv_args& p, unsigned ch
 }
 
 template <int K, int S>
+__device__ __forceinline__ void stage_input(const mc_dwconv_args& p, unsigned char* tile, long long img, int oy0,
+                                            int ox0, int c0, const float* ps, const float* pt, bool has_pro) {
+    Halo<K, S> hl;
+    load_halo<K, S>(p, hl, img, oy0, ox0, c0);
+    store_halo<K, S>(tile, hl, ps, pt, has_pro);
+}
+
+template <int K, int S>
 __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const mc_dwconv_args p, int tiles_h, int tiles_w) {
     using C = DwCfg<K, S>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -76,8 +96,6 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const mc_dwconv_args p,
     float* wl = reinterpret_cast<float*>(smem + C::TILE_BYTES);       // [K*K][TC]
     const int tid = threadIdx.x;
     const int cv = tid & 7;
-    const int strip = (tid >> 3) % C::NSTRIP;
-    const int orow = tid / (8 * C::NSTRIP);
     const int c0 = blockIdx.x * TC;
     const int c = c0 + cv * 8;
     const bool cvalid = c < p.c;
@@ -97,51 +115,69 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const mc_dwconv_args p,
     for (int q = 0; q < 8; ++q) { ssum[q] = 0.f; ssq[q] = 0.f; }
 
     const long long ntiles = (long long)p.n * tiles_h * tiles_w;
-    for (long long t = blockIdx.y; t < ntiles; t += gridDim.y) {
-        const int tx = (int)(t % tiles_w);
-        const int ty = (int)((t / tiles_w) % tiles_h);
-        const long long img = t / ((long long)tiles_w * tiles_h);
-        const int oy0 = ty * C::TOH, ox0 = tx * TOW;
+    auto tile_pos = [&](long long t, long long& img, int& oy0, int& ox0) {
+        ox0 = (int)(t % tiles_w) * TOW;
+        oy0 = (int)((t / tiles_w) % tiles_h) * C::TOH;
+        img = t / ((long long)tiles_w * tiles_h);
+    };
+    Halo<K, S> hl;
+    long long t = blockIdx.y;
+    {
+        long long img; int oy0, ox0;
+        if (t < ntiles) { tile_pos(t, img, oy0, ox0); load_halo<K, S>(p, hl, img, oy0, ox0, c0); }
+    }
+    for (; t < ntiles; t += gridDim.y) {
+        long long img; int oy0, ox0;
+        tile_pos(t, img, oy0, ox0);
         __syncthreads();                       // previous tile fully consumed (also orders the weight staging)
-        stage_input<K, S>(p, tile, img, oy0, ox0, c0, ps, pt, has_pro);
+        store_halo<K, S>(tile, hl, ps, pt, has_pro);
         __syncthreads();
-
-        float acc[C::R][8];
-#pragma unroll
-        for (int r = 0; r < C::R; ++r)
-#pragma unroll
-            for (int q = 0; q < 8; ++q) acc[r][q] = 0.f;
-
-#pragma unroll
-        for (int kh = 0; kh < K; ++kh) {
-            float in[C::NIN][8];
-            const unsigned char* rowp = tile + ((orow * S + kh) * C::IW_T + strip * C::R * S) * PIXB + cv * 16;
-#pragma unroll
-            for (int i = 0; i < C::NIN; ++i) unpack8(*reinterpret_cast<const uint4*>(rowp + i * PIXB), in[i]);
-#pragma unroll
-            for (int kw = 0; kw < K; ++kw) {
-                float wv[8];
-                load8f(wl + (kh * K + kw) * TC + cv * 8, wv);
-#pragma unroll
-                for (int r = 0; r < C::R; ++r)
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) acc[r][q] = fmaf(in[r * S + kw][q], wv[q], acc[r][q]);
-            }
+        if (t + gridDim.y < ntiles) {          // prefetch the next tile while this one computes
+            long long img2; int oy2, ox2;
+            tile_pos(t + gridDim.y, img2, oy2, ox2);
+            load_halo<K, S>(p, hl, img2, oy2, ox2, c0);
         }
-        const int oy = oy0 + orow;
-        if (cvalid && oy < p.oh) {
-            bf16_t* yrow = reinterpret_cast<bf16_t*>(p.out) + ((img * p.oh + oy) * (long long)p.ow) * p.c + c;
+#pragma unroll 1
+        for (int pass = 0; pass < C::PASSES; ++pass) {
+            const int item = tid + pass * 256;
+            const int strip = (item >> 3) % C::NSTRIP;
+            const int orow = item / (8 * C::NSTRIP);
+            float acc[C::R][8];
 #pragma unroll
-            for (int r = 0; r < C::R; ++r) {
-                int ox = ox0 + strip * C::R + r;
-                if (ox < p.ow) {
-                    uint4 o = pack8(acc[r]);
-                    *reinterpret_cast<uint4*>(yrow + (long long)ox * p.c) = o;
-                    if (p.stat_partials) {
-                        float f[8];
-                        unpack8(o, f);          // statistics of the stored (bf16-rounded) tensor
+            for (int r = 0; r < C::R; ++r)
 #pragma unroll
-                        for (int q = 0; q < 8; ++q) { ssum[q] += f[q]; ssq[q] += f[q] * f[q]; }
+                for (int q = 0; q < 8; ++q) acc[r][q] = 0.f;
+#pragma unroll(K == 5 ? 1 : 3)
+            for (int kh = 0; kh < K; ++kh) {          // k = 5: keep one filter row live at a time (VGPR budget)
+                float in[C::NIN][8];
+                const unsigned char* rowp = tile + ((orow * S + kh) * C::IW_T + strip * C::R * S) * PIXB + cv * 16;
+#pragma unroll
+                for (int i = 0; i < C::NIN; ++i) unpack8(*reinterpret_cast<const uint4*>(rowp + i * PIXB), in[i]);
+#pragma unroll
+                for (int kw = 0; kw < K; ++kw) {
+                    float wv[8];
+                    load8f(wl + (kh * K + kw) * TC + cv * 8, wv);
+#pragma unroll
+                    for (int r = 0; r < C::R; ++r)
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) acc[r][q] = fmaf(in[r * S + kw][q], wv[q], acc[r][q]);
+                }
+            }
+            const int oy = oy0 + orow;
+            if (cvalid && oy < p.oh) {
+                bf16_t* yrow = reinterpret_cast<bf16_t*>(p.out) + ((img * p.oh + oy) * (long long)p.ow) * p.c + c;
+#pragma unroll
+                for (int r = 0; r < C::R; ++r) {
+                    int ox = ox0 + strip * C::R + r;
+                    if (ox < p.ow) {
+                        uint4 o = pack8(acc[r]);
+                        *reinterpret_cast<uint4*>(yrow + (long long)ox * p.c) = o;
+                        if (p.stat_partials) {
+                            float f[8];
+                            unpack8(o, f);          // statistics of the stored (bf16-rounded) tensor
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) { ssum[q] += f[q]; ssq[q] += f[q] * f[q]; }
+                        }
                     }
                 }
             }
@@ -236,14 +272,28 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const mc_dwconv_
         for (int q = 0; q < 4; ++q) acc[t][q] = 0.f;
 
     const long long ntiles = (long long)p.n * tiles_h * tiles_w;
-    for (long long t = blockIdx.y; t < ntiles; t += gridDim.y) {
-        const int tx = (int)(t % tiles_w);
-        const int ty = (int)((t / tiles_w) % tiles_h);
-        const long long img = t / ((long long)tiles_w * tiles_h);
-        const int oy0 = ty * C::TOH, ox0 = tx * TOW;
+    auto tile_pos = [&](long long t, long long& img, int& oy0, int& ox0) {
+        ox0 = (int)(t % tiles_w) * TOW;
+        oy0 = (int)((t / tiles_w) % tiles_h) * C::TOH;
+        img = t / ((long long)tiles_w * tiles_h);
+    };
+    Halo<K, S> hl;
+    long long t = blockIdx.y;
+    {
+        long long img; int oy0, ox0;
+        if (t < ntiles) { tile_pos(t, img, oy0, ox0); load_halo<K, S>(p, hl, img, oy0, ox0, c0); }
+    }
+    for (; t < ntiles; t += gridDim.y) {
+        long long img; int oy0, ox0;
+        tile_pos(t, img, oy0, ox0);
         __syncthreads();
-        stage_input<K, S>(p, tile, img, oy0, ox0, c0, ps, pt, has_pro);
+        store_halo<K, S>(tile, hl, ps, pt, has_pro);
         __syncthreads();
+        if (t + gridDim.y < ntiles) {          // prefetch the next halo tile while this one is consumed
+            long long img2; int oy2, ox2;
+            tile_pos(t + gridDim.y, img2, oy2, ox2);
+            load_halo<K, S>(p, hl, img2, oy2, ox2, c0);
+        }
         const int oy = oy0 + orow;
         float g[RW][4];
 #pragma unroll
@@ -255,7 +305,7 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const mc_dwconv_
             g[r][0] = bf_lo(gv.x); g[r][1] = bf_hi(gv.x); g[r][2] = bf_lo(gv.y); g[r][3] = bf_hi(gv.y);
         }
 #pragma unroll
-        for (int kh = 0; kh < K; ++kh) {
+        for (int kh = 0; kh < K; ++kh) {              // must stay unrolled: acc[] is indexed by kh (registers, not scratch)
             float in[NINW][4];
             const unsigned char* rowp = tile + ((orow * S + kh) * C::IW_T + strip * RW * S) * PIXB + cq * 8;
 #pragma unroll

@@ -17,8 +17,14 @@ namespace {
 typedef __attribute__((ext_vector_type(4))) short s4_t;
 typedef __attribute__((address_space(3))) s4_t lds_s4_t;
 
-constexpr int RB = 64;         // pixel rows per step
-constexpr int MAXCH = 14;      // 16-byte chunks per thread per step: 64 * (N + K) / 8 / 256 <= 14
+constexpr int MAXCH = 14;      // 16-byte chunks per thread per step: RB * (N + K) / 8 / 256 <= 14
+// RB = pixel rows per step (64 .. 512, runtime): narrow layers take more rows per step so that every step moves
+// ~50 KB -- enough bytes in flight per workgroup to cover HBM latency with a one-step prefetch.
+static int pick_rb(int n, int k) {
+    int rb = 512;
+    while (rb > 64 && (long long)rb * (n + k) > 28672) rb >>= 1;
+    return rb;
+}
 
 __device__ __forceinline__ bf16x8_t tr_frag(const unsigned char* tile, int rs, int row0, int col0, int lane) {
     // 16x16x32 MFMA operand fragment for reduction rows row0 .. row0+31 and 16 columns col0 .. col0+15:
@@ -33,7 +39,7 @@ __device__ __forceinline__ bf16x8_t tr_frag(const unsigned char* tile, int rs, i
 }
 
 template <int AFM, int BFM>
-__global__ __launch_bounds__(256) void wgrad_rows_kernel(const mc_wgrad_rows_args p, int WB, int af, int bfn) {
+__global__ __launch_bounds__(256) void wgrad_rows_kernel(const mc_wgrad_rows_args p, int WB, int af, int bfn, int RB) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int rsy = p.N * 2, rsx = p.K * 2;
     unsigned char* sY = smem;
@@ -109,7 +115,6 @@ __global__ __launch_bounds__(256) void wgrad_rows_kernel(const mc_wgrad_rows_arg
         store_step(s);
         __syncthreads();
         if (s + gridDim.x < nsteps) load_step(s + gridDim.x);
-#pragma unroll
         for (int ks = 0; ks < RB / 32; ++ks) {
             bf16x8_t a[AFM], b[BFM];
 #pragma unroll
@@ -181,7 +186,7 @@ extern "C" int mc_wgrad_rows_supported(int n, int k) {
     return (af <= 4 && bfn <= 4) || (af <= 6 && bfn <= 4) || (af <= 4 && bfn <= 6);
 }
 extern "C" int mc_wgrad_rows_blocks(long long m) {
-    long long steps = (m + RB - 1) / RB;
+    long long steps = (m + 63) / 64;
     long long b = steps < 512 ? steps : 512;
     return (int)(b < 1 ? 1 : b);
 }
@@ -196,11 +201,13 @@ extern "C" int mc_wgrad_rows_bf16(const mc_wgrad_rows_args* a, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     int WA, WB, af, bfn;
     wave_split(p.N, p.K, &WA, &WB, &af, &bfn);
-    const int blocks = mc_wgrad_rows_blocks(p.M);
+    const int RB = pick_rb(p.N, p.K);
+    long long steps = (p.M + RB - 1) / RB;
+    const int blocks = (int)(steps < 512 ? steps : 512);      // <= mc_wgrad_rows_blocks(M): ws is large enough
     const size_t lds = (size_t)RB * (p.N + p.K) * 2 + 64;     // + slack: the last fragment may over-read 16 B
-    if (af <= 4 && bfn <= 4) hipLaunchKernelGGL((wgrad_rows_kernel<4, 4>), dim3(blocks), dim3(256), lds, st, p, WB, af, bfn);
-    else if (af <= 6 && bfn <= 4) hipLaunchKernelGGL((wgrad_rows_kernel<6, 4>), dim3(blocks), dim3(256), lds, st, p, WB, af, bfn);
-    else hipLaunchKernelGGL((wgrad_rows_kernel<4, 6>), dim3(blocks), dim3(256), lds, st, p, WB, af, bfn);
+    if (af <= 4 && bfn <= 4) hipLaunchKernelGGL((wgrad_rows_kernel<4, 4>), dim3(blocks), dim3(256), lds, st, p, WB, af, bfn, RB);
+    else if (af <= 6 && bfn <= 4) hipLaunchKernelGGL((wgrad_rows_kernel<6, 4>), dim3(blocks), dim3(256), lds, st, p, WB, af, bfn, RB);
+    else hipLaunchKernelGGL((wgrad_rows_kernel<4, 6>), dim3(blocks), dim3(256), lds, st, p, WB, af, bfn, RB);
     MC_LAUNCH_CHECK();
     long long nk = (long long)p.N * p.K;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(mc_div_up(nk, 16)), dim3(256), 0, st, p.ws, blocks, nk, p.dW, p.accumulate);
