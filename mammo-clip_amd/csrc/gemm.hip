@@ -1,27 +1,25 @@
-// bf16 MFMA GEMM family for gfx950: C[M,N] (+)= alpha * op(A)[M,K] . op(B)[K,N]  (+bias, act, residual)
+// Tiled bf16 MFMA GEMM family for gfx950: C[M,N] (+)= alpha * op(A)[M,K] . op(B)[K,N]  (+bias, +residual)
 //
-// One kernel template covers every matmul-shaped op on the hot path:
-//   * pointwise (1x1) convolutions in NHWC = GEMM over pixels  (efficientnet_custom.py:104,122,283)
-//   * their dgrad (B k-major = weight used un-transposed) and wgrad (A and B k-major, reduction over
-//     pixels, split-K with fp32 atomics)
-//   * BERT linears / attention matmuls (batched over (batch, head) with strides; no transposes)
-// Operands are staged global -> registers -> LDS (zero-filled out of range, optional fused
-// BN+SiLU(+SE gate) prologue on the streamed operand), fragments are read with ds_read_b128 and fed
-// to v_mfma_f32_16x16x32_bf16; 4 waves per workgroup, double-buffered LDS, one barrier per K tile.
-// The epilogue goes back through LDS so global stores are 16-byte row segments, and can emit
-// per-column sum / sum-of-squares partials (training-mode BatchNorm statistics of the conv output).
+// Serves every matmul-shaped op of the hot path that is NOT covered by the row-streaming kernels
+// (gemm_rows.hip / gemm_wgrad_rows.hip), i.e. the compute-heavier layers:
+//   * pointwise (1x1) convolutions of the late EfficientNet stages, NHWC = GEMM over pixels
+//     (efficientnet_custom.py:104,122,283), their dgrad and wgrad (reduction over pixels, split-K combined
+//     through a workspace, no atomics)
+//   * BERT linears and the attention matmuls (batched over (batch, head) with strides; no transposes)
+// Layout / prologue / output type are TEMPLATE parameters, so each instantiation's hot loop carries no dead
+// code (a "one kernel, runtime flags" version measured 22k instructions and was instruction-fetch bound):
+//   LAY 0 = NT  A[m*lda+k]  B[n*ldb+k]      (forward linears, dgrad through a transposed weight, Q.K^T)
+//   LAY 1 = NN  A[m*lda+k]  B[k*ldb+n]      (P.V, dS.K, dgrad through the plain weight)
+//   LAY 2 = TN  A[k*lda+m]  B[k*ldb+n]      (weight gradients, dV, dK)
+// Operands are staged global -> registers -> LDS (k-major operands are transposed on the way in), fragments
+// are read with ds_read_b128 and fed to v_mfma_f32_16x16x32_bf16; 4 waves per workgroup, double-buffered LDS,
+// one barrier per K tile, register-staged tiles prefetched across K tiles AND across row blocks.
+// The bf16 epilogue goes back through LDS so global stores are 16-byte row segments, and can emit per-column
+// sum / sum-of-squares partials (training-mode BatchNorm statistics of the conv output).
 #include "common.cuh"
 #include "../../include/mammoclip_hip.h"
 
 namespace {
-
-template <int BK> struct LdsCfg {
-    static constexpr int ROW_BYTES = BK * 2 + 16;   // padded row: conflict-light ds_read_b128
-};
-
-struct Frag {
-    uint4 v;
-};
 
 __device__ __forceinline__ uint4 zero4() { return make_uint4(0u, 0u, 0u, 0u); }
 
@@ -44,22 +42,19 @@ __device__ __forceinline__ uint4 apply_prologue(uint4 v, const mc_gemm_args& p, 
     return pack8(f);
 }
 
-template <int BM, int BN, int BK, int WGM, int WGN>
-__global__ __launch_bounds__(256) void gemm_bf16_kernel(const mc_gemm_args p) {
-    constexpr int ROWB = LdsCfg<BK>::ROW_BYTES;
+template <int BM, int BN, int BK, int WGM, int WGN, int LAY, int PRO, bool CF32>
+__global__ __launch_bounds__(256) void gemm_kernel(const mc_gemm_args p) {
+    constexpr bool AKM = (LAY == 2), BKM = (LAY >= 1);
+    constexpr int ROWB = BK * 2 + 16;                 // padded LDS row: conflict-light ds_read_b128
     constexpr int WM = BM / WGM, WN = BN / WGN;
     constexpr int FM = WM / 16, FN = WN / 16;
-    constexpr int KCH = BK / 8;                       // 16-byte chunks per row (k-contiguous mode)
-    constexpr int A_CH = (BM * KCH + 255) / 256;      // chunks per thread, k-contiguous A
-    constexpr int B_CH = (BN * KCH + 255) / 256;
-    constexpr int KP = BK / 2;                        // k pairs per tile (k-major mode)
-    constexpr int A_CHT = (KP * (BM / 8) + 255) / 256;
-    constexpr int B_CHT = (KP * (BN / 8) + 255) / 256;
-    constexpr int A_REGS = (A_CH > 2 * A_CHT) ? A_CH : 2 * A_CHT;
-    constexpr int B_REGS = (B_CH > 2 * B_CHT) ? B_CH : 2 * B_CHT;
+    constexpr int KCH = BK / 8;                       // 16-byte chunks per row (k-contiguous operands)
+    constexpr int KP = BK / 2;                        // k pairs per tile (k-major operands)
+    constexpr int A_REGS = AKM ? 2 * ((KP * (BM / 8) + 255) / 256) : (BM * KCH + 255) / 256;
+    constexpr int B_REGS = BKM ? 2 * ((KP * (BN / 8) + 255) / 256) : (BN * KCH + 255) / 256;
     constexpr int STAGE_BYTES = (BM + BN) * ROWB;
     constexpr int CROW = (BN + 8) * 2;                // epilogue tile row bytes (bf16)
-    constexpr int EPI_BYTES = BM * CROW;
+    constexpr int EPI_BYTES = CF32 ? 0 : BM * CROW;
     constexpr int LDS_BYTES = (2 * STAGE_BYTES > EPI_BYTES) ? 2 * STAGE_BYTES : EPI_BYTES;
     __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
 
@@ -82,30 +77,34 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const mc_gemm_args p) {
     const long long kbeg = (long long)split * tps * BK;
     long long kend = kbeg + tps * BK;
     if (kend > p.K) kend = p.K;
-
     const long long mtiles = (p.M + BM - 1) / BM;
+    const bool n_full = n0 + BN <= p.N;
 
     float colsum[8], colsq[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) { colsum[i] = 0.f; colsq[i] = 0.f; }
 
-    uint4 ra[A_REGS], rb[B_REGS];
+    uint4 ra0[A_REGS], rb0[B_REGS], ra1[A_REGS], rb1[B_REGS];   // two named register stages (stay in VGPRs)
 
-    // ---- global -> registers (all loads of a tile are issued back to back; nothing waits here)
-    auto load_tiles = [&](long long m0, long long k0) {
-        if (!p.a_kmajor) {
+    // ---- global -> registers.  full = tile entirely inside the matrices: no per-chunk predication.
+    auto load_tiles = [&](uint4 (&ra)[A_REGS], uint4 (&rb)[B_REGS], long long m0, long long k0) {
+        const bool full = n_full && (m0 + BM <= p.M) && (k0 + BK <= kend);
+        if (!AKM) {
 #pragma unroll
-            for (int i = 0; i < A_CH; ++i) {
+            for (int i = 0; i < A_REGS; ++i) {
                 int c = tid + i * 256;
                 int row = c / KCH, kc = c % KCH;
                 long long m = m0 + row, k = k0 + kc * 8;
-                uint4 v = zero4();
-                if (c < BM * KCH && m < p.M && k < kend) v = *reinterpret_cast<const uint4*>(A + m * p.lda + k);
-                ra[i] = v;
+                if (full) ra[i] = *reinterpret_cast<const uint4*>(A + m * p.lda + k);
+                else {
+                    uint4 v = zero4();
+                    if (c < BM * KCH && m < p.M && k < kend) v = *reinterpret_cast<const uint4*>(A + m * p.lda + k);
+                    ra[i] = v;
+                }
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < A_CHT; ++i) {
+            for (int i = 0; i < A_REGS / 2; ++i) {
                 int c = tid + i * 256;
                 int xc = c % (BM / 8), kp = c / (BM / 8);
                 long long m = m0 + xc * 8, k = k0 + 2 * kp;
@@ -117,19 +116,22 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const mc_gemm_args p) {
                 ra[2 * i] = v0; ra[2 * i + 1] = v1;
             }
         }
-        if (!p.b_kmajor) {
+        if (!BKM) {
 #pragma unroll
-            for (int i = 0; i < B_CH; ++i) {
+            for (int i = 0; i < B_REGS; ++i) {
                 int c = tid + i * 256;
                 int row = c / KCH, kc = c % KCH;
                 long long n = n0 + row, k = k0 + kc * 8;
-                uint4 v = zero4();
-                if (c < BN * KCH && n < p.N && k < kend) v = *reinterpret_cast<const uint4*>(B + n * p.ldb + k);
-                rb[i] = v;
+                if (full && BN * KCH >= 256) rb[i] = *reinterpret_cast<const uint4*>(B + n * p.ldb + k);
+                else {
+                    uint4 v = zero4();
+                    if (c < BN * KCH && n < p.N && k < kend) v = *reinterpret_cast<const uint4*>(B + n * p.ldb + k);
+                    rb[i] = v;
+                }
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < B_CHT; ++i) {
+            for (int i = 0; i < B_REGS / 2; ++i) {
                 int c = tid + i * 256;
                 int xc = c % (BN / 8), kp = c / (BN / 8);
                 long long n = n0 + xc * 8, k = k0 + 2 * kp;
@@ -147,17 +149,17 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const mc_gemm_args p) {
     // k-major operands are transposed on the way in: a thread holds rows k, k+1 for 8 consecutive x and writes
     // 8 dwords {x_j: (k, k+1)}.  The 16-byte slot inside the row is XOR-swizzled with (x >> 3) & 7 so the
     // 32-lane write groups do not pile onto one bank; the fragment reader applies the same XOR.
-    auto store_tiles = [&](int buf, long long m0, long long k0) {
+    auto store_tiles = [&](const uint4 (&ra)[A_REGS], const uint4 (&rb)[B_REGS], int buf, long long m0, long long k0) {
         unsigned char* sA = smem + buf * STAGE_BYTES;
         unsigned char* sB = sA + BM * ROWB;
-        if (!p.a_kmajor) {
+        if (!AKM) {
 #pragma unroll
-            for (int i = 0; i < A_CH; ++i) {
+            for (int i = 0; i < A_REGS; ++i) {
                 int c = tid + i * 256;
                 if (c < BM * KCH) {
                     int row = c / KCH, kc = c % KCH;
                     uint4 v = ra[i];
-                    if (p.pro_operand == 1) {
+                    if (PRO == 1) {
                         long long m = m0 + row, k = k0 + kc * 8;
                         if (m < p.M && k < kend) v = apply_prologue(v, p, m, (int)k);
                     }
@@ -166,7 +168,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const mc_gemm_args p) {
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < A_CHT; ++i) {
+            for (int i = 0; i < A_REGS / 2; ++i) {
                 int c = tid + i * 256;
                 if (c < KP * (BM / 8)) {
                     int xc = c % (BM / 8), kp = c / (BM / 8);
@@ -183,9 +185,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const mc_gemm_args p) {
                 }
             }
         }
-        if (!p.b_kmajor) {
+        if (!BKM) {
 #pragma unroll
-            for (int i = 0; i < B_CH; ++i) {
+            for (int i = 0; i < B_REGS; ++i) {
                 int c = tid + i * 256;
                 if (c < BN * KCH) {
                     int row = c / KCH, kc = c % KCH;
@@ -194,12 +196,12 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const mc_gemm_args p) {
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < B_CHT; ++i) {
+            for (int i = 0; i < B_REGS / 2; ++i) {
                 int c = tid + i * 256;
                 if (c < KP * (BN / 8)) {
                     int xc = c % (BN / 8), kp = c / (BN / 8);
                     uint4 v0 = rb[2 * i], v1 = rb[2 * i + 1];
-                    if (p.pro_operand == 2) {
+                    if (PRO == 2) {
                         long long n = n0 + xc * 8, k = k0 + 2 * kp;
                         if (n < p.N) {
                             if (k < kend) v0 = apply_prologue(v0, p, k, (int)n);
@@ -235,13 +237,13 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const mc_gemm_args p) {
 #pragma unroll
             for (int i = 0; i < FM; ++i) {
                 int row = wm * WM + i * 16 + (lane & 15);
-                int s = p.a_kmajor ? ((slot ^ ((row >> 3) & 7)) & (KCH - 1)) : slot;
+                int s = AKM ? ((slot ^ ((row >> 3) & 7)) & (KCH - 1)) : slot;
                 af[i] = *reinterpret_cast<const bf16x8_t*>(sA + row * ROWB + s * 16);
             }
 #pragma unroll
             for (int j = 0; j < FN; ++j) {
                 int row = wn * WN + j * 16 + (lane & 15);
-                int s = p.b_kmajor ? ((slot ^ ((row >> 3) & 7)) & (KCH - 1)) : slot;
+                int s = BKM ? ((slot ^ ((row >> 3) & 7)) & (KCH - 1)) : slot;
                 bfr[j] = *reinterpret_cast<const bf16x8_t*>(sB + row * ROWB + s * 16);
             }
 #pragma unroll
@@ -253,33 +255,12 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const mc_gemm_args p) {
     };
     // acc[i][j][r]: row m = wm*WM + i*16 + (lane & 15), col n = wn*WN + j*16 + (lane >> 4)*4 + r
 
-    long long mt = blockIdx.y;
-    if (mt < mtiles && kbeg < kend) load_tiles(mt * BM, kbeg);
-    int buf = 0;
-    for (; mt < mtiles; mt += gridDim.y) {
-        const long long m0 = mt * BM;
-#pragma unroll
-        for (int i = 0; i < FM; ++i)
-#pragma unroll
-            for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-
-        for (long long k0 = kbeg; k0 < kend; k0 += BK) {
-            store_tiles(buf, m0, k0);
-            __syncthreads();
-            // prefetch: next K tile of this row block, or the first K tile of this workgroup's NEXT row block, so
-            // the loads are in flight during the MFMAs and the epilogue
-            if (k0 + BK < kend) load_tiles(m0, k0 + BK);
-            else if (mt + gridDim.y < mtiles) load_tiles((mt + gridDim.y) * BM, kbeg);
-            compute(buf);
-            buf ^= 1;
-        }
+    auto epilogue = [&](const long long m0) {
         __syncthreads();   // all fragment reads done before smem is reused by the epilogue
-
-        // ---------------- epilogue ----------------
         const float alpha = p.alpha;
         const int mrow = wm * WM + (lane & 15);
         const int ncol = wn * WN + (lane >> 4) * 4;
-        if (p.c_f32) {
+        if (CF32) {
             const bool to_ws = p.splits > 1 && p.splitk_ws;
             float* C = to_ws ? p.splitk_ws + (long long)split * p.M * p.N : reinterpret_cast<float*>(p.C) + coff;
             const long long ldc = to_ws ? p.N : p.ldc;
@@ -303,20 +284,20 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const mc_gemm_args p) {
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < FM; ++i)
+            for (int j = 0; j < FN; ++j) {
+                int n = n0 + ncol + j * 16;
+                float bv[4] = {0.f, 0.f, 0.f, 0.f};
+                if (bias) {
 #pragma unroll
-                for (int j = 0; j < FN; ++j) {
-                    int n = n0 + ncol + j * 16;
-                    float v[4];
+                    for (int r = 0; r < 4; ++r) bv[r] = (n + r < p.N) ? bias[n + r] : 0.f;
+                }
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float bv = (bias && n + r < p.N) ? bias[n + r] : 0.f;
-                        v[r] = acc[i][j][r] * alpha + bv;
-                        if (p.act == 1) v[r] = gelu_f(v[r]);
-                    }
-                    uint2 pk = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+                for (int i = 0; i < FM; ++i) {
+                    uint2 pk = make_uint2(pack_bf2(acc[i][j][0] * alpha + bv[0], acc[i][j][1] * alpha + bv[1]),
+                                          pack_bf2(acc[i][j][2] * alpha + bv[2], acc[i][j][3] * alpha + bv[3]));
                     *reinterpret_cast<uint2*>(smem + (mrow + i * 16) * CROW + (ncol + j * 16) * 2) = pk;
                 }
+            }
             __syncthreads();
             bf16_t* C = reinterpret_cast<bf16_t*>(p.C) + coff;
             constexpr int CPR = BN / 8;                 // 16-byte chunks per tile row
@@ -348,10 +329,61 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const mc_gemm_args p) {
             }
             __syncthreads();
         }
+    };
+
+    // ---------------- software-pipelined main loop ----------------
+    // The (row block, K tile) pairs this workgroup owns form one flat sequence; two tiles are always in flight in
+    // registers (global loads are issued two steps ahead of the LDS store that consumes them), across K tiles AND
+    // across row blocks, so HBM/L2 latency is covered even when a row block has only one or two K tiles.
+    const long long ktn = kbeg < kend ? (kend - kbeg + BK - 1) / BK : 0;
+    const long long my_mt = blockIdx.y < mtiles ? (mtiles - blockIdx.y + gridDim.y - 1) / gridDim.y : 0;
+    const long long total = my_mt * ktn;
+    if (ktn == 0) {
+        for (long long mt = blockIdx.y; mt < mtiles; mt += gridDim.y) {
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+            epilogue(mt * BM);
+        }
+    } else {
+        // (m0, k0) of flat step i, advanced incrementally (no divisions in the loop)
+        long long pm0 = (long long)blockIdx.y * BM, pk0 = kbeg;          // position of the NEXT tile to load
+        auto advance = [&]() {
+            pk0 += BK;
+            if (pk0 >= kend) { pk0 = kbeg; pm0 += (long long)gridDim.y * BM; }
+        };
+        long long cm0 = pm0, ck0 = pk0;                                  // position of the tile being consumed
+        if (0 < total) { load_tiles(ra0, rb0, pm0, pk0); advance(); }
+        if (1 < total) { load_tiles(ra1, rb1, pm0, pk0); advance(); }
+        int buf = 0, sl = 0;
+        for (long long i = 0; i < total; ++i) {
+            if (ck0 == kbeg) {
+#pragma unroll
+                for (int a = 0; a < FM; ++a)
+#pragma unroll
+                    for (int b = 0; b < FN; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+            }
+            if (sl == 0) store_tiles(ra0, rb0, buf, cm0, ck0);
+            else store_tiles(ra1, rb1, buf, cm0, ck0);
+            __syncthreads();
+            if (i + 2 < total) {
+                if (sl == 0) load_tiles(ra0, rb0, pm0, pk0);
+                else load_tiles(ra1, rb1, pm0, pk0);
+                advance();
+            }
+            compute(buf);
+            buf ^= 1;
+            sl ^= 1;
+            const bool last_k = ck0 + BK >= kend;
+            if (last_k) epilogue(cm0);
+            ck0 += BK;
+            if (last_k) { ck0 = kbeg; cm0 += (long long)gridDim.y * BM; }
+        }
     }
 
     // ---------------- column statistics partials ----------------
-    if (p.stat_partials) {
+    if (!CF32 && p.stat_partials) {
         constexpr int CPR = BN / 8;
         constexpr int RPP = 256 / CPR;
         float* red = reinterpret_cast<float*>(smem);     // [RPP][BN][2]
@@ -402,10 +434,10 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, int splits, l
     }
 }
 
-template <int BM, int BN, int BK, int WGM, int WGN>
+template <int BM, int BN, int BK, int WGM, int WGN, int LAY, int PRO, bool CF32>
 int launch(const mc_gemm_args& p, int grid_m, hipStream_t st) {
     dim3 grid(mc_div_up(p.N, BN), grid_m, p.batch * p.splits);
-    hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, BK, WGM, WGN>), grid, dim3(256), 0, st, p);
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, WGM, WGN, LAY, PRO, CF32>), grid, dim3(256), 0, st, p);
     MC_LAUNCH_CHECK();
     if (p.splits > 1 && p.splitk_ws) {
         long long mn = p.M * p.N;
@@ -414,6 +446,19 @@ int launch(const mc_gemm_args& p, int grid_m, hipStream_t st) {
         MC_LAUNCH_CHECK();
     }
     return MC_OK;
+}
+
+template <int LAY, int PRO, bool CF32>
+int dispatch_tile(const mc_gemm_args& p, int grid_m, hipStream_t st) {
+    const bool small_k = p.K <= 48;
+    if (p.N > 64)
+        return small_k ? launch<128, 128, 32, 2, 2, LAY, PRO, CF32>(p, grid_m, st)
+                       : launch<128, 128, 64, 2, 2, LAY, PRO, CF32>(p, grid_m, st);
+    if (p.N > 32)
+        return small_k ? launch<128, 64, 32, 2, 2, LAY, PRO, CF32>(p, grid_m, st)
+                       : launch<128, 64, 64, 2, 2, LAY, PRO, CF32>(p, grid_m, st);
+    return small_k ? launch<128, 32, 32, 4, 1, LAY, PRO, CF32>(p, grid_m, st)
+                   : launch<128, 32, 64, 4, 1, LAY, PRO, CF32>(p, grid_m, st);
 }
 
 }  // namespace
@@ -435,6 +480,8 @@ extern "C" int mc_gemm_bf16(const mc_gemm_args* a, void* stream) {
     MC_CHECK((p.a_kmajor ? p.M : p.K) % 8 == 0, "gemm: contiguous extent of A must be a multiple of 8");
     MC_CHECK((p.b_kmajor ? p.N : p.K) % 8 == 0, "gemm: contiguous extent of B must be a multiple of 8");
     MC_CHECK(p.c_f32 || p.N % 8 == 0, "gemm: N must be a multiple of 8 for bf16 output");
+    MC_CHECK(!(p.a_kmajor && !p.b_kmajor), "gemm: layout A k-major with B k-contiguous is not provided");
+    MC_CHECK(p.act == 0, "gemm: fused activation is not provided (use mc_gelu_fwd)");
     if (p.batch <= 0) p.batch = 1;
     if (p.nb2 <= 0) p.nb2 = 1;
     if (p.splits <= 0) p.splits = 1;
@@ -442,8 +489,8 @@ extern "C" int mc_gemm_bf16(const mc_gemm_args* a, void* stream) {
     MC_CHECK(!(p.splits > 1 && p.splitk_ws) || (p.batch == 1 && !p.bias), "gemm: workspace split-K is unbatched, no bias");
     MC_CHECK(!(p.stat_partials && (p.c_f32 || p.batch != 1 || p.splits != 1)), "gemm: stats need plain bf16 output");
     MC_CHECK(p.pro_operand == 0 || (p.pro_scale && p.pro_shift), "gemm: prologue needs scale/shift");
-    MC_CHECK(p.pro_operand != 1 || !p.a_kmajor, "gemm: A prologue needs k-contiguous A");
-    MC_CHECK(p.pro_operand != 2 || p.b_kmajor, "gemm: B prologue needs k-major B");
+    MC_CHECK(p.pro_operand != 1 || (!p.a_kmajor && !p.b_kmajor && !p.c_f32), "gemm: A prologue is provided for NT, bf16 output");
+    MC_CHECK(p.pro_operand != 2 || (p.a_kmajor && p.b_kmajor && p.c_f32), "gemm: B prologue is provided for TN, fp32 output");
     MC_CHECK(!p.R || (!p.c_f32 && p.ldr % 8 == 0), "gemm: residual needs bf16 output and ldr % 8 == 0");
     if (p.alpha == 0.f) p.alpha = 1.f;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -451,14 +498,25 @@ extern "C" int mc_gemm_bf16(const mc_gemm_args* a, void* stream) {
     long long cap = p.max_grid_m > 0 ? p.max_grid_m : 512;
     int grid_m = (int)(mtiles < cap ? mtiles : cap);
     if (!p.stat_partials && p.max_grid_m <= 0) {
-        // no persistent accumulators needed: one tile per block up to the grid limit
-        grid_m = (int)(mtiles < 65535 ? mtiles : 65535);
+        // persistent over row blocks only as far as it keeps >= ~4 workgroups per CU in the grid
+        long long nt = mc_div_up(p.N, 128) * (long long)p.batch * p.splits;
+        long long want = 2048 / (nt > 0 ? nt : 1);
+        if (want < 1) want = 1;
+        grid_m = (int)(mtiles < want ? mtiles : want);
     }
-    const bool small_k = p.K <= 48;
-    if (p.N > 64) {
-        return small_k ? launch<128, 128, 32, 2, 2>(p, grid_m, st) : launch<128, 128, 64, 2, 2>(p, grid_m, st);
-    } else if (p.N > 32) {
-        return small_k ? launch<128, 64, 32, 2, 2>(p, grid_m, st) : launch<128, 64, 64, 2, 2>(p, grid_m, st);
+    const int lay = p.a_kmajor ? 2 : (p.b_kmajor ? 1 : 0);
+    if (lay == 0) {
+        if (p.c_f32) return dispatch_tile<0, 0, true>(p, grid_m, st);
+        if (p.pro_operand == 1) return dispatch_tile<0, 1, false>(p, grid_m, st);
+        return dispatch_tile<0, 0, false>(p, grid_m, st);
     }
-    return small_k ? launch<128, 32, 32, 4, 1>(p, grid_m, st) : launch<128, 32, 64, 4, 1>(p, grid_m, st);
+    if (lay == 1) {
+        if (p.c_f32) return dispatch_tile<1, 0, true>(p, grid_m, st);
+        return dispatch_tile<1, 0, false>(p, grid_m, st);
+    }
+    if (p.c_f32) {
+        if (p.pro_operand == 2) return dispatch_tile<2, 2, true>(p, grid_m, st);
+        return dispatch_tile<2, 0, true>(p, grid_m, st);
+    }
+    return dispatch_tile<2, 0, false>(p, grid_m, st);
 }

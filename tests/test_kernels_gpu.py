@@ -62,8 +62,8 @@ def test_gemm_bias_gelu_residual_stats():
     M, N, K = 700, 3072, 768
     x, w = rnd(M, K, seed=3), rnd(N, K, seed=4, scale=K ** -0.5)
     bias = rnd(N, seed=5, dtype=torch.float32)
-    y = ops.linear_fwd(x, w, bias=bias, act=1)
-    check(y, F.gelu(x.float() @ w.float().T + bias), 1e-2, "bias+gelu")
+    y = ops.gelu_fwd(ops.linear_fwd(x, w, bias=bias))
+    check(y, F.gelu((x.float() @ w.float().T + bias).to(BF).float()), 1e-2, "bias, then gelu")
     res = rnd(M, 768, seed=6)
     w2 = rnd(768, N, seed=7, scale=N ** -0.5)
     y2 = ops.linear_fwd(y, w2, bias=bias[:768].contiguous(), residual=res)
