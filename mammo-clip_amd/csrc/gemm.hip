@@ -43,15 +43,16 @@ __device__ __forceinline__ uint4 apply_prologue(uint4 v, const mc_gemm_args& p, 
 }
 
 template <int BM, int BN, int BK, int WGM, int WGN, int LAY, int PRO, bool CF32>
-__global__ __launch_bounds__(256) void gemm_kernel(const mc_gemm_args p) {
+__global__ __launch_bounds__(WGM * WGN * 64) void gemm_kernel(const mc_gemm_args p) {
+    constexpr int NT = WGM * WGN * 64;                // threads per workgroup (4 or 8 waves)
     constexpr bool AKM = (LAY == 2), BKM = (LAY >= 1);
     constexpr int ROWB = BK * 2 + 16;                 // padded LDS row: conflict-light ds_read_b128
     constexpr int WM = BM / WGM, WN = BN / WGN;
     constexpr int FM = WM / 16, FN = WN / 16;
     constexpr int KCH = BK / 8;                       // 16-byte chunks per row (k-contiguous operands)
     constexpr int KP = BK / 2;                        // k pairs per tile (k-major operands)
-    constexpr int A_REGS = AKM ? 2 * ((KP * (BM / 8) + 255) / 256) : (BM * KCH + 255) / 256;
-    constexpr int B_REGS = BKM ? 2 * ((KP * (BN / 8) + 255) / 256) : (BN * KCH + 255) / 256;
+    constexpr int A_REGS = AKM ? 2 * ((KP * (BM / 8) + (NT - 1)) / NT) : (BM * KCH + (NT - 1)) / NT;
+    constexpr int B_REGS = BKM ? 2 * ((KP * (BN / 8) + (NT - 1)) / NT) : (BN * KCH + (NT - 1)) / NT;
     constexpr int STAGE_BYTES = (BM + BN) * ROWB;
     constexpr int CROW = (BN + 8) * 2;                // epilogue tile row bytes (bf16)
     constexpr int EPI_BYTES = CF32 ? 0 : BM * CROW;
@@ -92,7 +93,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const mc_gemm_args p) {
         if (!AKM) {
 #pragma unroll
             for (int i = 0; i < A_REGS; ++i) {
-                int c = tid + i * 256;
+                int c = tid + i * NT;
                 int row = c / KCH, kc = c % KCH;
                 long long m = m0 + row, k = k0 + kc * 8;
                 if (full) ra[i] = *reinterpret_cast<const uint4*>(A + m * p.lda + k);
@@ -105,7 +106,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const mc_gemm_args p) {
         } else {
 #pragma unroll
             for (int i = 0; i < A_REGS / 2; ++i) {
-                int c = tid + i * 256;
+                int c = tid + i * NT;
                 int xc = c % (BM / 8), kp = c / (BM / 8);
                 long long m = m0 + xc * 8, k = k0 + 2 * kp;
                 uint4 v0 = zero4(), v1 = zero4();
@@ -119,10 +120,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(const mc_gemm_args p) {
         if (!BKM) {
 #pragma unroll
             for (int i = 0; i < B_REGS; ++i) {
-                int c = tid + i * 256;
+                int c = tid + i * NT;
                 int row = c / KCH, kc = c % KCH;
                 long long n = n0 + row, k = k0 + kc * 8;
-                if (full && BN * KCH >= 256) rb[i] = *reinterpret_cast<const uint4*>(B + n * p.ldb + k);
+                if (full && BN * KCH >= NT) rb[i] = *reinterpret_cast<const uint4*>(B + n * p.ldb + k);
                 else {
                     uint4 v = zero4();
                     if (c < BN * KCH && n < p.N && k < kend) v = *reinterpret_cast<const uint4*>(B + n * p.ldb + k);
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const mc_gemm_args p) {
         } else {
 #pragma unroll
             for (int i = 0; i < B_REGS / 2; ++i) {
-                int c = tid + i * 256;
+                int c = tid + i * NT;
                 int xc = c % (BN / 8), kp = c / (BN / 8);
                 long long n = n0 + xc * 8, k = k0 + 2 * kp;
                 uint4 v0 = zero4(), v1 = zero4();
@@ -155,7 +156,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const mc_gemm_args p) {
         if (!AKM) {
 #pragma unroll
             for (int i = 0; i < A_REGS; ++i) {
-                int c = tid + i * 256;
+                int c = tid + i * NT;
                 if (c < BM * KCH) {
                     int row = c / KCH, kc = c % KCH;
                     uint4 v = ra[i];
@@ -169,7 +170,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const mc_gemm_args p) {
         } else {
 #pragma unroll
             for (int i = 0; i < A_REGS / 2; ++i) {
-                int c = tid + i * 256;
+                int c = tid + i * NT;
                 if (c < KP * (BM / 8)) {
                     int xc = c % (BM / 8), kp = c / (BM / 8);
                     const uint32_t* w0 = reinterpret_cast<const uint32_t*>(&ra[2 * i]);
@@ -188,7 +189,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const mc_gemm_args p) {
         if (!BKM) {
 #pragma unroll
             for (int i = 0; i < B_REGS; ++i) {
-                int c = tid + i * 256;
+                int c = tid + i * NT;
                 if (c < BN * KCH) {
                     int row = c / KCH, kc = c % KCH;
                     *reinterpret_cast<uint4*>(sB + row * ROWB + kc * 16) = rb[i];
@@ -197,7 +198,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const mc_gemm_args p) {
         } else {
 #pragma unroll
             for (int i = 0; i < B_REGS / 2; ++i) {
-                int c = tid + i * 256;
+                int c = tid + i * NT;
                 if (c < KP * (BN / 8)) {
                     int xc = c % (BN / 8), kp = c / (BN / 8);
                     uint4 v0 = rb[2 * i], v1 = rb[2 * i + 1];
@@ -301,7 +302,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const mc_gemm_args p) {
             __syncthreads();
             bf16_t* C = reinterpret_cast<bf16_t*>(p.C) + coff;
             constexpr int CPR = BN / 8;                 // 16-byte chunks per tile row
-            constexpr int RPP = 256 / CPR;              // rows per pass
+            constexpr int RPP = NT / CPR;              // rows per pass
             const int cc = tid % CPR, r0 = tid / CPR;
             const int n = n0 + cc * 8;
             if (n < p.N) {
@@ -385,7 +386,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const mc_gemm_args p) {
     // ---------------- column statistics partials ----------------
     if (!CF32 && p.stat_partials) {
         constexpr int CPR = BN / 8;
-        constexpr int RPP = 256 / CPR;
+        constexpr int RPP = NT / CPR;
         float* red = reinterpret_cast<float*>(smem);     // [RPP][BN][2]
         const int cc = tid % CPR, r0 = tid / CPR;
         __syncthreads();
@@ -395,7 +396,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const mc_gemm_args p) {
             red[(r0 * BN + cc * 8 + q) * 2 + 1] = colsq[q];
         }
         __syncthreads();
-        for (int c = tid; c < BN; c += 256) {
+        for (int c = tid; c < BN; c += NT) {
             float s = 0.f, s2 = 0.f;
             for (int r = 0; r < RPP; ++r) { s += red[(r * BN + c) * 2]; s2 += red[(r * BN + c) * 2 + 1]; }
             int n = n0 + c;
@@ -436,12 +437,13 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, int splits, l
 
 template <int BM, int BN, int BK, int WGM, int WGN, int LAY, int PRO, bool CF32>
 int launch(const mc_gemm_args& p, int grid_m, hipStream_t st) {
+    constexpr int NT = WGM * WGN * 64;
     dim3 grid(mc_div_up(p.N, BN), grid_m, p.batch * p.splits);
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, WGM, WGN, LAY, PRO, CF32>), grid, dim3(256), 0, st, p);
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, WGM, WGN, LAY, PRO, CF32>), grid, dim3(NT), 0, st, p);
     MC_LAUNCH_CHECK();
     if (p.splits > 1 && p.splitk_ws) {
         long long mn = p.M * p.N;
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(mc_div_up(mc_div_up(mn, 4), 256)), dim3(256), 0, st, p.splitk_ws,
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(mc_div_up(mc_div_up(mn, 4), NT)), dim3(NT), 0, st, p.splitk_ws,
                            p.splits, mn, p.N, reinterpret_cast<float*>(p.C), p.ldc, p.c_atomic);
         MC_LAUNCH_CHECK();
     }
@@ -451,9 +453,11 @@ int launch(const mc_gemm_args& p, int grid_m, hipStream_t st) {
 template <int LAY, int PRO, bool CF32>
 int dispatch_tile(const mc_gemm_args& p, int grid_m, hipStream_t st) {
     const bool small_k = p.K <= 48;
+    // 128x128 tiles run with 8 waves (wave tile 64x32): half the accumulator / staging registers per thread,
+    // twice the waves per CU to overlap global->LDS staging with MFMA issue
     if (p.N > 64)
-        return small_k ? launch<128, 128, 32, 2, 2, LAY, PRO, CF32>(p, grid_m, st)
-                       : launch<128, 128, 64, 2, 2, LAY, PRO, CF32>(p, grid_m, st);
+        return small_k ? launch<128, 128, 32, 2, 4, LAY, PRO, CF32>(p, grid_m, st)
+                       : launch<128, 128, 64, 2, 4, LAY, PRO, CF32>(p, grid_m, st);
     if (p.N > 32)
         return small_k ? launch<128, 64, 32, 2, 2, LAY, PRO, CF32>(p, grid_m, st)
                        : launch<128, 64, 64, 2, 2, LAY, PRO, CF32>(p, grid_m, st);
