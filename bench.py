@@ -38,8 +38,12 @@ WORKLOADS = {
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 MFMA_PEAK_TFS = 2500.0         # dense bf16 MFMA peak
 
-STREAM_OPS = ("mc_dwconv_fwd", "mc_dwconv_bwd_weight", "mc_dwconv_bwd_data", "mc_bnact_apply", "mc_bnact_pool",
-              "mc_bnact_bwd_reduce", "mc_bnact_bwd_apply", "mc_bnact_se_dgate")
+# The dominant kernel of the step (rocprofv3 --kernel-trace --stats, profiles/r01_cfg3_kernel_stats.csv: 12.2 % of GPU
+# time): bnact_bwd_apply_k, the BatchNorm(+SiLU) backward "apply" pass  dx = A*dz + B*x + C  (reads the saved conv
+# output x and the upstream gradient g, writes dx): HBM-bound, 3 x rows x channels x 2 B algorithmic bytes per launch.
+ROOFLINE_OP = "mc_bnact_bwd_apply"
+ROOFLINE_KERNEL = "bnact_bwd_k<true> (BatchNorm+SiLU backward apply pass)"
+STREAM_OPS = (ROOFLINE_OP,)
 
 
 def model_cfg(enc_name):
@@ -157,10 +161,12 @@ def main():
     if rank == 0:
         ms = dt / args.steps * 1e3
         pairs = b * world * args.steps / dt
-        sb = sum(v[2] for k, v in summ.items() if k in STREAM_OPS)
-        st = sum(v[1] for k, v in summ.items() if k in STREAM_OPS)
-        sc = sum(v[0] for k, v in summ.items() if k in STREAM_OPS)
+        sc, st, sb, _ = summ.get(ROOFLINE_OP, (0, 0.0, 0, 0))
         ach = sb / (st * 1e-3) / 1e9 if st > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_roofline_traffic.json")
+        if os.path.exists(tpath) and args.workload == "cfg3" and not args.batch:
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")   # PMC pass (rocprofv3 --pmc), same workload
         res = {
             "metric": "image-text pairs/s (whole node), EN-B5+BioClinicalBERT contrastive pre-training step",
             "value": round(pairs, 3), "unit": "image-text pairs/s", "n_gpus": world, "steps": args.steps,
@@ -171,10 +177,11 @@ def main():
                                    f"AdamW; fwd+loss+bwd+optimizer; dropout/drop-connect on",
                        "global_batch": b * world, "parallelism": f"dp{world}", "loss": round(loss_val, 5)},
             "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
-                         "kernel": "depthwise-conv + BatchNorm/SiLU streaming kernels (" + ",".join(STREAM_OPS) + ")",
-                         "launches": sc, "ms_in_kernels_per_step": round(st / args.steps, 3),
-                         "algorithmic_bytes_per_step": int(sb / args.steps)},
+                         "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "kernel": ROOFLINE_KERNEL, "launches": sc,
+                         "avg_launch_us": round(st / max(sc, 1) * 1e3, 1),
+                         "algorithmic_bytes_per_launch": int(sb / max(sc, 1)),
+                         "timing": "HIP events on the launch stream around every launch inside the timed steps"},
         }
         if world == 1 and not args.no_cpu_baseline:
             try:

@@ -29,20 +29,35 @@ def DistAutogradAllGatherFunction(partial=False):
     return F
 
 
+def _tensor_collectives_ok():
+    """RCCL ("nccl") has native all_gather_into_tensor / reduce_scatter_tensor; the gloo backend used by the CPU
+    tests gets the list forms of the same collectives."""
+    return dist.get_backend() == "nccl"
+
+
 class _FusedGather(torch.autograd.Function):
-    """stacked [k,b,D] -> [W,k,b,D] with one all_gather_into_tensor; backward one reduce_scatter_tensor."""
+    """stacked [k,b,D] -> [W,k,b,D] with ONE all-gather; backward ONE reduce-scatter(SUM)."""
 
     @staticmethod
     def forward(ctx, stacked):
         W = dist.get_world_size()
-        out = torch.empty((W,) + tuple(stacked.shape), dtype=stacked.dtype, device=stacked.device)
-        dist.all_gather_into_tensor(out, stacked.contiguous())
-        return out
+        stacked = stacked.contiguous()
+        out = torch.empty((W * stacked.shape[0],) + tuple(stacked.shape[1:]), dtype=stacked.dtype, device=stacked.device)
+        if _tensor_collectives_ok():
+            dist.all_gather_into_tensor(out, stacked)
+        else:
+            dist.all_gather(list(out.chunk(W, 0)), stacked)
+        return out.view((W,) + tuple(stacked.shape))
 
     @staticmethod
     def backward(ctx, grad):
+        W = grad.shape[0]
+        grad = grad.contiguous()
         out = torch.empty(grad.shape[1:], dtype=grad.dtype, device=grad.device)
-        dist.reduce_scatter_tensor(out, grad.contiguous(), op=dist.ReduceOp.SUM)
+        if _tensor_collectives_ok():
+            dist.reduce_scatter_tensor(out, grad.view((W * grad.shape[1],) + tuple(grad.shape[2:])), op=dist.ReduceOp.SUM)
+        else:
+            dist.reduce_scatter(out, [g.contiguous() for g in grad.unbind(0)], op=dist.ReduceOp.SUM)
         return out
 
 

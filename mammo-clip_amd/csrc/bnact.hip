@@ -145,96 +145,101 @@ __global__ __launch_bounds__(256) void bnact_img_reduce_k(const mc_bnact_args p)
     }
 }
 
-__device__ __forceinline__ void bwd_dz8(const mc_bnact_args& p, long long pix, int c8, const float* x,
-                                        const float* s, const float* t, float* dz) {
-    float up[8];
-    if (p.g) unpack8(*reinterpret_cast<const uint4*>(p.g + pix * p.c + c8), up);
-    else {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) up[q] = 0.f;
-    }
-    long long img = 0;
-    if (p.mul || p.add || p.rowscale) img = pix / p.hw;
-    if (p.mul) {
-        float m[8];
-        load8f(p.mul + img * p.c + c8, m);
-#pragma unroll
-        for (int q = 0; q < 8; ++q) up[q] *= m[q];
-    }
-    if (p.add) {
-        const float asc = (p.add_scale == 0.f) ? 1.f : p.add_scale;
-        float a[8];
-        load8f(p.add + img * p.c + c8, a);
-#pragma unroll
-        for (int q = 0; q < 8; ++q) up[q] += a[q] * asc;
-    }
-    float rs = p.rowscale ? p.rowscale[img] : 1.f;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        float d = up[q] * rs;
-        if (p.act == 1) d *= silu_grad_f(x[q] * s[q] + t[q]);
-        dz[q] = d;
-    }
-}
-
-__global__ __launch_bounds__(256) void bnact_bwd_reduce_k(const mc_bnact_args p) {
+// Backward through y = act(x*scale + shift) * rowscale with upstream gradient g*mul[img,c] + add[img,c]*add_scale:
+//   REDUCE pass:  per-channel sums (sum dz, sum dz*xhat)          -> partials
+//   APPLY  pass:  dx = A*dz + B*x + C (coefficients from mc_bn_bwd_finalize) -> bf16
+// Grid = (row blocks, image): a workgroup stays inside ONE image, so the per-(image, channel) factors are loaded
+// once; a thread owns one 8-channel vector and walks down the rows, so the per-channel parameters live in registers
+// and the loop body is two 16-byte loads, the activation derivative and (APPLY) one 16-byte store, two rows in
+// flight per iteration.
+template <bool APPLY>
+__global__ __launch_bounds__(256) void bnact_bwd_k(const mc_bnact_args p) {
     RowMap rm(p.c);
-    __shared__ float red[256 * 16];
-    const long long rows = p.n_img * p.hw;
+    __shared__ float red[APPLY ? 1 : 256 * 16];
+    const long long img = blockIdx.y;
+    const bf16_t* xb = p.x + img * p.hw * p.c;
+    const bf16_t* gb = p.g ? p.g + img * p.hw * p.c : nullptr;
+    bf16_t* dxb = APPLY ? p.dx + img * p.hw * p.c : nullptr;
+    const float rs = p.rowscale ? p.rowscale[img] : 1.f;
+    const float asc = (p.add_scale == 0.f) ? 1.f : p.add_scale;
+    const long long rstride = (long long)gridDim.x * rm.rpb;
     for (int cbase = 0; cbase < rm.cv; cbase += rm.cvp) {
-        int v = cbase + rm.cl;
+        const int v = cbase + rm.cl;
+        const bool active = rm.rl < rm.rpb && v < rm.cv;
         float a0[8], a1[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) { a0[q] = 0.f; a1[q] = 0.f; }
-        if (rm.rl < rm.rpb && v < rm.cv) {
-            float s[8], t[8], mu[8], is[8];
+        if (active) {
+            float s[8], t[8], k0[8], k1[8], k2[8], mulv[8], addv[8];
             load8f(p.scale + v * 8, s);
             load8f(p.shift + v * 8, t);
-            load8f(p.mean + v * 8, mu);
-            load8f(p.invstd + v * 8, is);
-            for (long long r = (long long)blockIdx.x * rm.rpb + rm.rl; r < rows; r += (long long)gridDim.x * rm.rpb) {
-                float x[8], dz[8];
-                unpack8(*reinterpret_cast<const uint4*>(p.x + r * p.c + v * 8), x);
-                bwd_dz8(p, r, v * 8, x, s, t, dz);
+            if (APPLY) { load8f(p.coef + v * 8, k0); load8f(p.coef + p.c + v * 8, k1); load8f(p.coef + 2 * p.c + v * 8, k2); }
+            else { load8f(p.mean + v * 8, k0); load8f(p.invstd + v * 8, k1); }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { mulv[q] = rs; addv[q] = 0.f; }
+            if (p.mul) {
+                float m[8];
+                load8f(p.mul + img * p.c + v * 8, m);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) mulv[q] = m[q] * rs;
+            }
+            if (p.add) {
+                float m[8];
+                load8f(p.add + img * p.c + v * 8, m);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) addv[q] = m[q] * asc * rs;
+            }
+            auto body = [&](long long r, const uint4& xv, const uint4& gv) {
+                float x[8], g[8], dz[8];
+                unpack8(xv, x);
+                unpack8(gv, g);
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
-                    a0[q] += dz[q];
-                    a1[q] += dz[q] * (x[q] - mu[q]) * is[q];
+                    float d = g[q] * mulv[q] + addv[q];
+                    if (p.act == 1) d *= silu_grad_f(x[q] * s[q] + t[q]);
+                    dz[q] = d;
+                }
+                if (APPLY) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) dz[q] = k0[q] * dz[q] + k1[q] * x[q] + k2[q];
+                    *reinterpret_cast<uint4*>(dxb + r * p.c + v * 8) = pack8(dz);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) { a0[q] += dz[q]; a1[q] += dz[q] * (x[q] - k0[q]) * k1[q]; }
+                }
+            };
+            const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
+            long long r = (long long)blockIdx.x * rm.rpb + rm.rl;
+            for (; r + rstride < p.hw; r += 2 * rstride) {          // two independent rows in flight
+                const long long r2 = r + rstride;
+                uint4 x0 = *reinterpret_cast<const uint4*>(xb + r * p.c + v * 8);
+                uint4 x1 = *reinterpret_cast<const uint4*>(xb + r2 * p.c + v * 8);
+                uint4 g0 = gb ? *reinterpret_cast<const uint4*>(gb + r * p.c + v * 8) : z4;
+                uint4 g1 = gb ? *reinterpret_cast<const uint4*>(gb + r2 * p.c + v * 8) : z4;
+                body(r, x0, g0);
+                body(r2, x1, g1);
+            }
+            if (r < p.hw) {
+                uint4 x0 = *reinterpret_cast<const uint4*>(xb + r * p.c + v * 8);
+                uint4 g0 = gb ? *reinterpret_cast<const uint4*>(gb + r * p.c + v * 8) : z4;
+                body(r, x0, g0);
+            }
+        }
+        if (!APPLY) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { red[threadIdx.x * 16 + q] = a0[q]; red[threadIdx.x * 16 + 8 + q] = a1[q]; }
+            __syncthreads();
+            if (rm.rl == 0 && v < rm.cv) {
+                const long long prow = img * gridDim.x + blockIdx.x;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    float sm = 0.f;
+                    for (int r = 0; r < rm.rpb; ++r) sm += red[(r * rm.cvp + rm.cl) * 16 + q];
+                    p.partials[(prow * 2 + (q >> 3)) * p.c + v * 8 + (q & 7)] = sm;
                 }
             }
+            __syncthreads();
         }
-#pragma unroll
-        for (int q = 0; q < 8; ++q) { red[threadIdx.x * 16 + q] = a0[q]; red[threadIdx.x * 16 + 8 + q] = a1[q]; }
-        __syncthreads();
-        if (rm.rl == 0 && v < rm.cv) {
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                float sm = 0.f;
-                for (int r = 0; r < rm.rpb; ++r) sm += red[(r * rm.cvp + rm.cl) * 16 + q];
-                p.partials[((long long)blockIdx.x * 2 + (q >> 3)) * p.c + v * 8 + (q & 7)] = sm;
-            }
-        }
-        __syncthreads();
-    }
-}
-
-__global__ __launch_bounds__(256) void bnact_bwd_apply_k(const mc_bnact_args p) {
-    const int cvn = p.c / 8;
-    const long long total = p.n_img * p.hw * cvn;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        int cv = (int)(i % cvn);
-        long long pix = i / cvn;
-        float x[8], s[8], t[8], dz[8], A[8], B[8], Cc[8];
-        unpack8(*reinterpret_cast<const uint4*>(p.x + pix * p.c + cv * 8), x);
-        load8f(p.scale + cv * 8, s);
-        load8f(p.shift + cv * 8, t);
-        bwd_dz8(p, pix, cv * 8, x, s, t, dz);
-        load8f(p.coef + cv * 8, A);
-        load8f(p.coef + p.c + cv * 8, B);
-        load8f(p.coef + 2 * p.c + cv * 8, Cc);
-#pragma unroll
-        for (int q = 0; q < 8; ++q) dz[q] = A[q] * dz[q] + B[q] * x[q] + Cc[q];
-        *reinterpret_cast<uint4*>(p.dx + pix * p.c + cv * 8) = pack8(dz);
     }
 }
 
@@ -404,16 +409,17 @@ extern "C" int mc_bn_eval_coeffs(const float* gamma, const float* beta, const fl
     MC_LAUNCH_CHECK();
     return MC_OK;
 }
-extern "C" int mc_bnact_rows(const mc_bnact_args* a) {
-    int cv = a->c / 8;
+static int bwd_grid_x(const mc_bnact_args& p) {
+    int cv = p.c / 8;
     int cvp = cv < 256 ? cv : 256;
     int rpb = 256 / (cvp > 0 ? cvp : 1);
-    long long rows = a->n_img * a->hw;
-    long long b = (rows + (long long)rpb * 32 - 1) / ((long long)rpb * 32);
-    if (b < 1) b = 1;
-    if (b > 1024) b = 1024;
-    return (int)b;
+    long long per = (p.hw + (long long)rpb * 32 - 1) / ((long long)rpb * 32);      // >= ~32 rows per thread
+    long long cap = 4096 / (p.n_img > 0 ? p.n_img : 1);
+    if (cap < 1) cap = 1;
+    long long gx = per < cap ? per : cap;
+    return (int)(gx < 1 ? 1 : gx);
 }
+extern "C" int mc_bnact_rows(const mc_bnact_args* a) { return (int)(bwd_grid_x(*a) * a->n_img); }
 extern "C" int mc_bnact_apply(const mc_bnact_args* a, void* stream) {
     const mc_bnact_args& p = *a;
     if (int e = check_bnact(p)) return e;
@@ -463,7 +469,7 @@ extern "C" int mc_bnact_bwd_reduce(const mc_bnact_args* a, void* stream) {
     const mc_bnact_args& p = *a;
     if (int e = check_bnact(p)) return e;
     MC_CHECK(p.partials && p.mean && p.invstd, "bnact_bwd_reduce: null partials/mean/invstd");
-    hipLaunchKernelGGL(bnact_bwd_reduce_k, dim3(mc_bnact_rows(a)), dim3(256), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL((bnact_bwd_k<false>), dim3(bwd_grid_x(p), (unsigned)p.n_img), dim3(256), 0, (hipStream_t)stream, p);
     MC_LAUNCH_CHECK();
     return MC_OK;
 }
@@ -471,7 +477,7 @@ extern "C" int mc_bnact_bwd_apply(const mc_bnact_args* a, void* stream) {
     const mc_bnact_args& p = *a;
     if (int e = check_bnact(p)) return e;
     MC_CHECK(p.coef && p.dx, "bnact_bwd_apply: null coef/dx");
-    hipLaunchKernelGGL(bnact_bwd_apply_k, dim3(stream_blocks(p.n_img * p.hw * (p.c / 8))), dim3(256), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL((bnact_bwd_k<true>), dim3(bwd_grid_x(p), (unsigned)p.n_img), dim3(256), 0, (hipStream_t)stream, p);
     MC_LAUNCH_CHECK();
     return MC_OK;
 }

@@ -44,8 +44,8 @@ class GradBuckets:
             off += p.numel()
         idx = len(self.buckets)
         self.buckets.append((flat, plist, views))
-        for p in plist:
-            self.bucket_of[p] = idx
+        for p, v in zip(plist, views):
+            self.bucket_of[p] = (idx, v)
 
     def begin(self):
         self.pending = [len(plist) for (_, plist, _) in self.buckets]
@@ -53,15 +53,21 @@ class GradBuckets:
         self.seen = set()
 
     def _hook(self, p):
-        idx = self.bucket_of[p]
-        flat, plist, views = self.buckets[idx]
-        v = views[plist.index(p)]
+        idx, v = self.bucket_of[p]
+        flat = self.buckets[idx][0]
         v.copy_(p.grad)
         p.grad = v
         self.seen.add(p)
         self.pending[idx] -= 1
         if self.pending[idx] == 0:
-            self.handles.append(dist.all_reduce(flat, op=dist.ReduceOp.AVG, async_op=True))
+            self._reduce(flat)
+
+    def _reduce(self, flat):
+        """mean over ranks: RCCL has a native AVG; gloo (CPU tests) gets SUM followed by a scale"""
+        if dist.get_backend() == "nccl":
+            self.handles.append((dist.all_reduce(flat, op=dist.ReduceOp.AVG, async_op=True), None))
+        else:
+            self.handles.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True), flat))
 
     def finish(self):
         """Parameters that got no gradient (e.g. the unused BERT pooler) keep grad None, like under the reference's
@@ -71,9 +77,11 @@ class GradBuckets:
                 for p, v in zip(plist, views):
                     if p not in self.seen:
                         v.zero_()
-                self.handles.append(dist.all_reduce(flat, op=dist.ReduceOp.AVG, async_op=True))
-        for h in self.handles:
+                self._reduce(flat)
+        for h, flat in self.handles:
             h.wait()
+            if flat is not None:
+                flat.div_(dist.get_world_size())
 
 
 class Trainer:
