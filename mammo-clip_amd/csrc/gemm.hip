@@ -43,7 +43,8 @@ __device__ __forceinline__ uint4 apply_prologue(uint4 v, const mc_gemm_args& p, 
 }
 
 template <int BM, int BN, int BK, int WGM, int WGN, int LAY, int PRO, bool CF32>
-__global__ __launch_bounds__(WGM * WGN * 64) void gemm_kernel(const mc_gemm_args p) {
+__global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8) ? 4 : 2) void gemm_kernel(const mc_gemm_args p) {
+    // 8-wave tiles are held to <= 128 VGPRs so two workgroups (16 waves) fit a CU
     constexpr int NT = WGM * WGN * 64;                // threads per workgroup (4 or 8 waves)
     constexpr bool AKM = (LAY == 2), BKM = (LAY >= 1);
     constexpr int ROWB = BK * 2 + 16;                 // padded LDS row: conflict-light ds_read_b128
