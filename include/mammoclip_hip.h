@@ -208,6 +208,12 @@ int mc_bnact_pool(const mc_bnact_args* args, void* stream);
 int mc_bnact_bwd_reduce(const mc_bnact_args* args, void* stream);
 int mc_bnact_bwd_apply(const mc_bnact_args* args, void* stream);
 int mc_bnact_se_dgate(const mc_bnact_args* args, void* stream);
+/* one pass over (x, g): args->dgate = float[5][n_img][c]: {sum g*y, sum g*y', sum g*y'*xhat, sum y', sum y'*xhat}
+ * (y = act(z)); [0] is d loss / d gate, [1..4] let the BatchNorm-backward sums be formed without another pass: */
+int mc_bnact_se_sums(const mc_bnact_args* args, void* stream);
+/* partials[n_img][2][c] (the mc_bn_bwd_finalize input) for upstream gradient g*gate + dpooled*add_scale */
+int mc_bn_partials_from_se_sums(const float* sums, const float* gate, const float* dpooled, float add_scale,
+                                long long n_img, int c, float* partials, void* stream);
 /* dgamma = sum dz*xhat, dbeta = sum dz; coef[0..2][c] for bwd_apply */
 int mc_bn_bwd_finalize(const float* partials, int rows, int c, double count, const float* gamma,
                        const float* mean, const float* invstd, float* dgamma, float* dbeta, float* coef,

@@ -193,13 +193,15 @@ class _MBConvFn(torch.autograd.Function):
         da1 = ops.linear_dgrad(dp, sv["wp"], w_t=wp_t)
         dwp = ops.linear_wgrad(dp, d, pro=(st1.scale, st1.shift, gate, ohw))
         # squeeze-excite
-        dgate = ops.bnact_se_dgate(d, da1, n, ohw, a.cexp, st1.scale, st1.shift, 1)
-        dpooled, dw1, db1, dw2, dbse2 = ops.se_bwd(pooled, gate, dgate, blk._se_reduce.weight.view(a.cse, a.cexp),
+        # ONE pass over (d, dA1) yields d loss / d gate AND the ingredients of the bn1-backward reductions
+        sums = ops.bnact_se_sums(d, da1, n, ohw, a.cexp, st1, 1)
+        dpooled, dw1, db1, dw2, dbse2 = ops.se_bwd(pooled, gate, sums[0], blk._se_reduce.weight.view(a.cse, a.cexp),
                                                    blk._se_reduce.bias, blk._se_expand.weight.view(a.cexp, a.cse),
                                                    blk._se_expand.bias)
         # bn1 + swish: upstream of swish output = dA1 * gate + dpooled / (oh*ow)
+        part1 = ops.bn_partials_from_se_sums(sums, gate, dpooled, 1.0 / ohw)
         dd, dg1, db1n = ops.bnact_bwd(d, n, ohw, a.cexp, st1, blk._bn1.weight, 1, g=da1, mul=gate, add=dpooled,
-                                      add_scale=1.0 / ohw)
+                                      add_scale=1.0 / ohw, partials=part1)
         del da1
         # depthwise
         if a.expand != 1:

@@ -145,6 +145,97 @@ __global__ __launch_bounds__(256) void bnact_img_reduce_k(const mc_bnact_args p)
     }
 }
 
+// Squeeze-excite backward sums in ONE pass over (x = depthwise output, g = d loss / d (gated activation)):
+//   sums[0] = sum_hw g*y          (d loss / d gate)                       y  = silu(z), z = x*scale + shift
+//   sums[1] = sum_hw g*y'         sums[2] = sum_hw g*y'*xhat              y' = silu'(z), xhat = (x - mean)*invstd
+//   sums[3] = sum_hw y'           sums[4] = sum_hw y'*xhat
+// With these, the BatchNorm-backward reductions of the block follow WITHOUT another pass over the big tensors:
+//   dz = (g*gate + dpooled/HW) * y'  =>  sum dz = sum_img gate*sums[1] + dpooled/HW*sums[3]   (same with xhat: [2],[4])
+// (dpooled only exists after the SE MLP backward, which itself needs sums[0] -- hence the decomposition).
+__global__ __launch_bounds__(256) void bnact_se_sums_k(const mc_bnact_args p) {
+    RowMap rm(p.c);
+    __shared__ float red[256 * 8];
+    const long long img = blockIdx.x;
+    const bf16_t* xb = p.x + img * p.hw * p.c;
+    const bf16_t* gb = p.g + img * p.hw * p.c;
+    const long long plane = p.n_img * p.c;
+    for (int cbase = 0; cbase < rm.cv; cbase += rm.cvp) {
+        int v = cbase + rm.cl;
+        float acc[5][8];
+#pragma unroll
+        for (int k = 0; k < 5; ++k)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc[k][q] = 0.f;
+        if (rm.rl < rm.rpb && v < rm.cv) {
+            float s[8], t[8], mu[8], is[8];
+            load8f(p.scale + v * 8, s);
+            load8f(p.shift + v * 8, t);
+            load8f(p.mean + v * 8, mu);
+            load8f(p.invstd + v * 8, is);
+            auto body = [&](const uint4& xv, const uint4& gv) {
+                float x[8], g[8];
+                unpack8(xv, x);
+                unpack8(gv, g);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    float z = x[q] * s[q] + t[q];
+                    float sg = sigmoid_f(z);
+                    float y = z * sg, yd = sg * (1.0f + z * (1.0f - sg));
+                    float xh = (x[q] - mu[q]) * is[q];
+                    float gyd = g[q] * yd;
+                    acc[0][q] += g[q] * y;
+                    acc[1][q] += gyd;
+                    acc[2][q] += gyd * xh;
+                    acc[3][q] += yd;
+                    acc[4][q] += yd * xh;
+                }
+            };
+            const long long rstride = (long long)gridDim.y * rm.rpb;
+            long long r = (long long)blockIdx.y * rm.rpb + rm.rl;
+            for (; r + rstride < p.hw; r += 2 * rstride) {             // two independent rows in flight
+                uint4 x0 = *reinterpret_cast<const uint4*>(xb + r * p.c + v * 8);
+                uint4 x1 = *reinterpret_cast<const uint4*>(xb + (r + rstride) * p.c + v * 8);
+                uint4 g0 = *reinterpret_cast<const uint4*>(gb + r * p.c + v * 8);
+                uint4 g1 = *reinterpret_cast<const uint4*>(gb + (r + rstride) * p.c + v * 8);
+                body(x0, g0);
+                body(x1, g1);
+            }
+            if (r < p.hw)
+                body(*reinterpret_cast<const uint4*>(xb + r * p.c + v * 8), *reinterpret_cast<const uint4*>(gb + r * p.c + v * 8));
+        }
+        for (int k = 0; k < 5; ++k) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) red[threadIdx.x * 8 + q] = acc[k][q];
+            __syncthreads();
+            if (rm.rl == 0 && v < rm.cv) {
+                float* dst = p.dgate + k * plane + img * p.c;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    float sm = 0.f;
+                    for (int r = 0; r < rm.rpb; ++r) sm += red[(r * rm.cvp + rm.cl) * 8 + q];
+                    if (gridDim.y == 1) dst[v * 8 + q] = sm;
+                    else atomicAdd(dst + v * 8 + q, sm);
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// BN-backward partials [n_img][2][c] from the per-image sums above, the SE gate and d loss / d pooled
+__global__ void bn_partials_from_se_sums_k(const float* __restrict__ sums, const float* __restrict__ gate,
+                                           const float* __restrict__ dpooled, float add_scale, long long n_img, int c,
+                                           float* __restrict__ partials) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long plane = n_img * c;
+    if (i >= plane) return;
+    long long img = i / c;
+    int ch = (int)(i % c);
+    float gt = gate[i], dp = dpooled[i] * add_scale;
+    partials[(img * 2 + 0) * c + ch] = gt * sums[1 * plane + i] + dp * sums[3 * plane + i];
+    partials[(img * 2 + 1) * c + ch] = gt * sums[2 * plane + i] + dp * sums[4 * plane + i];
+}
+
 // Backward through y = act(x*scale + shift) * rowscale with upstream gradient g*mul[img,c] + add[img,c]*add_scale:
 //   REDUCE pass:  per-channel sums (sum dz, sum dz*xhat)          -> partials
 //   APPLY  pass:  dx = A*dz + B*x + C (coefficients from mc_bn_bwd_finalize) -> bf16
@@ -462,6 +553,27 @@ extern "C" int mc_bnact_se_dgate(const mc_bnact_args* a, void* stream) {
         MC_CHECK(e == hipSuccess, "bnact_se_dgate: memset failed");
     }
     hipLaunchKernelGGL((bnact_img_reduce_k<1>), dim3((unsigned)p.n_img, sp), dim3(256), 0, (hipStream_t)stream, p);
+    MC_LAUNCH_CHECK();
+    return MC_OK;
+}
+extern "C" int mc_bnact_se_sums(const mc_bnact_args* a, void* stream) {
+    const mc_bnact_args& p = *a;
+    if (int e = check_bnact(p)) return e;
+    MC_CHECK(p.g && p.dgate && p.mean && p.invstd, "bnact_se_sums: null g / sums / mean / invstd");
+    int sp = img_splits(p);
+    if (sp > 1) {
+        hipError_t e = hipMemsetAsync(p.dgate, 0, sizeof(float) * 5 * p.n_img * p.c, (hipStream_t)stream);
+        MC_CHECK(e == hipSuccess, "bnact_se_sums: memset failed");
+    }
+    hipLaunchKernelGGL(bnact_se_sums_k, dim3((unsigned)p.n_img, sp), dim3(256), 0, (hipStream_t)stream, p);
+    MC_LAUNCH_CHECK();
+    return MC_OK;
+}
+extern "C" int mc_bn_partials_from_se_sums(const float* sums, const float* gate, const float* dpooled, float add_scale,
+                                           long long n_img, int c, float* partials, void* stream) {
+    MC_CHECK(sums && gate && dpooled && partials && n_img > 0 && c > 0, "bn_partials_from_se_sums: bad args");
+    hipLaunchKernelGGL(bn_partials_from_se_sums_k, dim3(mc_div_up(n_img * c, 256)), dim3(256), 0, (hipStream_t)stream, sums,
+                       gate, dpooled, add_scale, n_img, c, partials);
     MC_LAUNCH_CHECK();
     return MC_OK;
 }

@@ -18,7 +18,7 @@ constexpr int TOW = 16;
 
 template <int K, int S> struct DwCfg {
     static constexpr int TOH = (S == 1) ? 8 : 4;
-    static constexpr int R = (S == 1 && K == 3) ? 4 : 2;  // output pixels per strip (along W)
+    static constexpr int R = 2;                           // output pixels per strip (along W)
     static constexpr int NSTRIP = TOW / R;
     static constexpr int PASSES = TOH * NSTRIP * 8 / 256; // strips per thread
     static constexpr int IH_T = (TOH - 1) * S + K;
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const mc_dwconv_args p,
             for (int r = 0; r < C::R; ++r)
 #pragma unroll
                 for (int q = 0; q < 8; ++q) acc[r][q] = 0.f;
-#pragma unroll(K == 5 ? 1 : 3)
+#pragma unroll 1
             for (int kh = 0; kh < K; ++kh) {          // k = 5: keep one filter row live at a time (VGPR budget)
                 float in[C::NIN][8];
                 const unsigned char* rowp = tile + ((orow * S + kh) * C::IW_T + strip * C::R * S) * PIXB + cv * 16;

@@ -103,6 +103,8 @@ _SIGS = {
     "mc_bnact_bwd_reduce": ([C.POINTER(BnactArgs), P], I),
     "mc_bnact_bwd_apply": ([C.POINTER(BnactArgs), P], I),
     "mc_bnact_se_dgate": ([C.POINTER(BnactArgs), P], I),
+    "mc_bnact_se_sums": ([C.POINTER(BnactArgs), P], I),
+    "mc_bn_partials_from_se_sums": ([P, P, P, F, LL, I, P, P], I),
     "mc_bn_bwd_finalize": ([P, I, I, D, P, P, P, P, P, P, P], I),
     "mc_colsum_rows": ([LL, I], I),
     "mc_colsum_bf16": ([P, LL, I, LL, P, P, I, P], I),

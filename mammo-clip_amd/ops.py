@@ -322,17 +322,39 @@ def bnact_se_dgate(x, g, n_img, hw, c, scale, shift, act):
     return dgate
 
 
-def bnact_bwd(x, n_img, hw, c, stats, gamma, act, g=None, mul=None, add=None, rowscale=None, add_scale=1.0):
-    """Backward through y = act(BN_train(x)) (* rowscale).  Returns (dx bf16, dgamma, dbeta)."""
+def bnact_se_sums(x, g, n_img, hw, c, stats, act):
+    """[5, n_img, c] per-image sums of ONE pass over (x, g): see mc_bnact_se_sums."""
+    a = _bnact(x, n_img, hw, c, stats.scale, stats.shift, act)
+    sums = empty((5, n_img, c), torch.float32, x)
+    a.g, a.dgate, a.mean, a.invstd = _p(g), _p(sums), _p(stats.mean), _p(stats.invstd)
+    _note(4 * n_img * hw * c)
+    L.call("mc_bnact_se_sums", C.byref(a), _st())
+    return sums
+
+
+def bn_partials_from_se_sums(sums, gate, dpooled, add_scale):
+    _, n_img, c = sums.shape
+    part = empty((n_img, 2, c), torch.float32, sums)
+    L.call("mc_bn_partials_from_se_sums", _p(sums), _p(gate), _p(dpooled), float(add_scale), n_img, c, _p(part), _st())
+    return part
+
+
+def bnact_bwd(x, n_img, hw, c, stats, gamma, act, g=None, mul=None, add=None, rowscale=None, add_scale=1.0,
+              partials=None):
+    """Backward through y = act(BN_train(x)) (* rowscale).  Returns (dx bf16, dgamma, dbeta).
+    partials: precomputed [rows, 2, c] reduction (skips the reduce pass over the big tensors)."""
     a = _bnact(x, n_img, hw, c, stats.scale, stats.shift, act)
     a.g, a.mul, a.add, a.rowscale = _p(g), _p(mul), _p(add), _p(rowscale)
     a.add_scale = add_scale
     a.mean, a.invstd = _p(stats.mean), _p(stats.invstd)
-    rows = L.load().mc_bnact_rows(C.byref(a))
-    part = empty((rows, 2, c), torch.float32, x)
-    a.partials = _p(part)
-    _note(2 * n_img * hw * c * (2 if g is not None else 1))
-    L.call("mc_bnact_bwd_reduce", C.byref(a), _st())
+    if partials is not None:
+        part, rows = partials, partials.shape[0]
+    else:
+        rows = L.load().mc_bnact_rows(C.byref(a))
+        part = empty((rows, 2, c), torch.float32, x)
+        a.partials = _p(part)
+        _note(2 * n_img * hw * c * (2 if g is not None else 1))
+        L.call("mc_bnact_bwd_reduce", C.byref(a), _st())
     buf = empty((5, c), torch.float32, x)        # dgamma, dbeta, coefA, coefB, coefC
     L.call("mc_bn_bwd_finalize", _p(part), rows, c, float(n_img * hw), _p(gamma), _p(stats.mean), _p(stats.invstd),
            _p(buf[0]), _p(buf[1]), _p(buf[2]), _st())

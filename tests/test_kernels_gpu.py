@@ -310,6 +310,14 @@ def test_bn_train_fwd_bwd(n_img, hw, c):
     check(dbeta, br.grad, 2e-3, "bn bwd dbeta")
     dgate = ops.bnact_se_dgate(x, g, n_img, hw, c, st.scale, st.shift, 1)
     check(dgate, (g.float() * F.silu(z.detach())).view(n_img, hw, c).sum(1), 1e-4, "se dgate")
+    # fused SE sums: same dgate, and BN-backward partials without a second pass
+    sums = ops.bnact_se_sums(x, g, n_img, hw, c, st, 1)
+    check(sums[0], dgate, 1e-5, "se sums dgate")
+    part = ops.bn_partials_from_se_sums(sums, mul, add, 1.0)
+    dx2, dgamma2, dbeta2 = ops.bnact_bwd(x, n_img, hw, c, st, gamma, 1, g=g, mul=mul, add=add, partials=part)
+    check(dgamma2, gr.grad, 2e-3, "bn bwd dgamma (from se sums)")
+    check(dbeta2, br.grad, 2e-3, "bn bwd dbeta (from se sums)")
+    check(dx2, xr.grad, 1.5e-2, "bn bwd dx (from se sums)")
 
 
 def test_bn_bwd_plain_rowscale_and_broadcast():
