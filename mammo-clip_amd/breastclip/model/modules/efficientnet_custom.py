@@ -258,7 +258,7 @@ class _HeadFn(torch.autograd.Function):
         mod = ctx.mod
         de, dgamma, dbeta = ops.bnact_bwd(e, n, h * wd, cout, ctx.st, mod._bn1.weight, 1, add=dpooled.contiguous(),
                                           add_scale=1.0 / (h * wd))
-        dx = ops.linear_dgrad(de, wb)
+        dx = ops.linear_dgrad(de, wb, w_t=ops.cast_transpose_bf16(mod._conv_head.weight.view(cout, cin)))
         dw = ops.linear_wgrad(de, x)
         return dx, dw.view(cout, cin, 1, 1), dgamma, dbeta, None, None, None, None
 

@@ -107,20 +107,20 @@ class _LayerFn(torch.autograd.Function):
         hg = ops.gelu_fwd(sv["h1"])                                  # recomputed
         g["output.dense.weight"] = ops.linear_wgrad(do, hg)
         g["output.dense.bias"] = ops.colsum(do)
-        dhg = ops.linear_dgrad(do, sv["w2"])
+        dhg = ops.linear_dgrad(do, sv["w2"], w_t=ops.cast_transpose_bf16(lyr.output.dense.weight))
         del hg, do
         dh1 = ops.gelu_bwd(dhg, sv["h1"])
         del dhg
         g["intermediate.dense.weight"] = ops.linear_wgrad(dh1, a)
         g["intermediate.dense.bias"] = ops.colsum(dh1)
-        da = ops.linear_dgrad(dh1, sv["wi"], residual=da_res)
+        da = ops.linear_dgrad(dh1, sv["wi"], residual=da_res, w_t=ops.cast_transpose_bf16(lyr.intermediate.dense.weight))
         del dh1, da_res
         # a = LN1(dropout(ao) + x)
         dao, dx_res, g["attention.output.LayerNorm.weight"], g["attention.output.LayerNorm.bias"] = ops.add_ln_bwd(
             da, sv["ao"], x, att.output.LayerNorm.weight, sv["ln1"][0], sv["ln1"][1], ph, seed, sid + 1)
         g["attention.output.dense.weight"] = ops.linear_wgrad(dao, sv["ctxv"])
         g["attention.output.dense.bias"] = ops.colsum(dao)
-        dctx = ops.linear_dgrad(dao, sv["wo"])
+        dctx = ops.linear_dgrad(dao, sv["wo"], w_t=ops.cast_transpose_bf16(att.output.dense.weight))
         del dao
         # attention core
         dpd = torch.empty((b, nh, t, t), dtype=torch.float32, device=x.device)
@@ -138,7 +138,10 @@ class _LayerFn(torch.autograd.Function):
         del ds
         dwqkv = ops.linear_wgrad(dqkv, x)
         dbqkv = ops.colsum(dqkv)
-        dx = ops.linear_dgrad(dqkv, sv["wqkv"], residual=dx_res)
+        wqkv_t = torch.empty((H, 3 * H), dtype=torch.bfloat16, device=x.device)      # [in, 3*out] = wqkv^T
+        for i, m_ in enumerate((att.self.query, att.self.key, att.self.value)):
+            wqkv_t[:, i * H:(i + 1) * H].copy_(ops.cast_transpose_bf16(m_.weight))
+        dx = ops.linear_dgrad(dqkv, sv["wqkv"], residual=dx_res, w_t=wqkv_t)
         for i, nm in enumerate(("query", "key", "value")):
             g[f"attention.self.{nm}.weight"] = dwqkv[i * H:(i + 1) * H]
             g[f"attention.self.{nm}.bias"] = dbqkv[i * H:(i + 1) * H]

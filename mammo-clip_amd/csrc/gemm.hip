@@ -42,6 +42,22 @@ __device__ __forceinline__ uint4 apply_prologue(uint4 v, const mc_gemm_args& p, 
     return pack8(f);
 }
 
+// k-major operands (reduction index = row of the stored matrix) stay ROW-MAJOR in LDS ([k][x], 16-byte stores) and
+// are turned into MFMA fragments by gfx950's LDS transpose-read: within a 16-lane group lane i supplies the address
+// of row i/4, cols (i%4)*4..+3 of a 4x16 block and lane c receives column c, rows 0..3 (verified on hardware).
+typedef __attribute__((ext_vector_type(4))) short s4_t;
+typedef __attribute__((address_space(3))) s4_t lds_s4_t;
+__device__ __forceinline__ bf16x8_t tr_frag(const unsigned char* tile, int rs, int row0, int col0, int lane) {
+    const int g = lane >> 4, i = lane & 15;
+    const unsigned char* a = tile + (size_t)(row0 + g * 8 + (i >> 2)) * rs + (col0 + (i & 3) * 4) * 2;
+    s4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_t*)(a));
+    s4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_t*)(a + 4 * rs));
+    typedef __attribute__((ext_vector_type(8))) short s8_t;
+    s8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8_t, v);
+}
+constexpr int tr_pad_bytes(int bx) { return bx >= 128 ? 48 : (bx >= 64 ? 16 : 32); }   // conflict-free tr-read strides
+
 template <int BM, int BN, int BK, int WGM, int WGN, int LAY, int PRO, bool CF32>
 __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8) ? 4 : 2) void gemm_kernel(const mc_gemm_args p) {
     // 8-wave tiles are held to <= 128 VGPRs so two workgroups (16 waves) fit a CU
@@ -51,10 +67,13 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8) ? 4 : 2) void gemm
     constexpr int WM = BM / WGM, WN = BN / WGN;
     constexpr int FM = WM / 16, FN = WN / 16;
     constexpr int KCH = BK / 8;                       // 16-byte chunks per row (k-contiguous operands)
-    constexpr int KP = BK / 2;                        // k pairs per tile (k-major operands)
-    constexpr int A_REGS = AKM ? 2 * ((KP * (BM / 8) + (NT - 1)) / NT) : (BM * KCH + (NT - 1)) / NT;
-    constexpr int B_REGS = BKM ? 2 * ((KP * (BN / 8) + (NT - 1)) / NT) : (BN * KCH + (NT - 1)) / NT;
-    constexpr int STAGE_BYTES = (BM + BN) * ROWB;
+    constexpr int RSA = BM * 2 + tr_pad_bytes(BM);    // row strides of the row-major [k][x] tiles of k-major operands
+    constexpr int RSB = BN * 2 + tr_pad_bytes(BN);
+    constexpr int A_REGS = AKM ? (BK * (BM / 8) + (NT - 1)) / NT : (BM * KCH + (NT - 1)) / NT;
+    constexpr int B_REGS = BKM ? (BK * (BN / 8) + (NT - 1)) / NT : (BN * KCH + (NT - 1)) / NT;
+    constexpr int A_BYTES = AKM ? BK * RSA : BM * ROWB;
+    constexpr int B_BYTES = BKM ? BK * RSB : BN * ROWB;
+    constexpr int STAGE_BYTES = A_BYTES + B_BYTES + 64;
     constexpr int CROW = (BN + 8) * 2;                // epilogue tile row bytes (bf16)
     constexpr int EPI_BYTES = CF32 ? 0 : BM * CROW;
     constexpr int LDS_BYTES = (2 * STAGE_BYTES > EPI_BYTES) ? 2 * STAGE_BYTES : EPI_BYTES;
@@ -106,16 +125,13 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8) ? 4 : 2) void gemm
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < A_REGS / 2; ++i) {
+            for (int i = 0; i < A_REGS; ++i) {
                 int c = tid + i * NT;
-                int xc = c % (BM / 8), kp = c / (BM / 8);
-                long long m = m0 + xc * 8, k = k0 + 2 * kp;
-                uint4 v0 = zero4(), v1 = zero4();
-                if (c < KP * (BM / 8) && m < p.M) {
-                    if (k < kend) v0 = *reinterpret_cast<const uint4*>(A + k * p.lda + m);
-                    if (k + 1 < kend) v1 = *reinterpret_cast<const uint4*>(A + (k + 1) * p.lda + m);
-                }
-                ra[2 * i] = v0; ra[2 * i + 1] = v1;
+                int xc = c % (BM / 8), kr = c / (BM / 8);
+                long long m = m0 + xc * 8, k = k0 + kr;
+                uint4 v = zero4();
+                if (c < BK * (BM / 8) && m < p.M && k < kend) v = *reinterpret_cast<const uint4*>(A + k * p.lda + m);
+                ra[i] = v;
             }
         }
         if (!BKM) {
@@ -133,27 +149,23 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8) ? 4 : 2) void gemm
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < B_REGS / 2; ++i) {
+            for (int i = 0; i < B_REGS; ++i) {
                 int c = tid + i * NT;
-                int xc = c % (BN / 8), kp = c / (BN / 8);
-                long long n = n0 + xc * 8, k = k0 + 2 * kp;
-                uint4 v0 = zero4(), v1 = zero4();
-                if (c < KP * (BN / 8) && n < p.N) {
-                    if (k < kend) v0 = *reinterpret_cast<const uint4*>(B + k * p.ldb + n);
-                    if (k + 1 < kend) v1 = *reinterpret_cast<const uint4*>(B + (k + 1) * p.ldb + n);
-                }
-                rb[2 * i] = v0; rb[2 * i + 1] = v1;
+                int xc = c % (BN / 8), kr = c / (BN / 8);
+                long long n = n0 + xc * 8, k = k0 + kr;
+                uint4 v = zero4();
+                if (c < BK * (BN / 8) && n < p.N && k < kend) v = *reinterpret_cast<const uint4*>(B + k * p.ldb + n);
+                rb[i] = v;
             }
         }
     };
 
     // ---- registers -> LDS (the fused BN+SiLU(+gate) prologue is applied here, after the loads have landed).
-    // k-major operands are transposed on the way in: a thread holds rows k, k+1 for 8 consecutive x and writes
-    // 8 dwords {x_j: (k, k+1)}.  The 16-byte slot inside the row is XOR-swizzled with (x >> 3) & 7 so the
-    // 32-lane write groups do not pile onto one bank; the fragment reader applies the same XOR.
+    // k-contiguous operands: [x][BK] rows (padded), read with ds_read_b128.  k-major operands: [BK][x] rows exactly
+    // as loaded (16-byte stores), read with the transpose-read.
     auto store_tiles = [&](const uint4 (&ra)[A_REGS], const uint4 (&rb)[B_REGS], int buf, long long m0, long long k0) {
         unsigned char* sA = smem + buf * STAGE_BYTES;
-        unsigned char* sB = sA + BM * ROWB;
+        unsigned char* sB = sA + A_BYTES;
         if (!AKM) {
 #pragma unroll
             for (int i = 0; i < A_REGS; ++i) {
@@ -170,20 +182,11 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8) ? 4 : 2) void gemm
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < A_REGS / 2; ++i) {
+            for (int i = 0; i < A_REGS; ++i) {
                 int c = tid + i * NT;
-                if (c < KP * (BM / 8)) {
-                    int xc = c % (BM / 8), kp = c / (BM / 8);
-                    const uint32_t* w0 = reinterpret_cast<const uint32_t*>(&ra[2 * i]);
-                    const uint32_t* w1 = reinterpret_cast<const uint32_t*>(&ra[2 * i + 1]);
-                    int slot = ((kp >> 2) ^ (xc & 7)) & (KCH - 1);
-                    int boff = slot * 16 + (kp & 3) * 4;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        uint32_t a = w0[j >> 1], b = w1[j >> 1];
-                        uint32_t d = (j & 1) ? ((a >> 16) | (b & 0xffff0000u)) : ((a & 0xffffu) | (b << 16));
-                        *reinterpret_cast<uint32_t*>(sA + (xc * 8 + j) * ROWB + boff) = d;
-                    }
+                if (c < BK * (BM / 8)) {
+                    int xc = c % (BM / 8), kr = c / (BM / 8);
+                    *reinterpret_cast<uint4*>(sA + kr * RSA + xc * 16) = ra[i];
                 }
             }
         }
@@ -198,28 +201,16 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8) ? 4 : 2) void gemm
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < B_REGS / 2; ++i) {
+            for (int i = 0; i < B_REGS; ++i) {
                 int c = tid + i * NT;
-                if (c < KP * (BN / 8)) {
-                    int xc = c % (BN / 8), kp = c / (BN / 8);
-                    uint4 v0 = rb[2 * i], v1 = rb[2 * i + 1];
+                if (c < BK * (BN / 8)) {
+                    int xc = c % (BN / 8), kr = c / (BN / 8);
+                    uint4 v = rb[i];
                     if (PRO == 2) {
-                        long long n = n0 + xc * 8, k = k0 + 2 * kp;
-                        if (n < p.N) {
-                            if (k < kend) v0 = apply_prologue(v0, p, k, (int)n);
-                            if (k + 1 < kend) v1 = apply_prologue(v1, p, k + 1, (int)n);
-                        }
+                        long long n = n0 + xc * 8, k = k0 + kr;
+                        if (n < p.N && k < kend) v = apply_prologue(v, p, k, (int)n);
                     }
-                    const uint32_t* w0 = reinterpret_cast<const uint32_t*>(&v0);
-                    const uint32_t* w1 = reinterpret_cast<const uint32_t*>(&v1);
-                    int slot = ((kp >> 2) ^ (xc & 7)) & (KCH - 1);
-                    int boff = slot * 16 + (kp & 3) * 4;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        uint32_t a = w0[j >> 1], b = w1[j >> 1];
-                        uint32_t d = (j & 1) ? ((a >> 16) | (b & 0xffff0000u)) : ((a & 0xffffu) | (b << 16));
-                        *reinterpret_cast<uint32_t*>(sB + (xc * 8 + j) * ROWB + boff) = d;
-                    }
+                    *reinterpret_cast<uint4*>(sB + kr * RSB + xc * 16) = v;
                 }
             }
         }
@@ -231,22 +222,20 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8) ? 4 : 2) void gemm
     // output COLUMNS of one output row: 8-byte LDS / 16-byte global stores in the epilogue instead of scalars.
     auto compute = [&](int buf) {
         const unsigned char* sA = smem + buf * STAGE_BYTES;
-        const unsigned char* sB = sA + BM * ROWB;
+        const unsigned char* sB = sA + A_BYTES;
 #pragma unroll
         for (int kk = 0; kk < BK / 32; ++kk) {
             bf16x8_t af[FM], bfr[FN];
             const int slot = kk * 4 + (lane >> 4);
 #pragma unroll
             for (int i = 0; i < FM; ++i) {
-                int row = wm * WM + i * 16 + (lane & 15);
-                int s = AKM ? ((slot ^ ((row >> 3) & 7)) & (KCH - 1)) : slot;
-                af[i] = *reinterpret_cast<const bf16x8_t*>(sA + row * ROWB + s * 16);
+                if (AKM) af[i] = tr_frag(sA, RSA, kk * 32, wm * WM + i * 16, lane);
+                else af[i] = *reinterpret_cast<const bf16x8_t*>(sA + (wm * WM + i * 16 + (lane & 15)) * ROWB + slot * 16);
             }
 #pragma unroll
             for (int j = 0; j < FN; ++j) {
-                int row = wn * WN + j * 16 + (lane & 15);
-                int s = BKM ? ((slot ^ ((row >> 3) & 7)) & (KCH - 1)) : slot;
-                bfr[j] = *reinterpret_cast<const bf16x8_t*>(sB + row * ROWB + s * 16);
+                if (BKM) bfr[j] = tr_frag(sB, RSB, kk * 32, wn * WN + j * 16, lane);
+                else bfr[j] = *reinterpret_cast<const bf16x8_t*>(sB + (wn * WN + j * 16 + (lane & 15)) * ROWB + slot * 16);
             }
 #pragma unroll
             for (int i = 0; i < FM; ++i)

@@ -128,6 +128,10 @@ def linear_dgrad(dy, w, residual=None, w_t=None):
     if w_t is not None and _rows_ok(M, K, N, None, 0):
         gemm_rows(dy, w_t, dx, residual=residual, kind="dgrad_rows")
         return dx
+    if w_t is not None:       # NT form through the transposed weight: both operands k-contiguous (16-byte LDS stores)
+        gemm(dy, w_t, dx, M, K, N, dy.stride(0), w_t.stride(0), dx.stride(0), R=residual,
+             ldr=(residual.stride(0) if residual is not None else 0), kind="dgrad")
+        return dx
     gemm(dy, w, dx, M, K, N, dy.stride(0), w.stride(0), dx.stride(0), b_kmajor=1, R=residual,
          ldr=(residual.stride(0) if residual is not None else 0), kind="dgrad")
     return dx
