@@ -1,13 +1,14 @@
 // Depthwise k x k convolution (k in {3,5}, stride in {1,2}) for NHWC bf16, gfx950.
 // [ref: efficientnet_custom.py:109-111  _depthwise_conv (+ static ZeroPad2d, efficient_net_custom_utils.py:248-276)]
 //
-// HBM-bound stencil: a workgroup stages a (TOH*S+K-1) x (TOW*S+K-1) x 64-channel input halo tile in LDS with
-// coalesced 16-byte loads (the BatchNorm+SiLU of the producing expand conv is applied once per element while
-// staging, zero padding is inserted after the activation), then every thread computes a strip of R output
-// pixels for one 8-channel vector with a sliding window out of LDS.  Workgroups are persistent over spatial
-// tiles so the per-channel sum / sum-of-squares for the following training-mode BatchNorm leave the kernel
-// as a small [workgroups][2][C] partial buffer (deterministic, no atomics).
+// Forward (and stride-1 data gradient, = forward with flipped taps): "marching" kernel below - column strips walked
+// top to bottom with the partial output rows held in registers.  Weight gradient: 2-D halo tiles staged in LDS with
+// coalesced 16-byte loads (the BatchNorm+SiLU of the producing expand conv is applied once per element while staging,
+// zero padding is inserted after the activation).  Both are persistent over their work items so the per-channel
+// sum / sum-of-squares for the following training-mode BatchNorm leave the kernel as a small [workgroups][2][C]
+// partial buffer (deterministic, no atomics).
 #include "common.cuh"
+#include <type_traits>
 #include "../../include/mammoclip_hip.h"
 
 namespace {
@@ -76,129 +77,6 @@ __device__ __forceinline__ void store_halo(unsigned char* tile, const Halo<K, S>
                 val = pack8(f);
             }
             *reinterpret_cast<uint4*>(tile + v * PIXB + cv * 16) = val;
-        }
-    }
-}
-
-template <int K, int S>
-__device__ __forceinline__ void stage_input(const mc_dwconv_args& p, unsigned char* tile, long long img, int oy0,
-                                            int ox0, int c0, const float* ps, const float* pt, bool has_pro) {
-    Halo<K, S> hl;
-    load_halo<K, S>(p, hl, img, oy0, ox0, c0);
-    store_halo<K, S>(tile, hl, ps, pt, has_pro);
-}
-
-template <int K, int S>
-__global__ __launch_bounds__(256) void dwconv_fwd_kernel(const mc_dwconv_args p, int tiles_h, int tiles_w) {
-    using C = DwCfg<K, S>;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* tile = smem;
-    float* wl = reinterpret_cast<float*>(smem + C::TILE_BYTES);       // [K*K][TC]
-    const int tid = threadIdx.x;
-    const int cv = tid & 7;
-    const int c0 = blockIdx.x * TC;
-    const int c = c0 + cv * 8;
-    const bool cvalid = c < p.c;
-    const bool has_pro = p.pro_scale != nullptr;
-
-    for (int i = tid; i < K * K * TC; i += 256) {
-        int tap = i / TC, ch = i % TC;
-        wl[i] = (c0 + ch < p.c) ? p.w_kkc[(long long)tap * p.c + c0 + ch] : 0.f;
-    }
-    float ps[8], pt[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) { ps[q] = 1.f; pt[q] = 0.f; }
-    if (has_pro && cvalid) { load8f(p.pro_scale + c, ps); load8f(p.pro_shift + c, pt); }
-
-    float ssum[8], ssq[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) { ssum[q] = 0.f; ssq[q] = 0.f; }
-
-    const long long ntiles = (long long)p.n * tiles_h * tiles_w;
-    auto tile_pos = [&](long long t, long long& img, int& oy0, int& ox0) {
-        ox0 = (int)(t % tiles_w) * TOW;
-        oy0 = (int)((t / tiles_w) % tiles_h) * C::TOH;
-        img = t / ((long long)tiles_w * tiles_h);
-    };
-    Halo<K, S> hl;
-    long long t = blockIdx.y;
-    {
-        long long img; int oy0, ox0;
-        if (t < ntiles) { tile_pos(t, img, oy0, ox0); load_halo<K, S>(p, hl, img, oy0, ox0, c0); }
-    }
-    for (; t < ntiles; t += gridDim.y) {
-        long long img; int oy0, ox0;
-        tile_pos(t, img, oy0, ox0);
-        __syncthreads();                       // previous tile fully consumed (also orders the weight staging)
-        store_halo<K, S>(tile, hl, ps, pt, has_pro);
-        __syncthreads();
-        if (t + gridDim.y < ntiles) {          // prefetch the next tile while this one computes
-            long long img2; int oy2, ox2;
-            tile_pos(t + gridDim.y, img2, oy2, ox2);
-            load_halo<K, S>(p, hl, img2, oy2, ox2, c0);
-        }
-#pragma unroll 1
-        for (int pass = 0; pass < C::PASSES; ++pass) {
-            const int item = tid + pass * 256;
-            const int strip = (item >> 3) % C::NSTRIP;
-            const int orow = item / (8 * C::NSTRIP);
-            float acc[C::R][8];
-#pragma unroll
-            for (int r = 0; r < C::R; ++r)
-#pragma unroll
-                for (int q = 0; q < 8; ++q) acc[r][q] = 0.f;
-#pragma unroll 1
-            for (int kh = 0; kh < K; ++kh) {          // k = 5: keep one filter row live at a time (VGPR budget)
-                float in[C::NIN][8];
-                const unsigned char* rowp = tile + ((orow * S + kh) * C::IW_T + strip * C::R * S) * PIXB + cv * 16;
-#pragma unroll
-                for (int i = 0; i < C::NIN; ++i) unpack8(*reinterpret_cast<const uint4*>(rowp + i * PIXB), in[i]);
-#pragma unroll
-                for (int kw = 0; kw < K; ++kw) {
-                    float wv[8];
-                    load8f(wl + (kh * K + kw) * TC + cv * 8, wv);
-#pragma unroll
-                    for (int r = 0; r < C::R; ++r)
-#pragma unroll
-                        for (int q = 0; q < 8; ++q) acc[r][q] = fmaf(in[r * S + kw][q], wv[q], acc[r][q]);
-                }
-            }
-            const int oy = oy0 + orow;
-            if (cvalid && oy < p.oh) {
-                bf16_t* yrow = reinterpret_cast<bf16_t*>(p.out) + ((img * p.oh + oy) * (long long)p.ow) * p.c + c;
-#pragma unroll
-                for (int r = 0; r < C::R; ++r) {
-                    int ox = ox0 + strip * C::R + r;
-                    if (ox < p.ow) {
-                        uint4 o = pack8(acc[r]);
-                        *reinterpret_cast<uint4*>(yrow + (long long)ox * p.c) = o;
-                        if (p.stat_partials) {
-                            float f[8];
-                            unpack8(o, f);          // statistics of the stored (bf16-rounded) tensor
-#pragma unroll
-                            for (int q = 0; q < 8; ++q) { ssum[q] += f[q]; ssq[q] += f[q] * f[q]; }
-                        }
-                    }
-                }
-            }
-        }
-    }
-
-    if (p.stat_partials) {
-        __syncthreads();
-        float* red = reinterpret_cast<float*>(smem);      // [32 groups][8 cv][16]
-        const int grp = tid >> 3;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            red[(grp * 8 + cv) * 16 + q] = ssum[q];
-            red[(grp * 8 + cv) * 16 + 8 + q] = ssq[q];
-        }
-        __syncthreads();
-        if (tid < 128) {
-            int ch = tid & 63, which = tid >> 6;          // 0 = sum, 1 = sumsq
-            float s = 0.f;
-            for (int g = 0; g < 32; ++g) s += red[(g * 8 + (ch >> 3)) * 16 + which * 8 + (ch & 7)];
-            if (c0 + ch < p.c) p.stat_partials[((long long)blockIdx.y * 2 + which) * p.c + c0 + ch] = s;
         }
     }
 }
@@ -338,6 +216,361 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const mc_dwconv_
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// "Marching" forward kernel.  A lane owns CPL (2 or 4) channels of NCOL adjacent output columns and walks down
+// the rows of its segment: every staged input row is read from LDS once per lane (NIN reads of 4*CPL/2 bytes; the
+// 64 lanes of a wave cover PXW pixels x LP lanes = contiguous LDS), unpacked once, and scattered with packed fp32
+// FMAs (v_pk_fma_f32, two channels per instruction) into the A = ceil(K/S) output rows it touches; the filter taps
+// of the lane's channels live in registers.  Rows are staged in blocks of RB = NR*A*S input rows so the
+// accumulator rotation is static.  Compared with a 2-D halo tile this removes the vertical halo (each input row is
+// loaded and BN+SiLU-activated once per column strip), all LDS weight reads, and most LDS activation reads and
+// bf16->fp32 unpacks.  All per-thread staging geometry (global offset, LDS offset, row, column) is constant for
+// the whole kernel and kept in registers, so a staged block costs a handful of instructions per 16-byte vector.
+constexpr int pmod_c(int a, int m) { return ((a % m) + m) % m; }
+constexpr int fdiv_c(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
+
+template <int K, int S, int CPL, int LP, int NCOL_ = 2> struct MarchCfg {
+    static constexpr int H2 = CPL / 2;                     // packed fp32 pairs per lane
+    static constexpr int PXW = 64 / LP;                    // pixels per wave (LP = lanes per pixel)
+    static constexpr int NCOL = NCOL_;                     // adjacent output columns per lane
+    static constexpr int NS = NCOL * S;                    // input-pixel distance between neighbouring lanes' bases
+    static constexpr int TOW = 4 * PXW * NCOL;             // output columns per strip (4 waves)
+    static constexpr int A = (K + S - 1) / S;              // output rows in flight per lane
+    static constexpr int P = A * S;                        // input rows per accumulator rotation period
+    static constexpr int IW_T = (TOW - 1) * S + K;         // staged input columns
+    static constexpr int NIN = (NCOL - 1) * S + K;         // input pixels a lane reads per row
+    static constexpr int TCH = LP * CPL;                   // channels per tile
+    static constexpr int PXB = TCH * 2;                    // bytes per staged pixel
+    static constexpr int VPP = PXB / 16;                   // 16-byte vectors per staged pixel
+    // LDS conflict avoidance.  8-byte reads, 128-byte pixels: the two pixels of a half-wave are NS pixels apart and
+    // would share banks, so pixel p is stored at position p ^ ((p >> log2(NS)) & 1) (dense, no padding).  4-byte
+    // reads, 64-byte pixels: pad the pixel stride so the 4 pixels of a wave land in 4 different 16-bank groups.
+    static constexpr bool SWZ = (CPL == 4 && LP == 16);
+    static constexpr int SWZ_BIT = (NS == 2) ? 1 : 2;
+    static constexpr int PSB = (CPL == 2 && LP == 16) ? (NS == 2 ? 96 : 80) : (CPL == 2 && LP == 32) ? (NS == 4 ? 160 : 144) : PXB;
+    static constexpr int IWP = SWZ ? (IW_T + (2 << SWZ_BIT) - 1) / (2 << SWZ_BIT) * (2 << SWZ_BIT) : IW_T;
+    static constexpr int NR_ = (24576 + P * IW_T * PXB / 2) / (P * IW_T * PXB);
+    static constexpr int NR = NR_ < 1 ? 1 : NR_;           // periods per staged block (~24 KB of loads in flight)
+    static constexpr int RB = P * NR;                      // input rows per staged block
+    static constexpr int TS = 256 - 256 % VPP;             // staging threads (vector index within a pixel fixed per thread)
+    static constexpr int NV = (RB * IW_T * VPP + TS - 1) / TS;
+    static constexpr int BUF_BYTES = RB * IWP * PSB;
+    static constexpr int OCC = (K == 3 && S == 1) ? 3 : 2;           // workgroups per CU the register budget is set for
+};
+
+#ifdef MARCH_PROF
+__device__ unsigned long long g_march_prof[8];     // developer phase profile (scripts/dwbench.hip)
+#define MPROF(i) do { unsigned long long t_ = __builtin_amdgcn_s_memtime(); pacc[i] += t_ - tprof; tprof = t_; } while (0)
+#else
+#define MPROF(i)
+#endif
+
+template <int K, int S, int CPL, int LP, int NCOL>
+__global__ __launch_bounds__(256, (K == 3 && S == 1 ? 3 : 2)) void dwconv_march_fwd_kernel(const mc_dwconv_args p, int strips, int segs,
+                                                                                int seg_rows, int ctiles, int gy) {
+    using C = MarchCfg<K, S, CPL, LP, NCOL>;
+    typedef typename std::conditional<CPL == 4, uint2, uint32_t>::type ldsv_t;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[C::BUF_BYTES > 8192 ? C::BUF_BYTES : 8192];
+    __shared__ __attribute__((aligned(16))) float pro_lds[2][C::TCH];      // prologue scale / shift of the tile's channels
+    // XCD-aware decomposition: the channel tiles of one (image, strip, segment) share 128-byte lines, so they are
+    // given consecutive slots on the SAME XCD (workgroup id % 8) and meet in that XCD's L2.
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int ct = slot % ctiles, y = (slot / ctiles) * 8 + xcd;
+    if (y >= gy) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lq = lane % LP, px = lane / LP;
+    const bool lane_ok = px < C::PXW;
+    const int c0 = ct * C::TCH;
+    const int cl = c0 + lq * CPL;                          // the lane's first channel
+    const bool ch_ok = lane_ok && cl < p.c;
+    const int xl0 = (wave * C::PXW + (lane_ok ? px : 0)) * C::NCOL;     // tile-local first output column
+    const bool has_pro = p.pro_scale != nullptr;
+    // LDS read bases (see SWZ above): reads whose table offset is even use lb_p, odd ones lb_m
+    const int qb = C::SWZ ? ((xl0 * S) >> C::SWZ_BIT) & 1 : 0;
+    const int lbase = xl0 * S * C::PSB + lq * (CPL * 2);
+    const int lb_p = lbase + qb * C::PSB, lb_m = lbase - qb * C::PSB;
+
+    f32x2_t w[K * K][C::H2];
+#pragma unroll
+    for (int t = 0; t < K * K; ++t)
+#pragma unroll
+        for (int h = 0; h < C::H2; ++h) {
+            w[t][h] = f32x2_t{0.f, 0.f};
+            if (ch_ok) w[t][h] = *reinterpret_cast<const f32x2_t*>(p.w_kkc + (long long)t * p.c + cl + 2 * h);
+        }
+
+    // ---- per-thread staging geometry, constant for the whole kernel
+    const int vv = tid % C::VPP;
+    const int cs = c0 + vv * 8;
+    const bool st_ok = tid < C::TS && cs < p.c;
+    const long long in_row_pitch = (long long)p.w * p.c;   // elements
+    unsigned meta[C::NV];                                  // row | col << 8 | LDS byte offset << 16 (in 16-byte units)
+#pragma unroll
+    for (int i = 0; i < C::NV; ++i) {
+        const int v = tid + i * C::TS;
+        const int row = v / (C::IW_T * C::VPP), col = (v / C::VPP) % C::IW_T;
+        const int pos = C::SWZ ? (col ^ ((col >> C::SWZ_BIT) & 1)) : col;
+        meta[i] = (unsigned)row | ((unsigned)col << 8) | ((unsigned)(((row * C::IWP + pos) * C::PSB + vv * 16) >> 4) << 16);
+        if (v >= C::RB * C::IW_T * C::VPP) meta[i] = 0xffu;    // row 255: never valid
+    }
+    if (has_pro && tid < 2 * C::TCH) {
+        const int ch = tid % C::TCH;
+        const float* src = tid < C::TCH ? p.pro_scale : p.pro_shift;
+        pro_lds[tid / C::TCH][ch] = (c0 + ch < p.c) ? src[c0 + ch] : 0.f;
+    }
+
+    f32x2_t ssum[C::H2], ssq[C::H2];
+#pragma unroll
+    for (int h = 0; h < C::H2; ++h) { ssum[h] = f32x2_t{0.f, 0.f}; ssq[h] = f32x2_t{0.f, 0.f}; }
+    f32x2_t acc[C::NCOL][C::A][C::H2];
+    bf16_t* optr = nullptr;                                // lane's pixel in the next output row to complete
+    int o_next = 0;
+    unsigned col_ok = 0;                                   // bit i: the lane's i-th output column exists (and its channels do)
+    const long long row_pitch = (long long)p.ow * p.c;
+    const int pix_pitch = p.c;
+
+    const int nitems = p.n * strips * segs;
+    auto item_geom = [&](int it, int& img, int& ox0, int& oy0, int& nrows, int& nblk) {
+        const int strip = it % strips;
+        const int seg = (it / strips) % segs;
+        img = it / (strips * segs);
+        ox0 = strip * C::TOW;
+        oy0 = seg * seg_rows;
+        nrows = p.oh - oy0 < seg_rows ? p.oh - oy0 : seg_rows;
+        nblk = ((nrows - 1) * S + K + C::RB - 1) / C::RB;
+    };
+
+    uint4 vals[C::NV];
+    unsigned inb = 0;                                      // vectors of the staged block that hold real pixels
+    unsigned colmask = 0;                                  // per item: vectors whose column lies inside the image
+    // global -> registers for block b of item (img, ox0, oy0)
+    auto stage_load = [&](int img, int ox0, int oy0, int b, bool new_item) {
+        const int iy0 = oy0 * S - p.pad_t + b * C::RB, ix0 = ox0 * S - p.pad_l;
+        if (new_item) {
+            colmask = 0;
+#pragma unroll
+            for (int i = 0; i < C::NV; ++i) {
+                const int ix = ix0 + (int)((meta[i] >> 8) & 0xffu);
+                if (st_ok && ix >= 0 && ix < p.w) colmask |= 1u << i;
+            }
+        }
+        const bf16_t* org = p.x + ((long long)img * p.h + iy0) * in_row_pitch + (long long)ix0 * p.c + c0;
+        inb = 0;
+#pragma unroll
+        for (int i = 0; i < C::NV; ++i) {
+            // unconditional load (padding / out-of-tile vectors read a harmless valid address and are zeroed when
+            // stored): straight-line code keeps all loads of the block in flight together
+            const int iy = iy0 + (int)(meta[i] & 0xffu);
+            const bool ok = ((colmask >> i) & 1u) && iy >= 0 && iy < p.h;
+            const unsigned goff = (meta[i] & 0xffu) * (unsigned)in_row_pitch + ((meta[i] >> 8) & 0xffu) * (unsigned)p.c + vv * 8;
+            const bf16_t* a = ok ? org + goff : p.x;
+            vals[i] = *reinterpret_cast<const uint4*>(a);
+            inb |= (ok ? 1u : 0u) << i;
+        }
+    };
+    // registers -> LDS, with the fused BN+SiLU prologue on real pixels (zero padding stays zero)
+    auto stage_store = [&]() {
+        // explicit vmcnt(0): the uses below are conditional, and without an unconditional wait the compiler's waitcnt
+        // bookkeeping treats the prefetched registers as possibly-pending on later paths and drains the NEXT block's
+        // loads (vmcnt(0)) right before the compute loop, which serialises load latency with compute
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        float ps[8], pt[8];
+        if (has_pro) { load8f(&pro_lds[0][vv * 8], ps); load8f(&pro_lds[1][vv * 8], pt); }
+#pragma unroll
+        for (int i = 0; i < C::NV; ++i) {
+            if (tid < C::TS && (meta[i] & 0xffu) != 0xffu) {
+                const bool real = (inb >> i) & 1u;
+                uint4 val = real ? vals[i] : make_uint4(0u, 0u, 0u, 0u);
+                if (has_pro && real) {
+                    float f[8];
+                    unpack8(val, f);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) f[q] = silu_f(f[q] * ps[q] + pt[q]);
+                    val = pack8(f);
+                }
+                *reinterpret_cast<uint4*>(smem + ((meta[i] >> 16) << 4)) = val;
+            }
+        }
+    };
+
+    int it = y, img = 0;
+    int ox0 = 0, oy0 = 0, nrows = 0, nblk = 0, b = 0;
+    if (it >= nitems) return;                 // (never: gy <= nitems)
+    item_geom(it, img, ox0, oy0, nrows, nblk);
+    stage_load(img, ox0, oy0, 0, true);
+#ifdef MARCH_PROF
+    unsigned long long pacc[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long tprof = __builtin_amdgcn_s_memtime();
+#endif
+    while (true) {
+        __syncthreads();                       // previous block fully consumed
+        MPROF(0);
+        stage_store();
+        MPROF(1);
+        __syncthreads();
+        MPROF(2);
+        // prefetch the block after (it, b) while this one computes
+        int it2 = it, img2 = img;
+        int ox2 = ox0, oy2 = oy0, nrows2 = nrows, nblk2 = nblk, b2 = b + 1;
+        if (b2 >= nblk) {
+            it2 = it + gy; b2 = 0;
+            if (it2 < nitems) item_geom(it2, img2, ox2, oy2, nrows2, nblk2);
+        }
+        const bool more = it2 < nitems;
+        if (more) stage_load(img2, ox2, oy2, b2, b2 == 0);
+        MPROF(3);
+
+        if (b == 0) {                          // new item: clear the accumulators, aim the running output row pointer
+#pragma unroll
+            for (int i = 0; i < C::NCOL; ++i)
+#pragma unroll
+                for (int a = 0; a < C::A; ++a)
+#pragma unroll
+                    for (int h = 0; h < C::H2; ++h) acc[i][a][h] = f32x2_t{0.f, 0.f};
+            o_next = fdiv_c(-(K - 1), S);
+            optr = reinterpret_cast<bf16_t*>(p.out) + (((long long)img * p.oh + oy0 + o_next) * p.ow + ox0 + xl0) * p.c + cl;
+            col_ok = 0;
+#pragma unroll
+            for (int i = 0; i < C::NCOL; ++i) col_ok |= (ch_ok && ox0 + xl0 + i < p.ow ? 1u : 0u) << i;
+        }
+#pragma unroll 1
+        for (int sb = 0; sb < C::NR; ++sb) {
+            const unsigned char* lp_p = smem + lb_p + sb * (C::P * C::IWP * C::PSB);
+            const unsigned char* lp_m = smem + lb_m + sb * (C::P * C::IWP * C::PSB);
+#pragma unroll
+            for (int j = 0; j < C::P; ++j) {
+                f32x2_t in[C::NIN][C::H2];
+#pragma unroll
+                for (int i = 0; i < C::NIN; ++i) {
+                    const int t0 = C::SWZ ? (i ^ ((i >> C::SWZ_BIT) & 1)) : i;          // pixel position for qb == 0
+                    const unsigned char* a = ((t0 & 1) ? lp_m : lp_p) + (j * C::IWP + t0) * C::PSB;
+                    const ldsv_t v = *reinterpret_cast<const ldsv_t*>(a);
+                    if constexpr (CPL == 4) {
+                        in[i][0] = f32x2_t{bf_lo(v.x), bf_hi(v.x)};
+                        in[i][1] = f32x2_t{bf_lo(v.y), bf_hi(v.y)};
+                    } else {
+                        in[i][0] = f32x2_t{bf_lo(v), bf_hi(v)};
+                    }
+                }
+#pragma unroll
+                for (int kh = 0; kh < K; ++kh) {
+                    if (pmod_c(j - kh, S) != 0) continue;
+                    const int sl = pmod_c(fdiv_c(j - kh, S), C::A);
+#pragma unroll
+                    for (int kw = 0; kw < K; ++kw)
+#pragma unroll
+                        for (int i = 0; i < C::NCOL; ++i)
+#pragma unroll
+                            for (int h = 0; h < C::H2; ++h)
+                                acc[i][sl][h] = __builtin_elementwise_fma(w[kh * K + kw][h], in[i * S + kw][h], acc[i][sl][h]);
+                }
+                if (pmod_c(j - (K - 1), S) == 0) {             // output row o_next is complete
+                    const int sl = pmod_c(fdiv_c(j - (K - 1), S), C::A);
+                    if (o_next >= 0 && o_next < nrows) {
+#pragma unroll
+                        for (int i = 0; i < C::NCOL; ++i) {
+                            if ((col_ok >> i) & 1u) {
+                                uint32_t o2[C::H2];
+#pragma unroll
+                                for (int h = 0; h < C::H2; ++h) {
+                                    o2[h] = pack_bf2(acc[i][sl][h].x, acc[i][sl][h].y);
+                                    const f32x2_t r = {bf_lo(o2[h]), bf_hi(o2[h])};   // statistics of the stored (rounded) tensor
+                                    ssum[h] += r;
+                                    ssq[h] = __builtin_elementwise_fma(r, r, ssq[h]);
+                                }
+                                if constexpr (CPL == 4) *reinterpret_cast<uint2*>(optr + i * pix_pitch) = make_uint2(o2[0], o2[1]);
+                                else *reinterpret_cast<uint32_t*>(optr + i * pix_pitch) = o2[0];
+                            }
+                        }
+                    }
+                    ++o_next;
+                    optr += row_pitch;
+#pragma unroll
+                    for (int i = 0; i < C::NCOL; ++i)
+#pragma unroll
+                        for (int h = 0; h < C::H2; ++h) acc[i][sl][h] = f32x2_t{0.f, 0.f};
+                }
+            }
+        }
+        MPROF(4);
+#ifdef MARCH_PROF
+        pacc[5] += 1;
+#endif
+        if (!more) break;
+        it = it2; img = img2; ox0 = ox2; oy0 = oy2; nrows = nrows2; nblk = nblk2; b = b2;
+    }
+
+#ifdef MARCH_PROF
+    if (tid == 0)
+        for (int i = 0; i < 6; ++i) atomicAdd(&g_march_prof[i], pacc[i]);
+#endif
+    if (p.stat_partials) {
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem);          // [256 threads][2][CPL]
+#pragma unroll
+        for (int h = 0; h < C::H2; ++h) {
+            red[tid * 2 * CPL + 2 * h] = ssum[h].x; red[tid * 2 * CPL + 2 * h + 1] = ssum[h].y;
+            red[tid * 2 * CPL + CPL + 2 * h] = ssq[h].x; red[tid * 2 * CPL + CPL + 2 * h + 1] = ssq[h].y;
+        }
+        __syncthreads();
+        if (tid < 2 * C::TCH) {
+            const int ch = tid % C::TCH, which = tid / C::TCH;          // 0 = sum, 1 = sum of squares
+            float s = 0.f;
+            for (int wv = 0; wv < 4; ++wv)
+                for (int q = 0; q < C::PXW; ++q) s += red[(wv * 64 + q * LP + ch / CPL) * 2 * CPL + which * CPL + ch % CPL];
+            if (c0 + ch < p.c) p.stat_partials[((long long)y * 2 + which) * p.c + c0 + ch] = s;
+        }
+    }
+}
+
+struct MarchPlan { int strips, segs, seg_rows, ctiles, gy; };
+template <typename C> MarchPlan march_plan(const mc_dwconv_args& p) {
+    MarchPlan m;
+    m.strips = mc_div_up(p.ow, C::TOW);
+    m.ctiles = mc_div_up(p.c, C::TCH);
+    long long base = (long long)p.n * m.strips * m.ctiles;
+    int segs = (int)((3072 + base - 1) / base);
+    int max_segs = p.oh / 24 > 0 ? p.oh / 24 : 1;
+    if (segs > max_segs) segs = max_segs;
+    if (segs < 1) segs = 1;
+    m.seg_rows = mc_div_up(mc_div_up(p.oh, segs), C::A * C::NR) * (C::A * C::NR);
+    m.segs = mc_div_up(p.oh, m.seg_rows);
+    // persistent workgroups: as many as are resident at once, every one with the same item count
+    long long nitems = (long long)p.n * m.strips * m.segs;
+    long long cap = 256 * C::OCC / m.ctiles;
+    if (cap < 8) cap = 8;
+    long long per = (nitems + cap - 1) / cap;
+    m.gy = (int)((nitems + per - 1) / per);
+    return m;
+}
+
+// tile shape by kernel size and channel count: k = 3 runs 4 channels per lane (64 / 48 / 24-channel tiles),
+// k = 5 (25 taps per channel in registers) 2 channels per lane (32 / 24-channel tiles)
+template <int K, int S, typename F> auto march_dispatch(const mc_dwconv_args& p, F&& f) {
+    if constexpr (K == 3) {
+        if (p.c == 24) return f(MarchCfg<K, S, 4, 6>{});
+        if (p.c % 48 == 0 && p.c < 192) return f(MarchCfg<K, S, 4, 12>{});      // 48, 144: exact 48-channel tiles
+        return f(MarchCfg<K, S, 4, 16>{});
+    } else {
+        // 64-channel tiles (full 128-byte lines; 32-channel tiles measured 1.5x HBM over-fetch), 2 channels per lane
+        return f(MarchCfg<K, S, 2, 32, (S == 1 ? 4 : 2)>{});
+    }
+}
+template <int K, int S, typename C> int launch_march(const mc_dwconv_args& p, hipStream_t st) {
+    MarchPlan m = march_plan<C>(p);
+    int gy8 = (m.gy + 7) / 8 * 8;
+    hipLaunchKernelGGL((dwconv_march_fwd_kernel<K, S, C::H2 * 2, C::TCH / (C::H2 * 2), C::NCOL>), dim3(gy8 * m.ctiles), dim3(256), 0, st, p,
+                       m.strips, m.segs, m.seg_rows, m.ctiles, m.gy);
+    MC_LAUNCH_CHECK();
+    return MC_OK;
+}
+template <int K, int S> int launch_march_cp(const mc_dwconv_args& p, hipStream_t st) {
+    return march_dispatch<K, S>(p, [&](auto cfg) { return launch_march<K, S, decltype(cfg)>(p, st); });
+}
+template <int K, int S> int march_rows(const mc_dwconv_args& p) {
+    return march_dispatch<K, S>(p, [&](auto cfg) { return march_plan<decltype(cfg)>(p).gy; });
+}
+
 int check_common(const mc_dwconv_args& p) {
     MC_CHECK(p.x || p.dy, "dwconv: null input");
     MC_CHECK(p.out && p.n > 0 && p.h > 0 && p.w > 0 && p.c > 0, "dwconv: bad shape");
@@ -361,18 +594,6 @@ int grid_y_for(const mc_dwconv_args& p, long long ntiles) {
     return (int)(ntiles < want ? ntiles : want);
 }
 
-template <int K, int S> int launch_fwd(const mc_dwconv_args& p, hipStream_t st) {
-    using C = DwCfg<K, S>;
-    int th, tw;
-    tiles_of<K, S>(p, &th, &tw);
-    long long ntiles = (long long)p.n * th * tw;
-    dim3 grid(mc_div_up(p.c, TC), grid_y_for(p, ntiles));
-    size_t lds = C::TILE_BYTES + C::W_BYTES;
-    if (lds < 32 * 8 * 16 * 4) lds = 32 * 8 * 16 * 4;
-    hipLaunchKernelGGL((dwconv_fwd_kernel<K, S>), grid, dim3(256), lds, st, p, th, tw);
-    MC_LAUNCH_CHECK();
-    return MC_OK;
-}
 template <int K, int S> int launch_bww(const mc_dwconv_args& p, hipStream_t st) {
     using C = DwCfg<K, S>;
     int th, tw;
@@ -389,8 +610,8 @@ template <int K, int S> int launch_bww(const mc_dwconv_args& p, hipStream_t st) 
 }  // namespace
 
 extern "C" int mc_dwconv_stat_rows(const mc_dwconv_args* a) {
-    int th = mc_div_up(a->oh, a->stride == 1 ? 8 : 4), tw = mc_div_up(a->ow, TOW);
-    return grid_y_for(*a, (long long)a->n * th * tw);
+    if (a->k == 3) return a->stride == 1 ? march_rows<3, 1>(*a) : march_rows<3, 2>(*a);
+    return a->stride == 1 ? march_rows<5, 1>(*a) : march_rows<5, 2>(*a);
 }
 
 extern "C" int mc_dwconv_fwd(const mc_dwconv_args* a, void* stream) {
@@ -398,10 +619,10 @@ extern "C" int mc_dwconv_fwd(const mc_dwconv_args* a, void* stream) {
     if (int e = check_common(p)) return e;
     MC_CHECK(p.x && p.w_kkc, "dwconv_fwd: null x / w");
     hipStream_t st = (hipStream_t)stream;
-    if (p.k == 3 && p.stride == 1) return launch_fwd<3, 1>(p, st);
-    if (p.k == 3 && p.stride == 2) return launch_fwd<3, 2>(p, st);
-    if (p.k == 5 && p.stride == 1) return launch_fwd<5, 1>(p, st);
-    return launch_fwd<5, 2>(p, st);
+    if (p.k == 3 && p.stride == 1) return launch_march_cp<3, 1>(p, st);
+    if (p.k == 3 && p.stride == 2) return launch_march_cp<3, 2>(p, st);
+    if (p.k == 5 && p.stride == 1) return launch_march_cp<5, 1>(p, st);
+    return launch_march_cp<5, 2>(p, st);
 }
 
 extern "C" int mc_dwconv_bwd_data(const mc_dwconv_args* a, void* stream) {
