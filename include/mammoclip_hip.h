@@ -201,8 +201,13 @@ typedef struct mc_bnact_args {
     const float* coef;       /* bwd_apply: float[3][c] from mc_bn_bwd_finalize: dx = A*dz + B*x + C */
     mc_bf16* dx;
     float* dgate;            /* se_dgate: [n_img, c] = sum_hw g * act(z) */
+    /* pool / se_dgate / se_sums split the rows of an image over mc_bnact_img_splits() workgroups; when that is > 1
+     * they need float[splits * n_img * c] (se_sums: * 5) of scratch here and combine it in split order, so results are
+     * bit-reproducible run to run (no float atomics) */
+    float* split_ws;
 } mc_bnact_args;
 int mc_bnact_rows(const mc_bnact_args* args);
+int mc_bnact_img_splits(const mc_bnact_args* args);
 int mc_bnact_apply(const mc_bnact_args* args, void* stream);
 int mc_bnact_pool(const mc_bnact_args* args, void* stream);
 int mc_bnact_bwd_reduce(const mc_bnact_args* args, void* stream);

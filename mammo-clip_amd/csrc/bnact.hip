@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256) void bnact_img_reduce_k(const mc_bnact_args p)
                 float s = 0.f;
                 for (int r = 0; r < rm.rpb; ++r) s += red[(r * rm.cvp + rm.cl) * 8 + q];
                 if (gridDim.y == 1) dst[v * 8 + q] = s * post;
-                else atomicAdd(dst + v * 8 + q, s * post);
+                else p.split_ws[((long long)blockIdx.y * p.n_img + img) * p.c + v * 8 + q] = s * post;   // summed in fixed order
             }
         }
         __syncthreads();
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256) void bnact_se_sums_k(const mc_bnact_args p) {
                     float sm = 0.f;
                     for (int r = 0; r < rm.rpb; ++r) sm += red[(r * rm.cvp + rm.cl) * 8 + q];
                     if (gridDim.y == 1) dst[v * 8 + q] = sm;
-                    else atomicAdd(dst + v * 8 + q, sm);
+                    else p.split_ws[((long long)blockIdx.y * 5 + k) * plane + img * p.c + v * 8 + q] = sm;
                 }
             }
             __syncthreads();
@@ -519,6 +519,14 @@ extern "C" int mc_bnact_apply(const mc_bnact_args* a, void* stream) {
     MC_LAUNCH_CHECK();
     return MC_OK;
 }
+// out[i] = sum over splits of ws[split][i], in split order (deterministic, unlike float atomics)
+__global__ __launch_bounds__(256) void split_sum_k(const float* __restrict__ ws, float* __restrict__ out, long long n, int splits) {
+    long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int k = 0; k < splits; ++k) s += ws[(long long)k * n + i];
+    out[i] = s;
+}
 static int img_splits(const mc_bnact_args& p) {
     int cv = p.c / 8;
     int cvp = cv < 256 ? cv : 256;
@@ -530,17 +538,20 @@ static int img_splits(const mc_bnact_args& p) {
     if (s < 1) s = 1;
     return (int)s;
 }
+extern "C" int mc_bnact_img_splits(const mc_bnact_args* a) { return img_splits(*a); }
 extern "C" int mc_bnact_pool(const mc_bnact_args* a, void* stream) {
     const mc_bnact_args& p = *a;
     if (int e = check_bnact(p)) return e;
     MC_CHECK(p.pooled, "bnact_pool: null pooled");
     int sp = img_splits(p);
-    if (sp > 1) {
-        hipError_t e = hipMemsetAsync(p.pooled, 0, sizeof(float) * p.n_img * p.c, (hipStream_t)stream);
-        MC_CHECK(e == hipSuccess, "bnact_pool: memset failed");
-    }
+    MC_CHECK(sp == 1 || p.split_ws, "bnact_pool: split_ws needed (mc_bnact_img_splits() > 1)");
     hipLaunchKernelGGL((bnact_img_reduce_k<0>), dim3((unsigned)p.n_img, sp), dim3(256), 0, (hipStream_t)stream, p);
     MC_LAUNCH_CHECK();
+    if (sp > 1) {
+        long long n = p.n_img * p.c;
+        hipLaunchKernelGGL(split_sum_k, dim3(mc_div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, p.split_ws, p.pooled, n, sp);
+        MC_LAUNCH_CHECK();
+    }
     return MC_OK;
 }
 extern "C" int mc_bnact_se_dgate(const mc_bnact_args* a, void* stream) {
@@ -548,12 +559,14 @@ extern "C" int mc_bnact_se_dgate(const mc_bnact_args* a, void* stream) {
     if (int e = check_bnact(p)) return e;
     MC_CHECK(p.g && p.dgate, "bnact_se_dgate: null g/dgate");
     int sp = img_splits(p);
-    if (sp > 1) {
-        hipError_t e = hipMemsetAsync(p.dgate, 0, sizeof(float) * p.n_img * p.c, (hipStream_t)stream);
-        MC_CHECK(e == hipSuccess, "bnact_se_dgate: memset failed");
-    }
+    MC_CHECK(sp == 1 || p.split_ws, "bnact_se_dgate: split_ws needed (mc_bnact_img_splits() > 1)");
     hipLaunchKernelGGL((bnact_img_reduce_k<1>), dim3((unsigned)p.n_img, sp), dim3(256), 0, (hipStream_t)stream, p);
     MC_LAUNCH_CHECK();
+    if (sp > 1) {
+        long long n = p.n_img * p.c;
+        hipLaunchKernelGGL(split_sum_k, dim3(mc_div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, p.split_ws, p.dgate, n, sp);
+        MC_LAUNCH_CHECK();
+    }
     return MC_OK;
 }
 extern "C" int mc_bnact_se_sums(const mc_bnact_args* a, void* stream) {
@@ -561,12 +574,14 @@ extern "C" int mc_bnact_se_sums(const mc_bnact_args* a, void* stream) {
     if (int e = check_bnact(p)) return e;
     MC_CHECK(p.g && p.dgate && p.mean && p.invstd, "bnact_se_sums: null g / sums / mean / invstd");
     int sp = img_splits(p);
-    if (sp > 1) {
-        hipError_t e = hipMemsetAsync(p.dgate, 0, sizeof(float) * 5 * p.n_img * p.c, (hipStream_t)stream);
-        MC_CHECK(e == hipSuccess, "bnact_se_sums: memset failed");
-    }
+    MC_CHECK(sp == 1 || p.split_ws, "bnact_se_sums: split_ws needed (mc_bnact_img_splits() > 1)");
     hipLaunchKernelGGL(bnact_se_sums_k, dim3((unsigned)p.n_img, sp), dim3(256), 0, (hipStream_t)stream, p);
     MC_LAUNCH_CHECK();
+    if (sp > 1) {
+        long long n = 5 * p.n_img * p.c;
+        hipLaunchKernelGGL(split_sum_k, dim3(mc_div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, p.split_ws, p.dgate, n, sp);
+        MC_LAUNCH_CHECK();
+    }
     return MC_OK;
 }
 extern "C" int mc_bn_partials_from_se_sums(const float* sums, const float* gate, const float* dpooled, float add_scale,

@@ -523,6 +523,255 @@ __global__ __launch_bounds__(256, (K == 3 && S == 1 ? 3 : 2)) void dwconv_march_
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Marching weight-gradient kernel: same strip / staging structure as the forward kernel, but the registers hold the
+// K*K tap accumulators of the lane's channels instead of the taps, and the rotating A-deep register window holds the
+// unpacked dy rows (each dy row is read from LDS and unpacked once, then meets the K input rows it overlaps):
+//   dw[kh,kw,c] += dy[o, x, c] * x'[o*S + kh, x*S + kw, c]        (x' = BN+SiLU prologue applied while staging)
+// dy is staged through LDS beside x (position-major so a wave's reads are contiguous).  Accumulators run across all
+// items of the persistent workgroup; one LDS reduction + one atomic per (tap, channel) per workgroup at the end.
+template <int K, int S, int CPL, int LP, int NCOL>
+__global__ __launch_bounds__(256, 2) void dwconv_march_bww_kernel(const mc_dwconv_args p, int strips, int segs, int seg_rows,
+                                                                  int ctiles, int gy) {
+    using C = MarchCfg<K, S, CPL, LP, NCOL>;
+    typedef typename std::conditional<CPL == 4, uint2, uint32_t>::type ldsv_t;
+    constexpr int ORB = C::A * C::NR;                      // dy rows per staged block
+    constexpr int XQ = C::TOW / NCOL;                      // lane column groups per strip
+    constexpr int G_BYTES = ORB * C::TOW * C::PXB;
+    constexpr int NVG = (ORB * C::TOW * C::VPP + C::TS - 1) / C::TS;
+    constexpr int RED_BYTES = 256 * CPL * 4;
+    constexpr int SM_BYTES = (C::BUF_BYTES + G_BYTES > RED_BYTES) ? C::BUF_BYTES + G_BYTES : RED_BYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[SM_BYTES];
+    __shared__ __attribute__((aligned(16))) float pro_lds[2][C::TCH];
+    unsigned char* gsm = smem + C::BUF_BYTES;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int ct = slot % ctiles, y = (slot / ctiles) * 8 + xcd;
+    if (y >= gy) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lq = lane % LP, px = lane / LP;
+    const bool lane_ok = px < C::PXW;
+    const int c0 = ct * C::TCH;
+    const int cl = c0 + lq * CPL;
+    const int xq = wave * C::PXW + (lane_ok ? px : 0);
+    const int xl0 = xq * NCOL;
+    const bool has_pro = p.pro_scale != nullptr;
+    const int qb = C::SWZ ? ((xl0 * S) >> C::SWZ_BIT) & 1 : 0;
+    const int lbase = xl0 * S * C::PSB + lq * (CPL * 2);
+    const int lb_p = lbase + qb * C::PSB, lb_m = lbase - qb * C::PSB;
+    const int gbase = xq * C::PXB + lq * (CPL * 2);        // dy tile: [row][col % NCOL][col / NCOL][channels]
+
+    const int vv = tid % C::VPP;
+    const int cs = c0 + vv * 8;
+    const bool st_ok = tid < C::TS && cs < p.c;
+    const long long in_row_pitch = (long long)p.w * p.c, g_row_pitch = (long long)p.ow * p.c;
+    unsigned meta[C::NV], metag[NVG];                      // row | col << 8 | (LDS byte offset / 16) << 16
+#pragma unroll
+    for (int i = 0; i < C::NV; ++i) {
+        const int v = tid + i * C::TS;
+        const int row = v / (C::IW_T * C::VPP), col = (v / C::VPP) % C::IW_T;
+        const int pos = C::SWZ ? (col ^ ((col >> C::SWZ_BIT) & 1)) : col;
+        meta[i] = (unsigned)row | ((unsigned)col << 8) | ((unsigned)(((row * C::IWP + pos) * C::PSB + vv * 16) >> 4) << 16);
+        if (v >= C::RB * C::IW_T * C::VPP) meta[i] = 0xffu;
+    }
+#pragma unroll
+    for (int i = 0; i < NVG; ++i) {
+        const int v = tid + i * C::TS;
+        const int row = v / (C::TOW * C::VPP), col = (v / C::VPP) % C::TOW;
+        metag[i] = (unsigned)row | ((unsigned)col << 8) |
+                   ((unsigned)((((row * NCOL + col % NCOL) * XQ + col / NCOL) * C::PXB + vv * 16) >> 4) << 16);
+        if (v >= ORB * C::TOW * C::VPP) metag[i] = 0xffu;
+    }
+    if (has_pro && tid < 2 * C::TCH) {
+        const int ch = tid % C::TCH;
+        const float* src = tid < C::TCH ? p.pro_scale : p.pro_shift;
+        pro_lds[tid / C::TCH][ch] = (c0 + ch < p.c) ? src[c0 + ch] : 0.f;
+    }
+
+    f32x2_t acc[K * K][C::H2];
+#pragma unroll
+    for (int t = 0; t < K * K; ++t)
+#pragma unroll
+        for (int h = 0; h < C::H2; ++h) acc[t][h] = f32x2_t{0.f, 0.f};
+    f32x2_t g[C::A][NCOL][C::H2];
+
+    const int nitems = p.n * strips * segs;
+    auto item_geom = [&](int it, int& img, int& ox0, int& oy0, int& nrows, int& nblk) {
+        const int strip = it % strips;
+        const int seg = (it / strips) % segs;
+        img = it / (strips * segs);
+        ox0 = strip * C::TOW;
+        oy0 = seg * seg_rows;
+        nrows = p.oh - oy0 < seg_rows ? p.oh - oy0 : seg_rows;
+        nblk = ((nrows - 1) * S + K + C::RB - 1) / C::RB;
+    };
+
+    uint4 vals[C::NV], gvals[NVG];
+    unsigned inb = 0, colmask = 0, ginb = 0, gcolmask = 0;
+    auto stage_load = [&](int img, int ox0, int oy0, int nrows, int b, bool new_item) {
+        const int iy0 = oy0 * S - p.pad_t + b * C::RB, ix0 = ox0 * S - p.pad_l;
+        if (new_item) {
+            colmask = 0; gcolmask = 0;
+#pragma unroll
+            for (int i = 0; i < C::NV; ++i) {
+                const int ix = ix0 + (int)((meta[i] >> 8) & 0xffu);
+                if (st_ok && ix >= 0 && ix < p.w) colmask |= 1u << i;
+            }
+#pragma unroll
+            for (int i = 0; i < NVG; ++i)
+                if (st_ok && ox0 + (int)((metag[i] >> 8) & 0xffu) < p.ow) gcolmask |= 1u << i;
+        }
+        const bf16_t* org = p.x + ((long long)img * p.h + iy0) * in_row_pitch + (long long)ix0 * p.c + c0;
+        inb = 0;
+#pragma unroll
+        for (int i = 0; i < C::NV; ++i) {
+            const int iy = iy0 + (int)(meta[i] & 0xffu);
+            const bool ok = ((colmask >> i) & 1u) && iy >= 0 && iy < p.h;
+            const unsigned goff = (meta[i] & 0xffu) * (unsigned)in_row_pitch + ((meta[i] >> 8) & 0xffu) * (unsigned)p.c + vv * 8;
+            const bf16_t* a = ok ? org + goff : p.x;
+            vals[i] = *reinterpret_cast<const uint4*>(a);
+            inb |= (ok ? 1u : 0u) << i;
+        }
+        const int o0 = b * ORB;
+        const bf16_t* gorg = p.dy + ((long long)img * p.oh + oy0 + o0) * g_row_pitch + (long long)ox0 * p.c + c0;
+        ginb = 0;
+#pragma unroll
+        for (int i = 0; i < NVG; ++i) {
+            const int o = o0 + (int)(metag[i] & 0xffu);
+            const bool ok = ((gcolmask >> i) & 1u) && o < nrows;
+            const unsigned goff = (metag[i] & 0xffu) * (unsigned)g_row_pitch + ((metag[i] >> 8) & 0xffu) * (unsigned)p.c + vv * 8;
+            const bf16_t* a = ok ? gorg + goff : p.dy;
+            gvals[i] = *reinterpret_cast<const uint4*>(a);
+            ginb |= (ok ? 1u : 0u) << i;
+        }
+    };
+    auto stage_store = [&]() {
+        __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0), see the forward kernel
+        float ps[8], pt[8];
+        if (has_pro) { load8f(&pro_lds[0][vv * 8], ps); load8f(&pro_lds[1][vv * 8], pt); }
+#pragma unroll
+        for (int i = 0; i < C::NV; ++i) {
+            if (tid < C::TS && (meta[i] & 0xffu) != 0xffu) {
+                const bool real = (inb >> i) & 1u;
+                uint4 val = real ? vals[i] : make_uint4(0u, 0u, 0u, 0u);
+                if (has_pro && real) {
+                    float f[8];
+                    unpack8(val, f);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) f[q] = silu_f(f[q] * ps[q] + pt[q]);
+                    val = pack8(f);
+                }
+                *reinterpret_cast<uint4*>(smem + ((meta[i] >> 16) << 4)) = val;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NVG; ++i) {
+            if (tid < C::TS && (metag[i] & 0xffu) != 0xffu) {
+                const uint4 val = ((ginb >> i) & 1u) ? gvals[i] : make_uint4(0u, 0u, 0u, 0u);
+                *reinterpret_cast<uint4*>(gsm + ((metag[i] >> 16) << 4)) = val;
+            }
+        }
+    };
+
+    int it = y, img = 0;
+    int ox0 = 0, oy0 = 0, nrows = 0, nblk = 0, b = 0;
+    if (it >= nitems) return;
+    item_geom(it, img, ox0, oy0, nrows, nblk);
+    stage_load(img, ox0, oy0, nrows, 0, true);
+    while (true) {
+        __syncthreads();
+        stage_store();
+        __syncthreads();
+        int it2 = it, img2 = img;
+        int ox2 = ox0, oy2 = oy0, nrows2 = nrows, nblk2 = nblk, b2 = b + 1;
+        if (b2 >= nblk) {
+            it2 = it + gy; b2 = 0;
+            if (it2 < nitems) item_geom(it2, img2, ox2, oy2, nrows2, nblk2);
+        }
+        const bool more = it2 < nitems;
+        if (more) stage_load(img2, ox2, oy2, nrows2, b2, b2 == 0);
+
+        if (b == 0) {                          // new item: the dy window starts empty
+#pragma unroll
+            for (int a = 0; a < C::A; ++a)
+#pragma unroll
+                for (int i = 0; i < NCOL; ++i)
+#pragma unroll
+                    for (int h = 0; h < C::H2; ++h) g[a][i][h] = f32x2_t{0.f, 0.f};
+        }
+#pragma unroll
+        for (int sb = 0; sb < C::NR; ++sb) {
+            const unsigned char* lp_p = smem + lb_p + sb * (C::P * C::IWP * C::PSB);
+            const unsigned char* lp_m = smem + lb_m + sb * (C::P * C::IWP * C::PSB);
+#pragma unroll
+            for (int j = 0; j < C::P; ++j) {
+                f32x2_t in[C::NIN][C::H2];
+#pragma unroll
+                for (int i = 0; i < C::NIN; ++i) {
+                    const int t0 = C::SWZ ? (i ^ ((i >> C::SWZ_BIT) & 1)) : i;
+                    const unsigned char* a = ((t0 & 1) ? lp_m : lp_p) + (j * C::IWP + t0) * C::PSB;
+                    const ldsv_t v = *reinterpret_cast<const ldsv_t*>(a);
+                    if constexpr (CPL == 4) {
+                        in[i][0] = f32x2_t{bf_lo(v.x), bf_hi(v.x)};
+                        in[i][1] = f32x2_t{bf_lo(v.y), bf_hi(v.y)};
+                    } else {
+                        in[i][0] = f32x2_t{bf_lo(v), bf_hi(v)};
+                    }
+                }
+                if (j % S == 0) {                              // dy row (sb*A + j/S) of this block enters the window
+                    const int sl = pmod_c(j / S, C::A);
+                    const int d = sb * C::A + j / S;
+#pragma unroll
+                    for (int i = 0; i < NCOL; ++i) {
+                        const ldsv_t v = *reinterpret_cast<const ldsv_t*>(gsm + gbase + (d * NCOL + i) * XQ * C::PXB);
+                        if constexpr (CPL == 4) {
+                            g[sl][i][0] = f32x2_t{bf_lo(v.x), bf_hi(v.x)};
+                            g[sl][i][1] = f32x2_t{bf_lo(v.y), bf_hi(v.y)};
+                        } else {
+                            g[sl][i][0] = f32x2_t{bf_lo(v), bf_hi(v)};
+                        }
+                    }
+                }
+#pragma unroll
+                for (int kh = 0; kh < K; ++kh) {
+                    if (pmod_c(j - kh, S) != 0) continue;
+                    const int sl = pmod_c(fdiv_c(j - kh, S), C::A);
+#pragma unroll
+                    for (int kw = 0; kw < K; ++kw)
+#pragma unroll
+                        for (int i = 0; i < NCOL; ++i)
+#pragma unroll
+                            for (int h = 0; h < C::H2; ++h)
+                                acc[kh * K + kw][h] = __builtin_elementwise_fma(g[sl][i][h], in[i * S + kw][h], acc[kh * K + kw][h]);
+                }
+            }
+        }
+        if (!more) break;
+        it = it2; img = img2; ox0 = ox2; oy0 = oy2; nrows = nrows2; nblk = nblk2; b = b2;
+    }
+
+    // reduce the lanes that share a channel (PXW pixels x 4 waves) through LDS, one atomic per (tap, channel) per workgroup
+    float* red = reinterpret_cast<float*>(smem);          // [256 threads][CPL]
+    for (int t = 0; t < K * K; ++t) {
+        __syncthreads();
+#pragma unroll
+        for (int h = 0; h < C::H2; ++h) {
+            f32x2_t a = f32x2_t{0.f, 0.f};
+#pragma unroll
+            for (int tt = 0; tt < K * K; ++tt)
+                if (tt == t) a = acc[tt][h];              // static register indexing
+            red[tid * CPL + 2 * h] = lane_ok ? a.x : 0.f;
+            red[tid * CPL + 2 * h + 1] = lane_ok ? a.y : 0.f;
+        }
+        __syncthreads();
+        if (tid < C::TCH && c0 + tid < p.c) {
+            float s = 0.f;
+            for (int wv = 0; wv < 4; ++wv)
+                for (int q = 0; q < C::PXW; ++q) s += red[(wv * 64 + q * LP + tid / CPL) * CPL + tid % CPL];
+            atomicAdd(reinterpret_cast<float*>(p.out) + (long long)t * p.c + c0 + tid, s);
+        }
+    }
+}
+
 struct MarchPlan { int strips, segs, seg_rows, ctiles, gy; };
 template <typename C> MarchPlan march_plan(const mc_dwconv_args& p) {
     MarchPlan m;
@@ -566,6 +815,22 @@ template <int K, int S, typename C> int launch_march(const mc_dwconv_args& p, hi
 }
 template <int K, int S> int launch_march_cp(const mc_dwconv_args& p, hipStream_t st) {
     return march_dispatch<K, S>(p, [&](auto cfg) { return launch_march<K, S, decltype(cfg)>(p, st); });
+}
+template <int K, int S, typename C> int launch_march_bww(const mc_dwconv_args& p, hipStream_t st) {
+    MarchPlan m = march_plan<C>(p);
+    long long nitems = (long long)p.n * m.strips * m.segs;      // 2 workgroups per CU here
+    long long cap = 512 / m.ctiles;
+    if (cap < 8) cap = 8;
+    long long per = (nitems + cap - 1) / cap;
+    m.gy = (int)((nitems + per - 1) / per);
+    int gy8 = (m.gy + 7) / 8 * 8;
+    hipLaunchKernelGGL((dwconv_march_bww_kernel<K, S, C::H2 * 2, C::TCH / (C::H2 * 2), C::NCOL>), dim3(gy8 * m.ctiles), dim3(256), 0, st,
+                       p, m.strips, m.segs, m.seg_rows, m.ctiles, m.gy);
+    MC_LAUNCH_CHECK();
+    return MC_OK;
+}
+template <int K, int S> int launch_march_bww_cp(const mc_dwconv_args& p, hipStream_t st) {
+    return march_dispatch<K, S>(p, [&](auto cfg) { return launch_march_bww<K, S, decltype(cfg)>(p, st); });
 }
 template <int K, int S> int march_rows(const mc_dwconv_args& p) {
     return march_dispatch<K, S>(p, [&](auto cfg) { return march_plan<decltype(cfg)>(p).gy; });
@@ -643,8 +908,8 @@ extern "C" int mc_dwconv_bwd_weight(const mc_dwconv_args* a, void* stream) {
     if (int e = check_common(p)) return e;
     MC_CHECK(p.x && p.dy, "dwconv_bwd_weight: null x / dy");
     hipStream_t st = (hipStream_t)stream;
-    if (p.k == 3 && p.stride == 1) return launch_bww<3, 1>(p, st);
-    if (p.k == 3 && p.stride == 2) return launch_bww<3, 2>(p, st);
-    if (p.k == 5 && p.stride == 1) return launch_bww<5, 1>(p, st);
-    return launch_bww<5, 2>(p, st);
+    if (p.k == 3 && p.stride == 1) return launch_march_bww_cp<3, 1>(p, st);
+    if (p.k == 3 && p.stride == 2) return launch_march_bww_cp<3, 2>(p, st);
+    if (p.k == 5 && p.stride == 1) return launch_march_bww_cp<5, 1>(p, st);
+    return launch_march_bww_cp<5, 2>(p, st);
 }

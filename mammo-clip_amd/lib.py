@@ -71,7 +71,7 @@ class BnactArgs(C.Structure):
         ("rowscale", P), ("res", P), ("out", P),
         ("pooled", P),
         ("g", P), ("mul", P), ("add", P), ("add_scale", F), ("mean", P), ("invstd", P),
-        ("partials", P), ("coef", P), ("dx", P), ("dgate", P),
+        ("partials", P), ("coef", P), ("dx", P), ("dgate", P), ("split_ws", P),
     ]
 
 
@@ -98,6 +98,7 @@ _SIGS = {
     "mc_bn_finalize": ([P, I, I, D, P, P, P, P, F, F, I, P, P, P, P, P], I),
     "mc_bn_eval_coeffs": ([P, P, P, P, F, I, P, P, P], I),
     "mc_bnact_rows": ([C.POINTER(BnactArgs)], I),
+    "mc_bnact_img_splits": ([C.POINTER(BnactArgs)], I),
     "mc_bnact_apply": ([C.POINTER(BnactArgs), P], I),
     "mc_bnact_pool": ([C.POINTER(BnactArgs), P], I),
     "mc_bnact_bwd_reduce": ([C.POINTER(BnactArgs), P], I),

@@ -308,10 +308,21 @@ def bnact_apply(x, n_img, hw, c, scale, shift, act, rowscale=None, res=None):
     return out
 
 
+def _split_ws(a, x, n_img, c, planes=1):
+    """scratch for the per-image row splits (combined in split order: bit-reproducible, no float atomics)"""
+    sp = L.load().mc_bnact_img_splits(C.byref(a))
+    if sp <= 1:
+        return None
+    ws = empty((sp, planes, n_img, c), torch.float32, x)
+    a.split_ws = _p(ws)
+    return ws
+
+
 def bnact_pool(x, n_img, hw, c, scale, shift, act):
     a = _bnact(x, n_img, hw, c, scale, shift, act)
     pooled = empty((n_img, c), torch.float32, x)
     a.pooled = _p(pooled)
+    ws = _split_ws(a, x, n_img, c)  # noqa: F841  (kept alive until the launch is enqueued)
     _note(2 * n_img * hw * c)
     L.call("mc_bnact_pool", C.byref(a), _st())
     return pooled
@@ -321,6 +332,7 @@ def bnact_se_dgate(x, g, n_img, hw, c, scale, shift, act):
     a = _bnact(x, n_img, hw, c, scale, shift, act)
     dgate = empty((n_img, c), torch.float32, x)
     a.g, a.dgate = _p(g), _p(dgate)
+    ws = _split_ws(a, x, n_img, c)  # noqa: F841
     _note(4 * n_img * hw * c)
     L.call("mc_bnact_se_dgate", C.byref(a), _st())
     return dgate
@@ -331,6 +343,7 @@ def bnact_se_sums(x, g, n_img, hw, c, stats, act):
     a = _bnact(x, n_img, hw, c, stats.scale, stats.shift, act)
     sums = empty((5, n_img, c), torch.float32, x)
     a.g, a.dgate, a.mean, a.invstd = _p(g), _p(sums), _p(stats.mean), _p(stats.invstd)
+    ws = _split_ws(a, x, n_img, c, planes=5)  # noqa: F841
     _note(4 * n_img * hw * c)
     L.call("mc_bnact_se_sums", C.byref(a), _st())
     return sums

@@ -51,6 +51,18 @@ int main(int argc, char** argv) {
 #endif
             printf("\n");
         }
+        {   // weight gradient (x with prologue, dy = y buffer)
+            a.pro_scale = sc; a.pro_shift = sh; a.stat_partials = nullptr; a.dy = y; a.out = w;
+            if (mc_dwconv_bwd_weight(&a, nullptr)) { printf("err %s\n", mc_last_error()); return 1; }
+            HC(hipDeviceSynchronize());
+            HC(hipEventRecord(e0));
+            const int it = 5;
+            for (int i = 0; i < it; ++i) mc_dwconv_bwd_weight(&a, nullptr);
+            HC(hipEventRecord(e1)); HC(hipEventSynchronize(e1));
+            float ms; HC(hipEventElapsedTime(&ms, e0, e1)); ms /= it;
+            printf("bww k%ds%d c=%4d %3dx%3d pro=1  %7.3f ms %7.1f GB/s\n", s.k, s.s, s.c, s.h, s.w, ms, bytes / ms / 1e6);
+            a.out = y;
+        }
     }
     return 0;
 }
