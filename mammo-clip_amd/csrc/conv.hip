@@ -1,85 +1,17 @@
 // Depthwise k x k convolution (k in {3,5}, stride in {1,2}) for NHWC bf16, gfx950.
 // [ref: efficientnet_custom.py:109-111  _depthwise_conv (+ static ZeroPad2d, efficient_net_custom_utils.py:248-276)]
 //
-// Forward (and stride-1 data gradient, = forward with flipped taps): "marching" kernel below - column strips walked
-// top to bottom with the partial output rows held in registers.  Weight gradient: 2-D halo tiles staged in LDS with
-// coalesced 16-byte loads (the BatchNorm+SiLU of the producing expand conv is applied once per element while staging,
-// zero padding is inserted after the activation).  Both are persistent over their work items so the per-channel
-// sum / sum-of-squares for the following training-mode BatchNorm leave the kernel as a small [workgroups][2][C]
-// partial buffer (deterministic, no atomics).
+// Forward (and stride-1 data gradient, = forward with flipped taps) and weight gradient are "marching" kernels:
+// column strips walked top to bottom, input rows staged through LDS with coalesced 16-byte loads (the BatchNorm+SiLU
+// of the producing expand conv is applied once per element while staging, zero padding is inserted after the
+// activation), partial output rows / tap accumulators held in registers.  Workgroups are persistent over their work
+// items so the per-channel sum / sum-of-squares for the following training-mode BatchNorm leave the forward kernel
+// as a small [workgroups][2][C] partial buffer (deterministic, no atomics).  The stride-2 data gradient is a gather.
 #include "common.cuh"
 #include <type_traits>
 #include "../../include/mammoclip_hip.h"
 
 namespace {
-
-constexpr int TC = 64;              // channels per workgroup tile
-constexpr int PIXB = TC * 2 + 16;   // LDS bytes per staged pixel (padded)
-constexpr int TOW = 16;
-
-template <int K, int S> struct DwCfg {
-    static constexpr int TOH = (S == 1) ? 8 : 4;
-    static constexpr int R = 2;                           // output pixels per strip (along W)
-    static constexpr int NSTRIP = TOW / R;
-    static constexpr int PASSES = TOH * NSTRIP * 8 / 256; // strips per thread
-    static constexpr int IH_T = (TOH - 1) * S + K;
-    static constexpr int IW_T = (TOW - 1) * S + K;
-    static constexpr int NIN = (R - 1) * S + K;           // input vectors per filter row per strip
-    static constexpr int TILE_BYTES = IH_T * IW_T * PIXB;
-    static constexpr int W_BYTES = K * K * TC * 4;
-};
-
-// halo tile staging, split so the global loads of the NEXT tile can be in flight while the current tile computes:
-// load_halo issues all 16-byte loads of the (IH_T x IW_T x 64-channel) tile back to back into registers,
-// store_halo applies the optional BN+SiLU prologue (in-range pixels only: zero padding stays zero) and writes LDS.
-template <int K, int S> struct Halo {
-    static constexpr int NV = (DwCfg<K, S>::IH_T * DwCfg<K, S>::IW_T + 31) / 32;
-    uint4 vals[NV];
-    unsigned inb;
-};
-
-template <int K, int S>
-__device__ __forceinline__ void load_halo(const mc_dwconv_args& p, Halo<K, S>& hl, long long img, int oy0, int ox0, int c0) {
-    using C = DwCfg<K, S>;
-    const int tid = threadIdx.x;
-    const int c = c0 + (tid & 7) * 8;
-    const int iy0 = oy0 * S - p.pad_t, ix0 = ox0 * S - p.pad_l;
-    hl.inb = 0;
-#pragma unroll
-    for (int i = 0; i < Halo<K, S>::NV; ++i) {
-        int v = (tid >> 3) + i * 32;
-        int ty = v / C::IW_T, tx = v % C::IW_T;
-        int iy = iy0 + ty, ix = ix0 + tx;
-        hl.vals[i] = make_uint4(0u, 0u, 0u, 0u);
-        if (v < C::IH_T * C::IW_T && c < p.c && iy >= 0 && iy < p.h && ix >= 0 && ix < p.w) {
-            hl.vals[i] = *reinterpret_cast<const uint4*>(p.x + ((img * p.h + iy) * (long long)p.w + ix) * p.c + c);
-            hl.inb |= 1u << i;
-        }
-    }
-}
-
-template <int K, int S>
-__device__ __forceinline__ void store_halo(unsigned char* tile, const Halo<K, S>& hl, const float* ps, const float* pt,
-                                           bool has_pro) {
-    using C = DwCfg<K, S>;
-    const int tid = threadIdx.x;
-    const int cv = tid & 7;
-#pragma unroll
-    for (int i = 0; i < Halo<K, S>::NV; ++i) {
-        int v = (tid >> 3) + i * 32;
-        if (v < C::IH_T * C::IW_T) {
-            uint4 val = hl.vals[i];
-            if (has_pro && ((hl.inb >> i) & 1u)) {
-                float f[8];
-                unpack8(val, f);
-#pragma unroll
-                for (int q = 0; q < 8; ++q) f[q] = silu_f(f[q] * ps[q] + pt[q]);
-                val = pack8(f);
-            }
-            *reinterpret_cast<uint4*>(tile + v * PIXB + cv * 16) = val;
-        }
-    }
-}
 
 // generic gather form of the data gradient (any stride): dx[ih,iw] = sum_{kh,kw} dy[(ih+pt-kh)/S, (iw+pl-kw)/S] * w[kh,kw]
 template <int K>
@@ -116,103 +48,6 @@ __global__ __launch_bounds__(256) void dwconv_bwd_data_kernel(const mc_dwconv_ar
             }
         }
         *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.out) + pix * p.c + cv * 8) = pack8(acc);
-    }
-}
-
-// weight gradient: dw[kh,kw,c] += sum_{n,oy,ox} dy[n,oy,ox,c] * x'[n, oy*S+kh-pt, ox*S+kw-pl, c]
-// thread = (4-channel vector, pixel group); all K*K taps accumulate in registers across the persistent tile loop
-template <int K, int S>
-__global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const mc_dwconv_args p, int tiles_h, int tiles_w) {
-    using C = DwCfg<K, S>;
-    constexpr int RW = (S == 1) ? 8 : 4;                 // outputs per thread along W
-    constexpr int NSTR = TOW / RW;
-    constexpr int NINW = (RW - 1) * S + K;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* tile = smem;
-    const int tid = threadIdx.x;
-    const int cq = tid & 15;                              // 4-channel vector index inside the 64-channel tile
-    const int pg = tid >> 4;                              // 16 pixel groups
-    const int strip = pg % NSTR, orow = pg / NSTR;
-    const int c0 = blockIdx.x * TC;
-    const int c = c0 + cq * 4;
-    const bool cvalid = c < p.c;
-    const bool has_pro = p.pro_scale != nullptr;
-    const int cv = tid & 7;
-    float ps[8], pt[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) { ps[q] = 1.f; pt[q] = 0.f; }
-    if (has_pro && c0 + cv * 8 < p.c) { load8f(p.pro_scale + c0 + cv * 8, ps); load8f(p.pro_shift + c0 + cv * 8, pt); }
-
-    float acc[K * K][4];
-#pragma unroll
-    for (int t = 0; t < K * K; ++t)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) acc[t][q] = 0.f;
-
-    const long long ntiles = (long long)p.n * tiles_h * tiles_w;
-    auto tile_pos = [&](long long t, long long& img, int& oy0, int& ox0) {
-        ox0 = (int)(t % tiles_w) * TOW;
-        oy0 = (int)((t / tiles_w) % tiles_h) * C::TOH;
-        img = t / ((long long)tiles_w * tiles_h);
-    };
-    Halo<K, S> hl;
-    long long t = blockIdx.y;
-    {
-        long long img; int oy0, ox0;
-        if (t < ntiles) { tile_pos(t, img, oy0, ox0); load_halo<K, S>(p, hl, img, oy0, ox0, c0); }
-    }
-    for (; t < ntiles; t += gridDim.y) {
-        long long img; int oy0, ox0;
-        tile_pos(t, img, oy0, ox0);
-        __syncthreads();
-        store_halo<K, S>(tile, hl, ps, pt, has_pro);
-        __syncthreads();
-        if (t + gridDim.y < ntiles) {          // prefetch the next halo tile while this one is consumed
-            long long img2; int oy2, ox2;
-            tile_pos(t + gridDim.y, img2, oy2, ox2);
-            load_halo<K, S>(p, hl, img2, oy2, ox2, c0);
-        }
-        const int oy = oy0 + orow;
-        float g[RW][4];
-#pragma unroll
-        for (int r = 0; r < RW; ++r) {
-            int ox = ox0 + strip * RW + r;
-            uint2 gv = make_uint2(0u, 0u);
-            if (cvalid && oy < p.oh && ox < p.ow)
-                gv = *reinterpret_cast<const uint2*>(p.dy + ((img * p.oh + oy) * (long long)p.ow + ox) * p.c + c);
-            g[r][0] = bf_lo(gv.x); g[r][1] = bf_hi(gv.x); g[r][2] = bf_lo(gv.y); g[r][3] = bf_hi(gv.y);
-        }
-#pragma unroll
-        for (int kh = 0; kh < K; ++kh) {              // must stay unrolled: acc[] is indexed by kh (registers, not scratch)
-            float in[NINW][4];
-            const unsigned char* rowp = tile + ((orow * S + kh) * C::IW_T + strip * RW * S) * PIXB + cq * 8;
-#pragma unroll
-            for (int i = 0; i < NINW; ++i) {
-                uint2 v = *reinterpret_cast<const uint2*>(rowp + i * PIXB);
-                in[i][0] = bf_lo(v.x); in[i][1] = bf_hi(v.x); in[i][2] = bf_lo(v.y); in[i][3] = bf_hi(v.y);
-            }
-#pragma unroll
-            for (int kw = 0; kw < K; ++kw)
-#pragma unroll
-                for (int r = 0; r < RW; ++r)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        acc[kh * K + kw][q] = fmaf(g[r][q], in[r * S + kw][q], acc[kh * K + kw][q]);
-        }
-    }
-    // reduce the 16 pixel groups per tap through LDS, one atomic per (tap, channel) per workgroup
-    float* red = reinterpret_cast<float*>(smem);          // [16 pg][64 ch]
-    for (int tap = 0; tap < K * K; ++tap) {
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < 4; ++q) red[pg * 64 + cq * 4 + q] = acc[tap][q];
-        __syncthreads();
-        if (tid < 64 && c0 + tid < p.c) {
-            float s = 0.f;
-#pragma unroll
-            for (int g2 = 0; g2 < 16; ++g2) s += red[g2 * 64 + tid];
-            atomicAdd(reinterpret_cast<float*>(p.out) + (long long)tap * p.c + c0 + tid, s);
-        }
     }
 }
 
@@ -843,32 +678,6 @@ int check_common(const mc_dwconv_args& p) {
     MC_CHECK((p.k == 3 || p.k == 5) && (p.stride == 1 || p.stride == 2), "dwconv: k in {3,5}, stride in {1,2}");
     MC_CHECK(p.oh > 0 && p.ow > 0, "dwconv: bad output shape");
     MC_CHECK((p.pro_scale == nullptr) == (p.pro_shift == nullptr), "dwconv: prologue needs scale and shift");
-    return MC_OK;
-}
-
-template <int K, int S> int tiles_of(const mc_dwconv_args& p, int* th, int* tw) {
-    *th = mc_div_up(p.oh, DwCfg<K, S>::TOH);
-    *tw = mc_div_up(p.ow, TOW);
-    return 0;
-}
-int grid_y_for(const mc_dwconv_args& p, long long ntiles) {
-    int ctiles = mc_div_up(p.c, TC);
-    long long want = 2048 / ctiles;
-    if (want < 64) want = 64;
-    if (want > 1024) want = 1024;
-    return (int)(ntiles < want ? ntiles : want);
-}
-
-template <int K, int S> int launch_bww(const mc_dwconv_args& p, hipStream_t st) {
-    using C = DwCfg<K, S>;
-    int th, tw;
-    tiles_of<K, S>(p, &th, &tw);
-    long long ntiles = (long long)p.n * th * tw;
-    dim3 grid(mc_div_up(p.c, TC), grid_y_for(p, ntiles));
-    size_t lds = C::TILE_BYTES;
-    if (lds < 16 * 64 * 4) lds = 16 * 64 * 4;
-    hipLaunchKernelGGL((dwconv_bwd_weight_kernel<K, S>), grid, dim3(256), lds, st, p, th, tw);
-    MC_LAUNCH_CHECK();
     return MC_OK;
 }
 
