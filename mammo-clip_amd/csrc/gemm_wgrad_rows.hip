@@ -17,12 +17,15 @@ namespace {
 typedef __attribute__((ext_vector_type(4))) short s4_t;
 typedef __attribute__((address_space(3))) s4_t lds_s4_t;
 
-constexpr int MAXCH = 14;      // 16-byte chunks per thread per step: RB * (N + K) / 8 / 256 <= 14
-// RB = pixel rows per step (64 .. 512, runtime): narrow layers take more rows per step so that every step moves
-// ~50 KB -- enough bytes in flight per workgroup to cover HBM latency with a one-step prefetch.
-static int pick_rb(int n, int k) {
-    int rb = 512;
-    while (rb > 64 && (long long)rb * (n + k) > 28672) rb >>= 1;
+// RB = pixel rows per step (multiple of 32, runtime).  A step is prefetched ONE step ahead through registers, so the
+// bytes in flight per workgroup = the step size: NCH 16-byte chunks per thread.  Shapes with few output fragments
+// per wave have the registers for 16 chunks (64 KB steps, 128 KB in flight per CU), the others take 10 (40 KB).
+static int pick_nch(int af, int bfn) { return af * bfn <= 8 ? 16 : 10; }
+static int pick_rb(int n, int k, int nch) {
+    int rb = (nch * 256 * 8 / (n + k)) / 32 * 32;
+    if (rb > 1024) rb = 1024;
+    while (rb > 32 && (rb * (n / 8) + 255) / 256 + (rb * (k / 8) + 255) / 256 > nch) rb -= 32;   // whole slots per tensor
+    if (rb < 32) rb = 32;
     return rb;
 }
 
@@ -38,117 +41,144 @@ __device__ __forceinline__ bf16x8_t tr_frag(const unsigned char* tile, int rs, i
     return __builtin_bit_cast(bf16x8_t, v);
 }
 
-template <int AFM, int BFM>
-__global__ __launch_bounds__(256) void wgrad_rows_kernel(const mc_wgrad_rows_args p, int WB, int af, int bfn, int RB) {
+// AF x BF = 16x16 output fragments per wave (exact: the host picks the instantiation), WB = waves along K.
+// Per-thread chunk geometry (global offset, LDS offset, row) is constant over the steps and lives in registers: a
+// step costs a few instructions per 16-byte chunk instead of two runtime divisions.
+template <int AF, int BF, int MAXCH>
+__global__ __launch_bounds__(256, 2) void wgrad_rows_kernel(const mc_wgrad_rows_args p, int WB, int RB, int nch) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int rsy = p.N * 2, rsx = p.K * 2;
     unsigned char* sY = smem;
     unsigned char* sX = smem + RB * rsy;
+    float* spro = reinterpret_cast<float*>(smem + RB * (rsy + rsx) + 32 * 16 * 2 * 6 + 64);   // [2][K] prologue scale / shift
+    float* sgate = spro + 2 * p.K;                         // [2][K] SE gate row of the current / next step's image
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wa = wave / WB, wb = wave % WB;
     const int ny8 = p.N >> 3, nx8 = p.K >> 3;
     const int chY = RB * ny8, chT = chY + RB * nx8;
     const bool has_pro = p.pro_scale != nullptr;
-    const int fna = (p.N + 15) >> 4, fkb = (p.K + 15) >> 4;
 
-    f32x4_t acc[AFM][BFM];
+    f32x4_t acc[AF][BF];
 #pragma unroll
-    for (int i = 0; i < AFM; ++i)
+    for (int i = 0; i < AF; ++i)
 #pragma unroll
-        for (int j = 0; j < BFM; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < BF; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    if (has_pro)                                           // staged in LDS: re-read per step, not held in 160 registers
+        for (int i = tid; i < 2 * p.K; i += 256) spro[i] = i < p.K ? p.pro_scale[i] : p.pro_shift[i - p.K];
 
+    // chunk slots: the first nchy slots of every thread belong to dY, the rest to X (uniform per slot, so the base
+    // pointer of a slot is scalar and the per-lane part of an address is one 32-bit offset).  meta = row | chunk << 12.
+    const int nchy = (chY + 255) >> 8;
+    unsigned meta[MAXCH];
+#pragma unroll
+    for (int i = 0; i < MAXCH; ++i) {
+        meta[i] = 0xfffu;                                  // row 4095: never valid
+        if (i < nchy) {
+            const int c = tid + i * 256;
+            if (c < chY) { const int row = c / ny8; meta[i] = (unsigned)row | ((unsigned)(c - row * ny8) << 12); }
+        } else if (i < nch) {
+            const int c = tid + (i - nchy) * 256;
+            if (c < RB * nx8) { const int row = c / nx8; meta[i] = (unsigned)row | ((unsigned)(c - row * nx8) << 12); }
+        }
+    }
+    // steps never straddle an image when there is a gate (one gate row per step, staged through LDS one step ahead)
+    const long long rpi = p.pro_gate ? p.pro_rows_per_img : p.M;
+    const long long spi = (rpi + RB - 1) / RB;
+    const long long rem = p.M % rpi;                       // a partial last image is allowed
+    const long long nsteps = (p.M / rpi) * spi + (rem + RB - 1) / RB;
+    auto step_geom = [&](long long s, long long& m0, int& rows, long long& img) {
+        img = s / spi;
+        const long long ls = s - img * spi;
+        m0 = img * rpi + ls * RB;
+        const long long left = (p.M - img * rpi < rpi ? p.M - img * rpi : rpi) - ls * RB;
+        rows = (int)(left < RB ? left : RB);
+    };
     uint4 regs[MAXCH];
+    float4 greg = make_float4(1.f, 1.f, 1.f, 1.f);
     auto load_step = [&](long long s) {
-        const long long m0 = s * RB;
+        long long m0, img; int rows;
+        step_geom(s, m0, rows, img);
+        if (p.pro_gate && tid * 4 < p.K) greg = *reinterpret_cast<const float4*>(p.pro_gate + img * p.K + tid * 4);
+        const char* yb = reinterpret_cast<const char*>(p.dY + m0 * p.lddy);
+        const char* xb = reinterpret_cast<const char*>(p.X + m0 * p.ldx);
+        const unsigned ldyb = (unsigned)p.lddy * 2u, ldxb = (unsigned)p.ldx * 2u;
 #pragma unroll
         for (int i = 0; i < MAXCH; ++i) {
-            int c = tid + i * 256;
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (c < chY) {
-                int row = c / ny8, cc = c - row * ny8;
-                if (m0 + row < p.M) v = *reinterpret_cast<const uint4*>(p.dY + (m0 + row) * p.lddy + cc * 8);
-            } else if (c < chT) {
-                int c2 = c - chY;
-                int row = c2 / nx8, cc = c2 - row * nx8;
-                if (m0 + row < p.M) v = *reinterpret_cast<const uint4*>(p.X + (m0 + row) * p.ldx + cc * 8);
+            if (i < nch) {                                 // unconditional loads (rows past the end re-read row 0, zeroed at the store)
+                const unsigned row = meta[i] & 0xfffu, cc = meta[i] >> 12;
+                const unsigned r = (int)row < rows ? row : 0u;
+                const unsigned off = r * (i < nchy ? ldyb : ldxb) + cc * 16u;
+                regs[i] = *reinterpret_cast<const uint4*>((i < nchy ? yb : xb) + off);
             }
-            regs[i] = v;
         }
     };
-    auto store_step = [&](long long s) {
-        const long long m0 = s * RB;
+    auto store_step = [&](long long s, int par) {
+        __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0) (keeps the compiler from draining the NEXT step's loads early)
+        long long m0, img; int rows;
+        step_geom(s, m0, rows, img);
 #pragma unroll
         for (int i = 0; i < MAXCH; ++i) {
-            int c = tid + i * 256;
-            if (c < chY) {
-                int row = c / ny8, cc = c - row * ny8;
-                *reinterpret_cast<uint4*>(sY + row * rsy + cc * 16) = regs[i];
-            } else if (c < chT) {
-                int c2 = c - chY;
-                int row = c2 / nx8, cc = c2 - row * nx8;
-                uint4 v = regs[i];
-                if (has_pro && m0 + row < p.M) {
+            if (i < nch && (meta[i] & 0xfffu) != 0xfffu) {
+                const int row = (int)(meta[i] & 0xfffu), cc8 = (int)(meta[i] >> 12) * 8;
+                const bool isx = i >= nchy;
+                uint4 v = row < rows ? regs[i] : make_uint4(0u, 0u, 0u, 0u);
+                if (has_pro && isx && row < rows) {
                     float f[8], sc[8], sh[8];
                     unpack8(v, f);
-                    load8f(p.pro_scale + cc * 8, sc);
-                    load8f(p.pro_shift + cc * 8, sh);
+                    load8f(spro + cc8, sc);
+                    load8f(spro + p.K + cc8, sh);
 #pragma unroll
                     for (int q = 0; q < 8; ++q) f[q] = silu_f(f[q] * sc[q] + sh[q]);
                     if (p.pro_gate) {
                         float gv[8];
-                        load8f(p.pro_gate + ((m0 + row) / p.pro_rows_per_img) * p.K + cc * 8, gv);
+                        load8f(sgate + par * p.K + cc8, gv);
 #pragma unroll
                         for (int q = 0; q < 8; ++q) f[q] *= gv[q];
                     }
                     v = pack8(f);
                 }
-                *reinterpret_cast<uint4*>(sX + row * rsx + cc * 16) = v;
+                *reinterpret_cast<uint4*>((isx ? sX + row * rsx : sY + row * rsy) + cc8 * 2) = v;
             }
         }
     };
 
-    const long long nsteps = (p.M + RB - 1) / RB;
     long long s = blockIdx.x;
-    if (s < nsteps) load_step(s);
-    for (; s < nsteps; s += gridDim.x) {
-        __syncthreads();                       // previous step's fragment reads are done
-        store_step(s);
+    int par = 0;
+    if (s < nsteps) {
+        load_step(s);
+        if (p.pro_gate && tid * 4 < p.K) *reinterpret_cast<float4*>(sgate + tid * 4) = greg;
+    }
+    for (; s < nsteps; s += gridDim.x, par ^= 1) {
+        __syncthreads();                       // previous step's fragment reads are done; gate row of this step is in LDS
+        store_step(s, par);
         __syncthreads();
         if (s + gridDim.x < nsteps) load_step(s + gridDim.x);
+        // fragments past N / K read stale LDS (inside the allocation) into accumulators that are never written out
         for (int ks = 0; ks < RB / 32; ++ks) {
-            bf16x8_t a[AFM], b[BFM];
+            bf16x8_t a[AF], b[BF];
 #pragma unroll
-            for (int i = 0; i < AFM; ++i) {
-                int fa = wa * af + i;
-                if (i < af && fa < fna) a[i] = tr_frag(sY, rsy, ks * 32, fa * 16, lane);
-            }
+            for (int i = 0; i < AF; ++i) a[i] = tr_frag(sY, rsy, ks * 32, (wa * AF + i) * 16, lane);
 #pragma unroll
-            for (int j = 0; j < BFM; ++j) {
-                int fb = wb * bfn + j;
-                if (j < bfn && fb < fkb) b[j] = tr_frag(sX, rsx, ks * 32, fb * 16, lane);
-            }
+            for (int j = 0; j < BF; ++j) b[j] = tr_frag(sX, rsx, ks * 32, (wb * BF + j) * 16, lane);
 #pragma unroll
-            for (int i = 0; i < AFM; ++i)
+            for (int i = 0; i < AF; ++i)
 #pragma unroll
-                for (int j = 0; j < BFM; ++j)
-                    if (i < af && j < bfn && wa * af + i < fna && wb * bfn + j < fkb)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < BF; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
         }
+        if (p.pro_gate && s + gridDim.x < nsteps && tid * 4 < p.K)      // next step's gate row -> the other LDS slot
+            *reinterpret_cast<float4*>(sgate + (par ^ 1) * p.K + tid * 4) = greg;
     }
     // partial [N][K] of this workgroup -> workspace.  D[i][j]: i = n (A operand), j = k (B operand)
     float* W = p.ws + (long long)blockIdx.x * p.N * p.K;
 #pragma unroll
-    for (int i = 0; i < AFM; ++i)
+    for (int i = 0; i < AF; ++i)
 #pragma unroll
-        for (int j = 0; j < BFM; ++j) {
-            int fa = wa * af + i, fb = wb * bfn + j;
-            if (i < af && j < bfn && fa < fna && fb < fkb) {
-                int k = fb * 16 + (lane & 15);
+        for (int j = 0; j < BF; ++j) {
+            const int k = (wb * BF + j) * 16 + (lane & 15);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    int n = fa * 16 + (lane >> 4) * 4 + r;
-                    if (n < p.N && k < p.K) W[(long long)n * p.K + k] = acc[i][j][r];
-                }
+            for (int r = 0; r < 4; ++r) {
+                const int n = (wa * AF + i) * 16 + (lane >> 4) * 4 + r;
+                if (n < p.N && k < p.K) W[(long long)n * p.K + k] = acc[i][j][r];
             }
         }
 }
@@ -201,13 +231,25 @@ extern "C" int mc_wgrad_rows_bf16(const mc_wgrad_rows_args* a, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     int WA, WB, af, bfn;
     wave_split(p.N, p.K, &WA, &WB, &af, &bfn);
-    const int RB = pick_rb(p.N, p.K);
-    long long steps = (p.M + RB - 1) / RB;
-    const int blocks = (int)(steps < 512 ? steps : 512);      // <= mc_wgrad_rows_blocks(M): ws is large enough
-    const size_t lds = (size_t)RB * (p.N + p.K) * 2 + 64;     // + slack: the last fragment may over-read 16 B
-    if (af <= 4 && bfn <= 4) hipLaunchKernelGGL((wgrad_rows_kernel<4, 4>), dim3(blocks), dim3(256), lds, st, p, WB, af, bfn, RB);
-    else if (af <= 6 && bfn <= 4) hipLaunchKernelGGL((wgrad_rows_kernel<6, 4>), dim3(blocks), dim3(256), lds, st, p, WB, af, bfn, RB);
-    else hipLaunchKernelGGL((wgrad_rows_kernel<4, 6>), dim3(blocks), dim3(256), lds, st, p, WB, af, bfn, RB);
+    const int NCH = pick_nch(af, bfn);
+    const int RB = pick_rb(p.N, p.K, NCH);
+    const long long rpi = p.pro_gate ? p.pro_rows_per_img : p.M;
+    long long steps = (p.M / rpi) * ((rpi + RB - 1) / RB) + (p.M % rpi + RB - 1) / RB;
+    const long long cap = mc_wgrad_rows_blocks(p.M);          // rows of the caller's workspace
+    const int blocks = (int)(steps < cap ? steps : cap);
+    // LDS: both tiles + slack so that fragments past N / K (and the last fragment's 16-byte over-read) stay inside
+    const size_t lds = (size_t)RB * (p.N + p.K) * 2 + 32 * 16 * 2 * 6 + 64 + (size_t)p.K * 16;
+    const int nch = (RB * (p.N / 8) + 255) / 256 + (RB * (p.K / 8) + 255) / 256;   // dY slots + X slots per thread
+    MC_CHECK(nch <= NCH, "wgrad_rows: internal: step too large");
+#define WG_CASE(A_, B_) if (af == A_ && bfn == B_) { hipLaunchKernelGGL((wgrad_rows_kernel<A_, B_, (A_ * B_ <= 8 ? 16 : 10)>), dim3(blocks), dim3(256), lds, st, p, WB, RB, nch); } else
+    WG_CASE(1, 1) WG_CASE(1, 2) WG_CASE(1, 3) WG_CASE(1, 4) WG_CASE(1, 5) WG_CASE(1, 6)
+    WG_CASE(2, 1) WG_CASE(2, 2) WG_CASE(2, 3) WG_CASE(2, 4) WG_CASE(2, 5) WG_CASE(2, 6)
+    WG_CASE(3, 1) WG_CASE(3, 2) WG_CASE(3, 3) WG_CASE(3, 4) WG_CASE(3, 5) WG_CASE(3, 6)
+    WG_CASE(4, 1) WG_CASE(4, 2) WG_CASE(4, 3) WG_CASE(4, 4) WG_CASE(4, 5) WG_CASE(4, 6)
+    WG_CASE(5, 1) WG_CASE(5, 2) WG_CASE(5, 3) WG_CASE(5, 4)
+    WG_CASE(6, 1) WG_CASE(6, 2) WG_CASE(6, 3) WG_CASE(6, 4)
+    { MC_CHECK(false, "wgrad_rows: internal: no instantiation"); }
+#undef WG_CASE
     MC_LAUNCH_CHECK();
     long long nk = (long long)p.N * p.K;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(mc_div_up(nk, 16)), dim3(256), 0, st, p.ws, blocks, nk, p.dW, p.accumulate);
