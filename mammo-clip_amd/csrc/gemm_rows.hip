@@ -18,8 +18,10 @@
 
 namespace {
 
-template <int FN, int KC>
-__global__ __launch_bounds__(256) void gemm_rows_kernel(const mc_gemm_rows_args p) {
+// FN = output fragments (exact: ceil(N/16)), KC = 32-wide K chunks (padded), RG = 16-row groups per wave iteration,
+// PF = iterations in flight per wave
+template <int FN, int KC, int PF, int RG>
+__global__ __launch_bounds__(256, 2) void gemm_rows_kernel(const mc_gemm_rows_args p) {
     constexpr int NP = FN * 16;                    // padded output width
     constexpr int CROW = (NP + 8) * 2;             // staging row bytes
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -28,7 +30,6 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(const mc_gemm_rows_args 
     float* sShift = sScale + KC * 32;
     unsigned char* sC = reinterpret_cast<unsigned char*>(sShift + KC * 32);   // [4 waves][16][CROW]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int fn = (p.N + 15) >> 4;                // fragments actually used
     const int kc_used = (p.K + 31) >> 5;
     const bool has_pro = p.pro_scale != nullptr;
 
@@ -49,67 +50,66 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(const mc_gemm_rows_args 
 
     unsigned char* myC = sC + wave * 16 * CROW;
     const int mrow = lane & 15, kg = lane >> 4;
-    const long long ngroups = (p.M + 31) >> 5;
+    const long long ngroups = (p.M + RG * 16 - 1) / (RG * 16);
     const long long gstride = (long long)gridDim.x * 4;
-    float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};   // lane owns columns lane*4 .. lane*4+3
-
-    uint4 xn[2][KC];                                // prefetched fragments of the NEXT group
-    auto load_group = [&](long long g) {
+    // epilogue mapping: lane = (row slot, 16-byte column chunk); a lane always handles the same 8 output columns, so
+    // the BatchNorm statistics of the stored tensor accumulate in 16 registers inside the store loop
+    const int cpr = p.N >> 3;                       // 16-byte chunks per output row (<= 32)
+    const int slots = 64 / cpr;                     // rows written concurrently by one wave
+    const int c8 = lane % cpr, rs = lane / cpr;
+    const bool ep_active = rs < slots;
+    float ssum[8], ssq[8];
 #pragma unroll
-        for (int rg = 0; rg < 2; ++rg) {
-            long long m = g * 32 + rg * 16 + mrow;
+    for (int q = 0; q < 8; ++q) { ssum[q] = 0.f; ssq[q] = 0.f; }
+
+    // PF 32-row groups per wave are in flight (narrow K = few bytes per group: latency needs several groups ahead)
+    uint4 xn[PF][RG][KC];
+    auto load_group = [&](uint4 (&x)[RG][KC], long long g) {
+#pragma unroll
+        for (int rg = 0; rg < RG; ++rg) {
+            long long m = (g * RG + rg) * 16 + mrow;
+            if (m >= p.M) m = p.M - 1;              // clamped rows are computed but never stored
 #pragma unroll
             for (int kc = 0; kc < KC; ++kc) {
                 int k = kc * 32 + kg * 8;
                 uint4 v = make_uint4(0u, 0u, 0u, 0u);
-                if (kc < kc_used && m < p.M && k < p.K) v = *reinterpret_cast<const uint4*>(p.X + m * p.ldx + k);
-                xn[rg][kc] = v;
+                if (kc < kc_used && k < p.K) v = *reinterpret_cast<const uint4*>(p.X + m * p.ldx + k);
+                x[rg][kc] = v;
             }
         }
     };
-
-    long long g = (long long)blockIdx.x * 4 + wave;
-    if (g < ngroups) load_group(g);
-    for (; g < ngroups; g += gstride) {
-        uint4 xf[2][KC];
-#pragma unroll
-        for (int rg = 0; rg < 2; ++rg)
-#pragma unroll
-            for (int kc = 0; kc < KC; ++kc) xf[rg][kc] = xn[rg][kc];
-        if (g + gstride < ngroups) load_group(g + gstride);          // in flight during everything below
-
+    auto process = [&](long long g, uint4 (&xf)[RG][KC]) {
         if (has_pro) {
 #pragma unroll
-            for (int rg = 0; rg < 2; ++rg) {
-                long long m = g * 32 + rg * 16 + mrow;
-                if (m < p.M) {
-                    const float* gate = p.pro_gate ? p.pro_gate + (m / p.pro_rows_per_img) * p.K : nullptr;
+            for (int rg = 0; rg < RG; ++rg) {
+                long long m = (g * RG + rg) * 16 + mrow;
+                if (m >= p.M) m = p.M - 1;
+                const float* gate = p.pro_gate ? p.pro_gate + (m / p.pro_rows_per_img) * p.K : nullptr;
 #pragma unroll
-                    for (int kc = 0; kc < KC; ++kc) {
-                        int k = kc * 32 + kg * 8;
-                        if (kc < kc_used && k < p.K) {
-                            float f[8], s[8], t[8];
-                            unpack8(xf[rg][kc], f);
-                            load8f(sScale + k, s);
-                            load8f(sShift + k, t);
+                for (int kc = 0; kc < KC; ++kc) {
+                    int k = kc * 32 + kg * 8;
+                    if (kc < kc_used && k < p.K) {
+                        float f[8], s[8], t[8];
+                        unpack8(xf[rg][kc], f);
+                        load8f(sScale + k, s);
+                        load8f(sShift + k, t);
 #pragma unroll
-                            for (int q = 0; q < 8; ++q) f[q] = silu_f(f[q] * s[q] + t[q]);
-                            if (gate) {
-                                float gv[8];
-                                load8f(gate + k, gv);
+                        for (int q = 0; q < 8; ++q) f[q] = silu_f(f[q] * s[q] + t[q]);
+                        if (gate) {
+                            float gv[8];
+                            load8f(gate + k, gv);
 #pragma unroll
-                                for (int q = 0; q < 8; ++q) f[q] *= gv[q];
-                            }
-                            xf[rg][kc] = pack8(f);
+                            for (int q = 0; q < 8; ++q) f[q] *= gv[q];
                         }
+                        xf[rg][kc] = pack8(f);
                     }
                 }
             }
         }
 
-        f32x4_t acc[2][FN];
+        f32x4_t acc[RG][FN];
 #pragma unroll
-        for (int rg = 0; rg < 2; ++rg)
+        for (int rg = 0; rg < RG; ++rg)
 #pragma unroll
             for (int f = 0; f < FN; ++f) acc[rg][f] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -117,75 +117,88 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(const mc_gemm_rows_args 
             if (kc < kc_used) {
 #pragma unroll
                 for (int f = 0; f < FN; ++f) {
-                    if (f < fn) {
-                        bf16x8_t wf = *reinterpret_cast<const bf16x8_t*>(sW + ((size_t)(kc * FN + f) * 64 + lane) * 16);
-                        acc[0][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                            wf, *reinterpret_cast<const bf16x8_t*>(&xf[0][kc]), acc[0][f], 0, 0, 0);
-                        acc[1][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                            wf, *reinterpret_cast<const bf16x8_t*>(&xf[1][kc]), acc[1][f], 0, 0, 0);
-                    }
+                    bf16x8_t wf = *reinterpret_cast<const bf16x8_t*>(sW + ((size_t)(kc * FN + f) * 64 + lane) * 16);
+#pragma unroll
+                    for (int rg = 0; rg < RG; ++rg)
+                        acc[rg][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                            wf, *reinterpret_cast<const bf16x8_t*>(&xf[rg][kc]), acc[rg][f], 0, 0, 0);
                 }
             }
         }
 
-        // ---- epilogue per 16-row group: registers -> per-wave LDS tile -> contiguous global stores
-        const int cpr = p.N >> 3;                   // 16-byte chunks per output row
-        const int nchunks = 16 * cpr;
+        // ---- epilogue per 16-row group: registers -> per-wave LDS tile -> contiguous global stores (+ statistics)
 #pragma unroll
-        for (int rg = 0; rg < 2; ++rg) {
-            const long long mbase = g * 32 + rg * 16;
+        for (int rg = 0; rg < RG; ++rg) {
+            const long long mbase = (g * RG + rg) * 16;
             if (mbase >= p.M) break;
 #pragma unroll
             for (int f = 0; f < FN; ++f) {
-                if (f < fn) {
-                    uint2 pk = make_uint2(pack_bf2(acc[rg][f][0], acc[rg][f][1]), pack_bf2(acc[rg][f][2], acc[rg][f][3]));
-                    *reinterpret_cast<uint2*>(myC + mrow * CROW + (f * 16 + kg * 4) * 2) = pk;
-                }
+                uint2 pk = make_uint2(pack_bf2(acc[rg][f][0], acc[rg][f][1]), pack_bf2(acc[rg][f][2], acc[rg][f][3]));
+                *reinterpret_cast<uint2*>(myC + mrow * CROW + (f * 16 + kg * 4) * 2) = pk;
             }
             __builtin_amdgcn_wave_barrier();
-            if (p.stat_partials && lane * 4 < p.N) {
-                const int rows = (p.M - mbase) < 16 ? (int)(p.M - mbase) : 16;
-                for (int r = 0; r < rows; ++r) {
-                    uint2 v = *reinterpret_cast<const uint2*>(myC + r * CROW + lane * 8);
-                    float a0 = bf_lo(v.x), a1 = bf_hi(v.x), a2 = bf_lo(v.y), a3 = bf_hi(v.y);
-                    ssum[0] += a0; ssum[1] += a1; ssum[2] += a2; ssum[3] += a3;
-                    ssq[0] += a0 * a0; ssq[1] += a1 * a1; ssq[2] += a2 * a2; ssq[3] += a3 * a3;
-                }
-            }
-            for (int c = lane; c < nchunks; c += 64) {
-                int row = c / cpr, c8 = c - row * cpr;
-                long long m = mbase + row;
-                if (m < p.M) {
-                    uint4 v = *reinterpret_cast<const uint4*>(myC + row * CROW + c8 * 16);
-                    if (p.R) {
-                        float a[8], b[8];
+            if (ep_active) {
+                for (int row = rs; row < 16; row += slots) {
+                    const long long m = mbase + row;
+                    if (m < p.M) {
+                        uint4 v = *reinterpret_cast<const uint4*>(myC + row * CROW + c8 * 16);
+                        float a[8];
                         unpack8(v, a);
-                        unpack8(*reinterpret_cast<const uint4*>(p.R + m * p.ldr + c8 * 8), b);
+                        if (p.stat_partials) {          // statistics of the conv output itself (before any residual)
 #pragma unroll
-                        for (int q = 0; q < 8; ++q) a[q] += b[q];
-                        v = pack8(a);
+                            for (int q = 0; q < 8; ++q) { ssum[q] += a[q]; ssq[q] += a[q] * a[q]; }
+                        }
+                        if (p.R) {
+                            float b[8];
+                            unpack8(*reinterpret_cast<const uint4*>(p.R + m * p.ldr + c8 * 8), b);
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) a[q] += b[q];
+                            v = pack8(a);
+                        }
+                        *reinterpret_cast<uint4*>(p.C + m * p.ldc + c8 * 8) = v;
                     }
-                    *reinterpret_cast<uint4*>(p.C + m * p.ldc + c8 * 8) = v;
                 }
             }
             __builtin_amdgcn_wave_barrier();
+        }
+    };
+
+    const long long g0 = (long long)blockIdx.x * 4 + wave;
+#pragma unroll
+    for (int u = 0; u < PF; ++u)
+        if (g0 + u * gstride < ngroups) load_group(xn[u], g0 + u * gstride);
+    for (long long g = g0; g < ngroups; g += PF * gstride) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const long long gg = g + u * gstride;
+            if (gg < ngroups) {
+                uint4 xf[RG][KC];
+#pragma unroll
+                for (int rg = 0; rg < RG; ++rg)
+#pragma unroll
+                    for (int kc = 0; kc < KC; ++kc) xf[rg][kc] = xn[u][rg][kc];
+                if (gg + PF * gstride < ngroups) load_group(xn[u], gg + PF * gstride);   // in flight during PF groups of work
+                process(gg, xf);
+            }
         }
     }
 
     if (p.stat_partials) {
         __syncthreads();
-        float* red = reinterpret_cast<float*>(sC);        // [4 waves][256 cols][2]
-        if (lane * 4 < NP) {
+        float* red = reinterpret_cast<float*>(sC);        // [4 waves][64 lanes][16]
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                red[((wave * 256) + lane * 4 + q) * 2 + 0] = ssum[q];
-                red[((wave * 256) + lane * 4 + q) * 2 + 1] = ssq[q];
-            }
+        for (int q = 0; q < 8; ++q) {
+            red[(wave * 64 + lane) * 16 + q] = ep_active ? ssum[q] : 0.f;
+            red[(wave * 64 + lane) * 16 + 8 + q] = ep_active ? ssq[q] : 0.f;
         }
         __syncthreads();
         for (int c = tid; c < p.N; c += 256) {
             float s = 0.f, s2 = 0.f;
-            for (int w = 0; w < 4; ++w) { s += red[(w * 256 + c) * 2]; s2 += red[(w * 256 + c) * 2 + 1]; }
+            for (int w = 0; w < 4; ++w)
+                for (int r = 0; r < slots; ++r) {
+                    const float* e = red + (w * 64 + r * cpr + (c >> 3)) * 16 + (c & 7);
+                    s += e[0]; s2 += e[8];
+                }
             float* dst = p.stat_partials + (long long)blockIdx.x * 2 * p.N;
             dst[c] = s;
             dst[p.N + c] = s2;
@@ -195,19 +208,21 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(const mc_gemm_rows_args 
 
 template <int FN, int KC> size_t lds_bytes() {
     size_t staging = 4 * 16 * ((FN * 16 + 8) * 2);
-    size_t red = 4 * 256 * 2 * 4;
+    size_t red = 4 * 64 * 16 * 4;
     return (size_t)KC * FN * 1024 + 2 * KC * 32 * 4 + (staging > red ? staging : red);
 }
 
 template <int FN, int KC> int launch_rows(const mc_gemm_rows_args& p, int blocks, hipStream_t st) {
+    constexpr int RG = (FN >= 6 || KC >= 12) ? 1 : 2;   // wide outputs / deep K: 16 rows per iteration (register budget)
+    constexpr int PF = KC >= 8 ? 1 : 8 / KC;            // ~8-16 KB of activations in flight per wave
     size_t lds = lds_bytes<FN, KC>();
     static bool attr_set = false;
     if (lds > 64 * 1024 && !attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_rows_kernel<FN, KC>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_rows_kernel<FN, KC, PF, RG>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_rows_kernel<FN, KC>), dim3(blocks), dim3(256), lds, st, p);
+    hipLaunchKernelGGL((gemm_rows_kernel<FN, KC, PF, RG>), dim3(blocks), dim3(256), lds, st, p);
     MC_LAUNCH_CHECK();
     return MC_OK;
 }
@@ -216,21 +231,27 @@ template <int FN> int dispatch_kc(const mc_gemm_rows_args& p, int blocks, hipStr
     if (p.K <= 32) return launch_rows<FN, 1>(p, blocks, st);
     if (p.K <= 64) return launch_rows<FN, 2>(p, blocks, st);
     if (p.K <= 128) return launch_rows<FN, 4>(p, blocks, st);
-    if (p.K <= 256) return launch_rows<FN, 8>(p, blocks, st);
-    return launch_rows<FN, 12>(p, blocks, st);
+    if constexpr (FN <= 8) {
+        if (p.K <= 256) return launch_rows<FN, 8>(p, blocks, st);
+        if constexpr (FN <= 5) return launch_rows<FN, 12>(p, blocks, st);
+    }
+    mc_set_error("gemm_rows: internal: no instantiation");
+    return MC_ERR_ARG;
 }
 
 }  // namespace
 
 extern "C" int mc_gemm_rows_supported(int n, int k) {
     if (n <= 0 || k <= 0 || n > 256 || k > 384 || n % 8 || k % 8) return 0;
-    int fnp = n <= 32 ? 2 : (n <= 64 ? 4 : (n <= 128 ? 8 : 16));
+    int fn = (n + 15) / 16;
     int kcp = k <= 32 ? 1 : (k <= 64 ? 2 : (k <= 128 ? 4 : (k <= 256 ? 8 : 12)));
-    return fnp * kcp <= 64;                       // weight image <= 64 KiB of LDS
+    if (kcp == 8 && fn > 8) return 0;
+    if (kcp == 12 && fn > 5) return 0;
+    return fn * kcp <= 64;                        // weight image <= 64 KiB of LDS
 }
 
 extern "C" int mc_gemm_rows_blocks(long long m) {
-    long long groups = (m + 31) / 32;
+    long long groups = (m + 15) / 16;
     long long b = (groups + 3) / 4;
     if (b > 512) b = 512;
     if (b < 1) b = 1;
@@ -248,8 +269,22 @@ extern "C" int mc_gemm_rows_bf16(const mc_gemm_rows_args* a, void* stream) {
     MC_CHECK(!p.pro_gate || (p.pro_scale && p.pro_rows_per_img > 0), "gemm_rows: gate needs the BN prologue");
     hipStream_t st = (hipStream_t)stream;
     int blocks = mc_gemm_rows_blocks(p.M);
-    if (p.N <= 32) return dispatch_kc<2>(p, blocks, st);
-    if (p.N <= 64) return dispatch_kc<4>(p, blocks, st);
-    if (p.N <= 128) return dispatch_kc<8>(p, blocks, st);
-    return dispatch_kc<16>(p, blocks, st);
+    switch ((p.N + 15) / 16) {                     // exact fragment count: no dead accumulators, no predicated MFMAs
+        case 1: return dispatch_kc<1>(p, blocks, st);
+        case 2: return dispatch_kc<2>(p, blocks, st);
+        case 3: return dispatch_kc<3>(p, blocks, st);
+        case 4: return dispatch_kc<4>(p, blocks, st);
+        case 5: return dispatch_kc<5>(p, blocks, st);
+        case 6: return dispatch_kc<6>(p, blocks, st);
+        case 7: return dispatch_kc<7>(p, blocks, st);
+        case 8: return dispatch_kc<8>(p, blocks, st);
+        case 9: return dispatch_kc<9>(p, blocks, st);
+        case 10: return dispatch_kc<10>(p, blocks, st);
+        case 11: return dispatch_kc<11>(p, blocks, st);
+        case 12: return dispatch_kc<12>(p, blocks, st);
+        case 13: return dispatch_kc<13>(p, blocks, st);
+        case 14: return dispatch_kc<14>(p, blocks, st);
+        case 15: return dispatch_kc<15>(p, blocks, st);
+        default: return dispatch_kc<16>(p, blocks, st);
+    }
 }
