@@ -29,11 +29,23 @@ __global__ void bn_finalize_k(const float* __restrict__ partials, int rows, int 
     const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
     const int i = blockIdx.x * 16 + cl;
     double s = 0.0, s2 = 0.0;
-    if (i < c)
-        for (int r = rl; r < rows; r += 16) {
+    if (i < c) {
+        int r = rl;
+        for (; r + 7 * 16 < rows; r += 8 * 16) {           // 16 independent loads in flight per thread
+            float a[8], b[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                a[u] = partials[((long long)(r + u * 16) * 2) * c + i];
+                b[u] = partials[((long long)(r + u * 16) * 2 + 1) * c + i];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { s += (double)a[u]; s2 += (double)b[u]; }
+        }
+        for (; r < rows; r += 16) {
             s += (double)partials[((long long)r * 2) * c + i];
             s2 += (double)partials[((long long)r * 2 + 1) * c + i];
         }
+    }
     sh[0][rl][cl] = s; sh[1][rl][cl] = s2;
     __syncthreads();
     if (rl != 0 || i >= c) return;
@@ -342,11 +354,23 @@ __global__ void bn_bwd_finalize_k(const float* __restrict__ partials, int rows, 
     const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
     const int i = blockIdx.x * 16 + cl;
     double s0 = 0.0, s1 = 0.0;
-    if (i < c)
-        for (int r = rl; r < rows; r += 16) {
+    if (i < c) {
+        int r = rl;
+        for (; r + 7 * 16 < rows; r += 8 * 16) {           // 16 independent loads in flight per thread
+            float a[8], b[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                a[u] = partials[((long long)(r + u * 16) * 2) * c + i];
+                b[u] = partials[((long long)(r + u * 16) * 2 + 1) * c + i];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { s0 += (double)a[u]; s1 += (double)b[u]; }
+        }
+        for (; r < rows; r += 16) {
             s0 += (double)partials[((long long)r * 2) * c + i];
             s1 += (double)partials[((long long)r * 2 + 1) * c + i];
         }
+    }
     sh[0][rl][cl] = s0; sh[1][rl][cl] = s1;
     __syncthreads();
     if (rl != 0 || i >= c) return;
