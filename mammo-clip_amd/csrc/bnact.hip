@@ -121,9 +121,9 @@ __global__ __launch_bounds__(256) void bnact_img_reduce_k(const mc_bnact_args p)
             float s[8], t[8];
             load8f(p.scale + v * 8, s);
             load8f(p.shift + v * 8, t);
-            for (long long r = (long long)blockIdx.y * rm.rpb + rm.rl; r < p.hw; r += (long long)gridDim.y * rm.rpb) {
+            auto body = [&](const uint4& xv, const uint4& gv) {
                 float f[8];
-                unpack8(*reinterpret_cast<const uint4*>(xb + r * p.c + v * 8), f);
+                unpack8(xv, f);
                 if (MODE == 0) {
 #pragma unroll
                     for (int q = 0; q < 8; ++q) {
@@ -132,14 +132,30 @@ __global__ __launch_bounds__(256) void bnact_img_reduce_k(const mc_bnact_args p)
                     }
                 } else {
                     float g[8];
-                    unpack8(*reinterpret_cast<const uint4*>(gb + r * p.c + v * 8), g);
+                    unpack8(gv, g);
 #pragma unroll
                     for (int q = 0; q < 8; ++q) {
                         float z = f[q] * s[q] + t[q];
                         acc[q] += g[q] * (p.act == 1 ? silu_f(z) : z);
                     }
                 }
+            };
+            const long long rstride = (long long)gridDim.y * rm.rpb;
+            const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
+            long long r = (long long)blockIdx.y * rm.rpb + rm.rl;
+            for (; r + 3 * rstride < p.hw; r += 4 * rstride) {      // four independent rows in flight
+                uint4 xv[4], gv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    xv[u] = *reinterpret_cast<const uint4*>(xb + (r + u * rstride) * p.c + v * 8);
+                    gv[u] = (MODE == 1) ? *reinterpret_cast<const uint4*>(gb + (r + u * rstride) * p.c + v * 8) : z4;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) body(xv[u], gv[u]);
             }
+            for (; r < p.hw; r += rstride)
+                body(*reinterpret_cast<const uint4*>(xb + r * p.c + v * 8),
+                     (MODE == 1) ? *reinterpret_cast<const uint4*>(gb + r * p.c + v * 8) : z4);
         }
 #pragma unroll
         for (int q = 0; q < 8; ++q) red[threadIdx.x * 8 + q] = acc[q];
@@ -313,7 +329,18 @@ __global__ __launch_bounds__(256) void bnact_bwd_k(const mc_bnact_args p) {
             };
             const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
             long long r = (long long)blockIdx.x * rm.rpb + rm.rl;
-            for (; r + rstride < p.hw; r += 2 * rstride) {          // two independent rows in flight
+            if constexpr (APPLY)                                     // (the reduce variant has no registers to spare for this)
+            for (; r + 3 * rstride < p.hw; r += 4 * rstride) {      // four independent rows (8 loads) in flight
+                uint4 xv[4], gv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    xv[u] = *reinterpret_cast<const uint4*>(xb + (r + u * rstride) * p.c + v * 8);
+                    gv[u] = gb ? *reinterpret_cast<const uint4*>(gb + (r + u * rstride) * p.c + v * 8) : z4;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) body(r + u * rstride, xv[u], gv[u]);
+            }
+            for (; r + rstride < p.hw; r += 2 * rstride) {
                 const long long r2 = r + rstride;
                 uint4 x0 = *reinterpret_cast<const uint4*>(xb + r * p.c + v * 8);
                 uint4 x1 = *reinterpret_cast<const uint4*>(xb + r2 * p.c + v * 8);
