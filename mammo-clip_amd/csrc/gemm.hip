@@ -59,7 +59,7 @@ __device__ __forceinline__ bf16x8_t tr_frag(const unsigned char* tile, int rs, i
 constexpr int tr_pad_bytes(int bx) { return bx >= 128 ? 48 : (bx >= 64 ? 16 : 32); }   // conflict-free tr-read strides
 
 template <int BM, int BN, int BK, int WGM, int WGN, int LAY, int PRO, bool CF32>
-__global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8) ? 4 : 2) void gemm_kernel(const mc_gemm_args p) {
+__global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8) ? 4 : 2) void gemm_kernel(const mc_gemm_args p, const int gm) {
     // 8-wave tiles are held to <= 128 VGPRs so two workgroups (16 waves) fit a CU
     constexpr int NT = WGM * WGN * 64;                // threads per workgroup (4 or 8 waves)
     constexpr bool AKM = (LAY == 2), BKM = (LAY >= 1);
@@ -81,7 +81,18 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8) ? 4 : 2) void gemm
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave % WGN;
-    const int n0 = blockIdx.x * BN;
+    // XCD-aware tile placement: workgroups are dealt round-robin to the 8 XCDs by linear id, each with its own L2.
+    // All column tiles of one row block get consecutive slots on the SAME XCD, so the activation rows are fetched
+    // from HBM once per row block and the other column tiles hit that XCD's L2 (grid.y is padded to a multiple of 8).
+    // Only when there are enough row workgroups to keep the XCDs balanced (gm is then a multiple of 8).
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (gm >= 16) {
+        const int lin = blockIdx.y * gridDim.x + blockIdx.x;
+        bx = (lin >> 3) % gridDim.x;
+        by = ((lin >> 3) / gridDim.x) * 8 + (lin & 7);
+    }
+    if (by >= gm) return;
+    const int n0 = bx * BN;
 
     // batch / split decomposition of blockIdx.z
     const int split = blockIdx.z % p.splits;
@@ -327,10 +338,10 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8) ? 4 : 2) void gemm
     // registers (global loads are issued two steps ahead of the LDS store that consumes them), across K tiles AND
     // across row blocks, so HBM/L2 latency is covered even when a row block has only one or two K tiles.
     const long long ktn = kbeg < kend ? (kend - kbeg + BK - 1) / BK : 0;
-    const long long my_mt = blockIdx.y < mtiles ? (mtiles - blockIdx.y + gridDim.y - 1) / gridDim.y : 0;
+    const long long my_mt = by < mtiles ? (mtiles - by + gm - 1) / gm : 0;
     const long long total = my_mt * ktn;
     if (ktn == 0) {
-        for (long long mt = blockIdx.y; mt < mtiles; mt += gridDim.y) {
+        for (long long mt = by; mt < mtiles; mt += gm) {
 #pragma unroll
             for (int i = 0; i < FM; ++i)
 #pragma unroll
@@ -339,10 +350,10 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8) ? 4 : 2) void gemm
         }
     } else {
         // (m0, k0) of flat step i, advanced incrementally (no divisions in the loop)
-        long long pm0 = (long long)blockIdx.y * BM, pk0 = kbeg;          // position of the NEXT tile to load
+        long long pm0 = (long long)by * BM, pk0 = kbeg;                  // position of the NEXT tile to load
         auto advance = [&]() {
             pk0 += BK;
-            if (pk0 >= kend) { pk0 = kbeg; pm0 += (long long)gridDim.y * BM; }
+            if (pk0 >= kend) { pk0 = kbeg; pm0 += (long long)gm * BM; }
         };
         long long cm0 = pm0, ck0 = pk0;                                  // position of the tile being consumed
         if (0 < total) { load_tiles(ra0, rb0, pm0, pk0); advance(); }
@@ -369,7 +380,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8) ? 4 : 2) void gemm
             const bool last_k = ck0 + BK >= kend;
             if (last_k) epilogue(cm0);
             ck0 += BK;
-            if (last_k) { ck0 = kbeg; cm0 += (long long)gridDim.y * BM; }
+            if (last_k) { ck0 = kbeg; cm0 += (long long)gm * BM; }
         }
     }
 
@@ -391,7 +402,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8) ? 4 : 2) void gemm
             for (int r = 0; r < RPP; ++r) { s += red[(r * BN + c) * 2]; s2 += red[(r * BN + c) * 2 + 1]; }
             int n = n0 + c;
             if (n < p.N) {
-                float* dst = p.stat_partials + (long long)blockIdx.y * 2 * p.N;
+                float* dst = p.stat_partials + (long long)by * 2 * p.N;
                 dst[n] = s;
                 dst[p.N + n] = s2;
             }
@@ -429,7 +440,7 @@ template <int BM, int BN, int BK, int WGM, int WGN, int LAY, int PRO, bool CF32>
 int launch(const mc_gemm_args& p, int grid_m, hipStream_t st) {
     constexpr int NT = WGM * WGN * 64;
     dim3 grid(mc_div_up(p.N, BN), grid_m, p.batch * p.splits);
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, WGM, WGN, LAY, PRO, CF32>), grid, dim3(NT), 0, st, p);
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, WGM, WGN, LAY, PRO, CF32>), grid, dim3(NT), 0, st, p, grid_m);
     MC_LAUNCH_CHECK();
     if (p.splits > 1 && p.splitk_ws) {
         long long mn = p.M * p.N;
@@ -461,7 +472,9 @@ extern "C" int mc_gemm_stat_rows(const mc_gemm_args* a) {
     // number of partial rows the launch will write ( = gridDim.y )
     long long mtiles = (a->M + 127) / 128;
     long long cap = a->max_grid_m > 0 ? a->max_grid_m : 512;
-    return (int)(mtiles < cap ? mtiles : cap);
+    int gm = (int)(mtiles < cap ? mtiles : cap);
+    if (gm >= 16) gm &= ~7;                             // XCD-aware placement (see gemm_kernel) wants a multiple of 8
+    return gm;
 }
 
 extern "C" int mc_gemm_bf16(const mc_gemm_args* a, void* stream) {
@@ -498,6 +511,7 @@ extern "C" int mc_gemm_bf16(const mc_gemm_args* a, void* stream) {
         if (want < 1) want = 1;
         grid_m = (int)(mtiles < want ? mtiles : want);
     }
+    if (grid_m >= 16) grid_m &= ~7;                     // persistent over row blocks: any count works; 8 | grid_m balances the XCDs
     const int lay = p.a_kmajor ? 2 : (p.b_kmajor ? 1 : 0);
     if (lay == 0) {
         if (p.c_f32) return dispatch_tile<0, 0, true>(p, grid_m, st);
