@@ -91,12 +91,23 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8) ? 4 : 2) void gemm
         bx = (lin >> 3) % gridDim.x;
         by = ((lin >> 3) / gridDim.x) * 8 + (lin & 7);
     }
+    int bzz = blockIdx.z;
+    if (gm < 16 && p.batch == 1 && (gridDim.z & 7) == 0 && gridDim.z >= 16) {
+        // split-K (weight gradients): all output tiles of one K split read the same slab of both operands -> one
+        // XCD per split (splits dealt round-robin to the XCDs)
+        const int tiles = gridDim.x * gridDim.y;
+        const int lin = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        const int t = (lin >> 3) % tiles;
+        bx = t % gridDim.x;
+        by = t / gridDim.x;
+        bzz = ((lin >> 3) / tiles) * 8 + (lin & 7);
+    }
     if (by >= gm) return;
     const int n0 = bx * BN;
 
-    // batch / split decomposition of blockIdx.z
-    const int split = blockIdx.z % p.splits;
-    const int bz = blockIdx.z / p.splits;
+    // batch / split decomposition of the z index
+    const int split = bzz % p.splits;
+    const int bz = bzz / p.splits;
     const int b1 = bz / p.nb2, b2 = bz % p.nb2;
     const bf16_t* __restrict__ A = p.A + b1 * p.sA1 + b2 * p.sA2;
     const bf16_t* __restrict__ B = p.B + b1 * p.sB1 + b2 * p.sB2;
