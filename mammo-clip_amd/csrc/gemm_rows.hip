@@ -21,7 +21,7 @@ namespace {
 // FN = output fragments (exact: ceil(N/16)), KC = 32-wide K chunks (padded), RG = 16-row groups per wave iteration,
 // PF = iterations in flight per wave
 template <int FN, int KC, int PF, int RG>
-__global__ __launch_bounds__(256, 2) void gemm_rows_kernel(const mc_gemm_rows_args p) {
+__global__ __launch_bounds__(256, 2) void gemm_rows_kernel(const mc_gemm_rows_args p, const int nblocks, const int ntiles) {
     constexpr int NP = FN * 16;                    // padded output width
     constexpr int CROW = (NP + 8) * 2;             // staging row bytes
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -30,13 +30,21 @@ __global__ __launch_bounds__(256, 2) void gemm_rows_kernel(const mc_gemm_rows_ar
     float* sShift = sScale + KC * 32;
     unsigned char* sC = reinterpret_cast<unsigned char*>(sShift + KC * 32);   // [4 waves][16][CROW]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // Wide outputs (N > 256, K small) are split into column tiles of FN*16: every tile's workgroup keeps ITS slice of
+    // the weights in LDS and streams the same rows.  The column tiles of one row-block index get consecutive slots on
+    // the same XCD (workgroup id % 8), so the activation rows come from HBM once and from that XCD's L2 afterwards.
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int nt = slot % ntiles, bxr = (slot / ntiles) * 8 + xcd;
+    if (bxr >= nblocks) return;
+    const int n0 = nt * NP;
+    const int nw = p.N - n0 < NP ? p.N - n0 : NP;          // width of this column tile
     const int kc_used = (p.K + 31) >> 5;
     const bool has_pro = p.pro_scale != nullptr;
 
     // ---- stage weights as MFMA A-operand fragments: frag (kc, f), lane (i = l&15, kg = l>>4) = W[f*16+i][kc*32+kg*8 ..+8]
     for (int idx = tid; idx < KC * FN * 64; idx += 256) {
         int l = idx & 63, f = (idx >> 6) % FN, kc = (idx >> 6) / FN;
-        int n = f * 16 + (l & 15), k = kc * 32 + (l >> 4) * 8;
+        int n = n0 + f * 16 + (l & 15), k = kc * 32 + (l >> 4) * 8;
         uint4 v = make_uint4(0u, 0u, 0u, 0u);
         if (n < p.N && k < p.K) v = *reinterpret_cast<const uint4*>(p.W + (long long)n * p.ldw + k);
         *reinterpret_cast<uint4*>(sW + (size_t)idx * 16) = v;
@@ -51,10 +59,10 @@ __global__ __launch_bounds__(256, 2) void gemm_rows_kernel(const mc_gemm_rows_ar
     unsigned char* myC = sC + wave * 16 * CROW;
     const int mrow = lane & 15, kg = lane >> 4;
     const long long ngroups = (p.M + RG * 16 - 1) / (RG * 16);
-    const long long gstride = (long long)gridDim.x * 4;
+    const long long gstride = (long long)nblocks * 4;
     // epilogue mapping: lane = (row slot, 16-byte column chunk); a lane always handles the same 8 output columns, so
     // the BatchNorm statistics of the stored tensor accumulate in 16 registers inside the store loop
-    const int cpr = p.N >> 3;                       // 16-byte chunks per output row (<= 32)
+    const int cpr = nw >> 3;                        // 16-byte chunks per output row of this tile (<= 32)
     const int slots = 64 / cpr;                     // rows written concurrently by one wave
     const int c8 = lane % cpr, rs = lane / cpr;
     const bool ep_active = rs < slots;
@@ -150,12 +158,12 @@ __global__ __launch_bounds__(256, 2) void gemm_rows_kernel(const mc_gemm_rows_ar
                         }
                         if (p.R) {
                             float b[8];
-                            unpack8(*reinterpret_cast<const uint4*>(p.R + m * p.ldr + c8 * 8), b);
+                            unpack8(*reinterpret_cast<const uint4*>(p.R + m * p.ldr + n0 + c8 * 8), b);
 #pragma unroll
                             for (int q = 0; q < 8; ++q) a[q] += b[q];
                             v = pack8(a);
                         }
-                        *reinterpret_cast<uint4*>(p.C + m * p.ldc + c8 * 8) = v;
+                        *reinterpret_cast<uint4*>(p.C + m * p.ldc + n0 + c8 * 8) = v;
                     }
                 }
             }
@@ -163,7 +171,7 @@ __global__ __launch_bounds__(256, 2) void gemm_rows_kernel(const mc_gemm_rows_ar
         }
     };
 
-    const long long g0 = (long long)blockIdx.x * 4 + wave;
+    const long long g0 = (long long)bxr * 4 + wave;
 #pragma unroll
     for (int u = 0; u < PF; ++u)
         if (g0 + u * gstride < ngroups) load_group(xn[u], g0 + u * gstride);
@@ -192,14 +200,14 @@ __global__ __launch_bounds__(256, 2) void gemm_rows_kernel(const mc_gemm_rows_ar
             red[(wave * 64 + lane) * 16 + 8 + q] = ep_active ? ssq[q] : 0.f;
         }
         __syncthreads();
-        for (int c = tid; c < p.N; c += 256) {
+        for (int c = tid; c < nw; c += 256) {
             float s = 0.f, s2 = 0.f;
             for (int w = 0; w < 4; ++w)
                 for (int r = 0; r < slots; ++r) {
                     const float* e = red + (w * 64 + r * cpr + (c >> 3)) * 16 + (c & 7);
                     s += e[0]; s2 += e[8];
                 }
-            float* dst = p.stat_partials + (long long)blockIdx.x * 2 * p.N;
+            float* dst = p.stat_partials + (long long)bxr * 2 * p.N + n0;
             dst[c] = s;
             dst[p.N + c] = s2;
         }
@@ -214,7 +222,7 @@ template <int FN, int KC> size_t lds_bytes() {
 
 template <int FN, int KC> int launch_rows(const mc_gemm_rows_args& p, int blocks, hipStream_t st) {
     constexpr int RG = (FN >= 6 || KC >= 12) ? 1 : 2;   // wide outputs / deep K: 16 rows per iteration (register budget)
-    constexpr int PF = KC >= 8 ? 1 : 8 / KC;            // ~8-16 KB of activations in flight per wave
+    constexpr int PF = KC >= 6 ? 1 : 8 / KC;            // ~8-16 KB of activations in flight per wave
     size_t lds = lds_bytes<FN, KC>();
     static bool attr_set = false;
     if (lds > 64 * 1024 && !attr_set) {
@@ -222,7 +230,8 @@ template <int FN, int KC> int launch_rows(const mc_gemm_rows_args& p, int blocks
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_rows_kernel<FN, KC, PF, RG>), dim3(blocks), dim3(256), lds, st, p);
+    const int ntiles = (p.N + FN * 16 - 1) / (FN * 16);
+    hipLaunchKernelGGL((gemm_rows_kernel<FN, KC, PF, RG>), dim3((blocks + 7) / 8 * 8 * ntiles), dim3(256), lds, st, p, blocks, ntiles);
     MC_LAUNCH_CHECK();
     return MC_OK;
 }
@@ -231,6 +240,9 @@ template <int FN> int dispatch_kc(const mc_gemm_rows_args& p, int blocks, hipStr
     if (p.K <= 32) return launch_rows<FN, 1>(p, blocks, st);
     if (p.K <= 64) return launch_rows<FN, 2>(p, blocks, st);
     if (p.K <= 128) return launch_rows<FN, 4>(p, blocks, st);
+    if constexpr (FN == 8) {
+        if (p.K <= 192) return launch_rows<FN, 6>(p, blocks, st);     // 48 KiB weight slice: two workgroups per CU
+    }
     if constexpr (FN <= 8) {
         if (p.K <= 256) return launch_rows<FN, 8>(p, blocks, st);
         if constexpr (FN <= 5) return launch_rows<FN, 12>(p, blocks, st);
@@ -242,7 +254,8 @@ template <int FN> int dispatch_kc(const mc_gemm_rows_args& p, int blocks, hipStr
 }  // namespace
 
 extern "C" int mc_gemm_rows_supported(int n, int k) {
-    if (n <= 0 || k <= 0 || n > 256 || k > 384 || n % 8 || k % 8) return 0;
+    if (n <= 0 || k <= 0 || k > 384 || n % 8 || k % 8) return 0;
+    if (n > 256) return k <= 256;                  // column tiles of 128 (FN = 8), weights slice <= 64 KiB of LDS
     int fn = (n + 15) / 16;
     int kcp = k <= 32 ? 1 : (k <= 64 ? 2 : (k <= 128 ? 4 : (k <= 256 ? 8 : 12)));
     if (kcp == 8 && fn > 8) return 0;
@@ -269,6 +282,7 @@ extern "C" int mc_gemm_rows_bf16(const mc_gemm_rows_args* a, void* stream) {
     MC_CHECK(!p.pro_gate || (p.pro_scale && p.pro_rows_per_img > 0), "gemm_rows: gate needs the BN prologue");
     hipStream_t st = (hipStream_t)stream;
     int blocks = mc_gemm_rows_blocks(p.M);
+    if (p.N > 256) return dispatch_kc<8>(p, blocks, st);   // wide output: 128-column tiles
     switch ((p.N + 15) / 16) {                     // exact fragment count: no dead accumulators, no predicated MFMAs
         case 1: return dispatch_kc<1>(p, blocks, st);
         case 2: return dispatch_kc<2>(p, blocks, st);

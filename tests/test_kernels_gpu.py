@@ -142,7 +142,8 @@ def test_gemm_batched_attention_shapes():
 
 
 @pytest.mark.parametrize("M,N,K", [(10000, 144, 24), (9001, 24, 48), (20000, 240, 40), (8200, 40, 240), (8192, 64, 384),
-                                   (30000, 16, 16), (12345, 64, 384), (9000, 96, 16)])
+                                   (30000, 16, 16), (12345, 64, 384), (9000, 96, 16),
+                                   (9000, 768, 128), (10001, 1056, 176), (8300, 264, 40)])   # wide outputs: 128-column tiles
 def test_gemm_rows_streaming(M, N, K):
     """row-streaming kernel (full-row ownership, LDS-resident weights): fwd with stats + residual, prologue, dgrad"""
     x, w = rnd(M, K, seed=82), rnd(N, K, seed=83, scale=K ** -0.5)
