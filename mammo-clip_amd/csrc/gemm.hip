@@ -17,11 +17,16 @@
 // The bf16 epilogue goes back through LDS so global stores are 16-byte row segments, and can emit per-column
 // sum / sum-of-squares partials (training-mode BatchNorm statistics of the conv output).
 #include "common.cuh"
+#include <type_traits>
 #include "../../include/mammoclip_hip.h"
 
 namespace {
 
 __device__ __forceinline__ uint4 zero4() { return make_uint4(0u, 0u, 0u, 0u); }
+// component-wise (a select between two uint4 STRUCTS is lowered through scratch memory)
+__device__ __forceinline__ uint4 keep4(bool ok, const uint4& a) {
+    return make_uint4(ok ? a.x : 0u, ok ? a.y : 0u, ok ? a.z : 0u, ok ? a.w : 0u);
+}
 
 // fused prologue on a vector of 8 channels [ch0, ch0+8) of pixel `pix`:
 //   v' = silu(v * scale[c] + shift[c]) * gate[(pix / rows_per_img) * nch + c]
@@ -57,6 +62,13 @@ __device__ __forceinline__ bf16x8_t tr_frag(const unsigned char* tile, int rs, i
     return __builtin_bit_cast(bf16x8_t, v);
 }
 constexpr int tr_pad_bytes(int bx) { return bx >= 128 ? 48 : (bx >= 64 ? 16 : 32); }   // conflict-free tr-read strides
+
+#ifdef GEMM_PROF
+__device__ unsigned long long g_gemm_prof[8];      // developer phase profile (scripts/gemmbench.hip)
+#define GPROF(i) do { unsigned long long t_ = __builtin_amdgcn_s_memtime(); pacc[i] += t_ - tprof; tprof = t_; } while (0)
+#else
+#define GPROF(i)
+#endif
 
 template <int BM, int BN, int BK, int WGM, int WGN, int LAY, int PRO, bool CF32>
 __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8) ? 4 : 2) void gemm_kernel(const mc_gemm_args p, const int gm) {
@@ -129,120 +141,133 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8) ? 4 : 2) void gemm
 
     uint4 ra0[A_REGS], rb0[B_REGS], ra1[A_REGS], rb1[B_REGS];   // two named register stages (stay in VGPRs)
 
-    // ---- global -> registers.  full = tile entirely inside the matrices: no per-chunk predication.
-    auto load_tiles = [&](uint4 (&ra)[A_REGS], uint4 (&rb)[B_REGS], long long m0, long long k0) {
-        const bool full = n_full && (m0 + BM <= p.M) && (k0 + BK <= kend);
-        if (!AKM) {
+    // ---- global -> registers.  Every load is unconditional (chunks outside the matrices read a clamped, valid address
+    // and are zeroed when stored), so the loads of a tile issue back to back with nothing to wait for in between.
+    // Per-thread chunk offsets are constant over the tiles: interior tiles add them to a scalar tile base.
+    unsigned offA[A_REGS], offB[B_REGS];
 #pragma unroll
-            for (int i = 0; i < A_REGS; ++i) {
-                int c = tid + i * NT;
-                int row = c / KCH, kc = c % KCH;
-                long long m = m0 + row, k = k0 + kc * 8;
-                if (full) ra[i] = *reinterpret_cast<const uint4*>(A + m * p.lda + k);
-                else {
-                    uint4 v = zero4();
-                    if (c < BM * KCH && m < p.M && k < kend) v = *reinterpret_cast<const uint4*>(A + m * p.lda + k);
-                    ra[i] = v;
-                }
-            }
-        } else {
+    for (int i = 0; i < A_REGS; ++i) {
+        const int c = tid + i * NT;
+        offA[i] = AKM ? (unsigned)((c / (BM / 8)) * p.lda + (c % (BM / 8)) * 8) : (unsigned)((c / KCH) * p.lda + (c % KCH) * 8);
+    }
 #pragma unroll
-            for (int i = 0; i < A_REGS; ++i) {
-                int c = tid + i * NT;
-                int xc = c % (BM / 8), kr = c / (BM / 8);
-                long long m = m0 + xc * 8, k = k0 + kr;
-                uint4 v = zero4();
-                if (c < BK * (BM / 8) && m < p.M && k < kend) v = *reinterpret_cast<const uint4*>(A + k * p.lda + m);
-                ra[i] = v;
-            }
+    for (int i = 0; i < B_REGS; ++i) {
+        const int c = tid + i * NT;
+        offB[i] = BKM ? (unsigned)((c / (BN / 8)) * p.ldb + (c % (BN / 8)) * 8) : (unsigned)((c / KCH) * p.ldb + (c % KCH) * 8);
+    }
+    auto tile_full = [&](long long m0, long long k0) __attribute__((always_inline)) { return n_full && (m0 + BM <= p.M) && (k0 + BK <= kend); };
+    auto load_tiles = [&](uint4 (&ra)[A_REGS], uint4 (&rb)[B_REGS], long long m0, long long k0) __attribute__((always_inline)) {
+        constexpr bool A_ALL = (AKM ? BK * (BM / 8) : BM * KCH) % NT == 0;     // every thread's chunks lie inside the tile
+        constexpr bool B_ALL = (BKM ? BK * (BN / 8) : BN * KCH) % NT == 0;
+        if (tile_full(m0, k0) && A_ALL && B_ALL) {
+            const bf16_t* ab = AKM ? A + k0 * p.lda + m0 : A + m0 * p.lda + k0;
+            const bf16_t* bb = BKM ? B + k0 * p.ldb + n0 : B + (long long)n0 * p.ldb + k0;
+#pragma unroll
+            for (int i = 0; i < A_REGS; ++i) ra[i] = *reinterpret_cast<const uint4*>(ab + offA[i]);
+#pragma unroll
+            for (int i = 0; i < B_REGS; ++i) rb[i] = *reinterpret_cast<const uint4*>(bb + offB[i]);
+            return;
         }
-        if (!BKM) {
 #pragma unroll
-            for (int i = 0; i < B_REGS; ++i) {
-                int c = tid + i * NT;
-                int row = c / KCH, kc = c % KCH;
-                long long n = n0 + row, k = k0 + kc * 8;
-                if (full && BN * KCH >= NT) rb[i] = *reinterpret_cast<const uint4*>(B + n * p.ldb + k);
-                else {
-                    uint4 v = zero4();
-                    if (c < BN * KCH && n < p.N && k < kend) v = *reinterpret_cast<const uint4*>(B + n * p.ldb + k);
-                    rb[i] = v;
-                }
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < B_REGS; ++i) {
-                int c = tid + i * NT;
-                int xc = c % (BN / 8), kr = c / (BN / 8);
-                long long n = n0 + xc * 8, k = k0 + kr;
-                uint4 v = zero4();
-                if (c < BK * (BN / 8) && n < p.N && k < kend) v = *reinterpret_cast<const uint4*>(B + k * p.ldb + n);
-                rb[i] = v;
-            }
+        for (int i = 0; i < A_REGS; ++i) {
+            const int c = tid + i * NT;
+            long long m, k;
+            if (AKM) { m = m0 + (c % (BM / 8)) * 8; k = k0 + c / (BM / 8); }
+            else { m = m0 + c / KCH; k = k0 + (c % KCH) * 8; }
+            if (m >= p.M) m = AKM ? 0 : p.M - 1;
+            if (k >= kend) k = k0;
+            ra[i] = *reinterpret_cast<const uint4*>(AKM ? A + k * p.lda + m : A + m * p.lda + k);
         }
+#pragma unroll
+        for (int i = 0; i < B_REGS; ++i) {
+            const int c = tid + i * NT;
+            long long n, k;
+            if (BKM) { n = n0 + (c % (BN / 8)) * 8; k = k0 + c / (BN / 8); }
+            else { n = n0 + c / KCH; k = k0 + (c % KCH) * 8; }
+            if (n >= p.N) n = BKM ? 0 : p.N - 1;
+            if (k >= kend) k = k0;
+            rb[i] = *reinterpret_cast<const uint4*>(BKM ? B + k * p.ldb + n : B + n * p.ldb + k);
+        }
+    };
+    // validity of chunk i of a tile (only consulted for tiles that are not interior)
+    auto a_valid = [&](int i, long long m0, long long k0) __attribute__((always_inline)) {
+        const int c = tid + i * NT;
+        const long long m = AKM ? m0 + (c % (BM / 8)) * 8 : m0 + c / KCH;
+        const long long k = AKM ? k0 + c / (BM / 8) : k0 + (c % KCH) * 8;
+        return m < p.M && k < kend;
+    };
+    auto b_valid = [&](int i, long long k0) __attribute__((always_inline)) {
+        const int c = tid + i * NT;
+        const long long n = BKM ? n0 + (c % (BN / 8)) * 8 : n0 + c / KCH;
+        const long long k = BKM ? k0 + c / (BN / 8) : k0 + (c % KCH) * 8;
+        return n < p.N && k < kend;
     };
 
     // ---- registers -> LDS (the fused BN+SiLU(+gate) prologue is applied here, after the loads have landed).
     // k-contiguous operands: [x][BK] rows (padded), read with ds_read_b128.  k-major operands: [BK][x] rows exactly
     // as loaded (16-byte stores), read with the transpose-read.
-    auto store_tiles = [&](const uint4 (&ra)[A_REGS], const uint4 (&rb)[B_REGS], int buf, long long m0, long long k0) {
+    auto store_tiles = [&](const uint4 (&ra)[A_REGS], const uint4 (&rb)[B_REGS], int buf, long long m0, long long k0) __attribute__((always_inline)) {
         unsigned char* sA = smem + buf * STAGE_BYTES;
         unsigned char* sB = sA + A_BYTES;
-        if (!AKM) {
-#pragma unroll
-            for (int i = 0; i < A_REGS; ++i) {
-                int c = tid + i * NT;
-                if (c < BM * KCH) {
-                    int row = c / KCH, kc = c % KCH;
-                    uint4 v = ra[i];
-                    if (PRO == 1) {
-                        long long m = m0 + row, k = k0 + kc * 8;
-                        if (m < p.M && k < kend) v = apply_prologue(v, p, m, (int)k);
+        const bool full = tile_full(m0, k0);
+        // chunk index as a compile-time constant (the prologue makes the body large enough that a plain unrolled loop
+        // is not always unrolled, and a runtime index would push the register stage into scratch)
+        auto store_a = [&](auto ic) __attribute__((always_inline)) {
+            constexpr int i = decltype(ic)::value;
+            if constexpr (i < A_REGS) {
+                const int c = tid + i * NT;
+                if (c < (AKM ? BK * (BM / 8) : BM * KCH)) {
+                    uint4 v = keep4(full || a_valid(i, m0, k0), ra[i]);
+                    if (!AKM) {
+                        const int row = c / KCH, kc = c % KCH;
+                        if (PRO == 1) {
+                            const long long m = m0 + row, k = k0 + kc * 8;
+                            if (m < p.M && k < kend) v = apply_prologue(v, p, m, (int)k);
+                        }
+                        *reinterpret_cast<uint4*>(sA + row * ROWB + kc * 16) = v;
+                    } else {
+                        const int xc = c % (BM / 8), kr = c / (BM / 8);
+                        *reinterpret_cast<uint4*>(sA + kr * RSA + xc * 16) = v;
                     }
-                    *reinterpret_cast<uint4*>(sA + row * ROWB + kc * 16) = v;
                 }
             }
-        } else {
-#pragma unroll
-            for (int i = 0; i < A_REGS; ++i) {
-                int c = tid + i * NT;
-                if (c < BK * (BM / 8)) {
-                    int xc = c % (BM / 8), kr = c / (BM / 8);
-                    *reinterpret_cast<uint4*>(sA + kr * RSA + xc * 16) = ra[i];
-                }
-            }
-        }
-        if (!BKM) {
-#pragma unroll
-            for (int i = 0; i < B_REGS; ++i) {
-                int c = tid + i * NT;
-                if (c < BN * KCH) {
-                    int row = c / KCH, kc = c % KCH;
-                    *reinterpret_cast<uint4*>(sB + row * ROWB + kc * 16) = rb[i];
-                }
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < B_REGS; ++i) {
-                int c = tid + i * NT;
-                if (c < BK * (BN / 8)) {
-                    int xc = c % (BN / 8), kr = c / (BN / 8);
-                    uint4 v = rb[i];
-                    if (PRO == 2) {
-                        long long n = n0 + xc * 8, k = k0 + kr;
-                        if (n < p.N && k < kend) v = apply_prologue(v, p, k, (int)n);
+        };
+        auto store_b = [&](auto ic) __attribute__((always_inline)) {
+            constexpr int i = decltype(ic)::value;
+            if constexpr (i < B_REGS) {
+                const int c = tid + i * NT;
+                if (c < (BKM ? BK * (BN / 8) : BN * KCH)) {
+                    uint4 v = keep4(full || b_valid(i, k0), rb[i]);
+                    if (!BKM) {
+                        const int row = c / KCH, kc = c % KCH;
+                        *reinterpret_cast<uint4*>(sB + row * ROWB + kc * 16) = v;
+                    } else {
+                        const int xc = c % (BN / 8), kr = c / (BN / 8);
+                        if (PRO == 2) {
+                            const long long n = n0 + xc * 8, k = k0 + kr;
+                            if (n < p.N && k < kend) v = apply_prologue(v, p, k, (int)n);
+                        }
+                        *reinterpret_cast<uint4*>(sB + kr * RSB + xc * 16) = v;
                     }
-                    *reinterpret_cast<uint4*>(sB + kr * RSB + xc * 16) = v;
                 }
             }
-        }
+        };
+        static_assert(A_REGS <= 8 && B_REGS <= 8, "chunk lists below cover 8 per operand");
+        store_a(std::integral_constant<int, 0>{}); store_a(std::integral_constant<int, 1>{});
+        store_a(std::integral_constant<int, 2>{}); store_a(std::integral_constant<int, 3>{});
+        store_a(std::integral_constant<int, 4>{}); store_a(std::integral_constant<int, 5>{});
+        store_a(std::integral_constant<int, 6>{}); store_a(std::integral_constant<int, 7>{});
+        store_b(std::integral_constant<int, 0>{}); store_b(std::integral_constant<int, 1>{});
+        store_b(std::integral_constant<int, 2>{}); store_b(std::integral_constant<int, 3>{});
+        store_b(std::integral_constant<int, 4>{}); store_b(std::integral_constant<int, 5>{});
+        store_b(std::integral_constant<int, 6>{}); store_b(std::integral_constant<int, 7>{});
     };
 
     f32x4_t acc[FM][FN];
 
     // operands are SWAPPED in the MFMA (D = Bfrag . Afrag^T) so that a lane ends up with 4 consecutive
     // output COLUMNS of one output row: 8-byte LDS / 16-byte global stores in the epilogue instead of scalars.
-    auto compute = [&](int buf) {
+    auto compute = [&](int buf) __attribute__((always_inline)) {
         const unsigned char* sA = smem + buf * STAGE_BYTES;
         const unsigned char* sB = sA + A_BYTES;
 #pragma unroll
@@ -268,7 +293,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8) ? 4 : 2) void gemm
     };
     // acc[i][j][r]: row m = wm*WM + i*16 + (lane & 15), col n = wn*WN + j*16 + (lane >> 4)*4 + r
 
-    auto epilogue = [&](const long long m0) {
+    auto epilogue = [&](const long long m0) __attribute__((always_inline)) {
         __syncthreads();   // all fragment reads done before smem is reused by the epilogue
         const float alpha = p.alpha;
         const int mrow = wm * WM + (lane & 15);
@@ -362,39 +387,64 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8) ? 4 : 2) void gemm
     } else {
         // (m0, k0) of flat step i, advanced incrementally (no divisions in the loop)
         long long pm0 = (long long)by * BM, pk0 = kbeg;                  // position of the NEXT tile to load
-        auto advance = [&]() {
+        auto advance = [&]() __attribute__((always_inline)) {
             pk0 += BK;
             if (pk0 >= kend) { pk0 = kbeg; pm0 += (long long)gm * BM; }
         };
         long long cm0 = pm0, ck0 = pk0;                                  // position of the tile being consumed
         if (0 < total) { load_tiles(ra0, rb0, pm0, pk0); advance(); }
         if (1 < total) { load_tiles(ra1, rb1, pm0, pk0); advance(); }
-        int buf = 0, sl = 0;
-        for (long long i = 0; i < total; ++i) {
+        int buf = 0;
+#ifdef GEMM_PROF
+        unsigned long long pacc[6] = {0, 0, 0, 0, 0, 0};
+        unsigned long long tprof = __builtin_amdgcn_s_memtime();
+#endif
+        // one flat step; the loop below is unrolled by two so that each register stage is named statically (a runtime
+        // stage selector makes the compiler rotate the stages with register copies, which forces it to wait for the
+        // loads that are still in flight)
+        auto step = [&](uint4 (&ra)[A_REGS], uint4 (&rb)[B_REGS], long long i) __attribute__((always_inline)) {
             if (ck0 == kbeg) {
 #pragma unroll
                 for (int a = 0; a < FM; ++a)
 #pragma unroll
                     for (int b = 0; b < FN; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
             }
-            if (sl == 0) store_tiles(ra0, rb0, buf, cm0, ck0);
-            else store_tiles(ra1, rb1, buf, cm0, ck0);
+            store_tiles(ra, rb, buf, cm0, ck0);
+            GPROF(0);
             __syncthreads();
-            if (i + 2 < total) {
-                if (sl == 0) load_tiles(ra0, rb0, pm0, pk0);
-                else load_tiles(ra1, rb1, pm0, pk0);
-                advance();
+            GPROF(1);
+            {   // unconditional (the last two steps re-load their own tile, never consumed): with exactly one tile of
+                // loads per step on every path the compiler can count them, and waits vmcnt(N) instead of vmcnt(0)
+                const bool more = i + 2 < total;
+                load_tiles(ra, rb, more ? pm0 : cm0, more ? pk0 : ck0);
+                if (more) advance();
             }
+            GPROF(2);
             compute(buf);
+            GPROF(3);
             buf ^= 1;
-            sl ^= 1;
             const bool last_k = ck0 + BK >= kend;
             if (last_k) epilogue(cm0);
+            GPROF(4);
+#ifdef GEMM_PROF
+            pacc[5] += 1;
+#endif
             ck0 += BK;
             if (last_k) { ck0 = kbeg; cm0 += (long long)gm * BM; }
+        };
+        for (long long i = 0; i < total; i += 2) {
+            step(ra0, rb0, i);
+            if (i + 1 < total) step(ra1, rb1, i + 1);
         }
+#ifdef GEMM_PROF
+        if (tid == 0)
+            for (int q = 0; q < 6; ++q) atomicAdd(&g_gemm_prof[q], pacc[q]);
+#endif
     }
 
+#ifdef GEMM_PROF
+    // (pacc is scoped to the main loop above; flushed there)
+#endif
     // ---------------- column statistics partials ----------------
     if (!CF32 && p.stat_partials) {
         constexpr int CPR = BN / 8;
@@ -468,8 +518,8 @@ int dispatch_tile(const mc_gemm_args& p, int grid_m, hipStream_t st) {
     // 128x128 tiles run with 8 waves (wave tile 64x32): half the accumulator / staging registers per thread,
     // twice the waves per CU to overlap global->LDS staging with MFMA issue
     if (p.N > 64)
-        return small_k ? launch<128, 128, 32, 2, 4, LAY, PRO, CF32>(p, grid_m, st)
-                       : launch<128, 128, 64, 2, 4, LAY, PRO, CF32>(p, grid_m, st);
+        return small_k ? launch<128, 128, 32, 2, 2, LAY, PRO, CF32>(p, grid_m, st)
+                       : launch<128, 128, 64, 2, 2, LAY, PRO, CF32>(p, grid_m, st);
     if (p.N > 32)
         return small_k ? launch<128, 64, 32, 2, 2, LAY, PRO, CF32>(p, grid_m, st)
                        : launch<128, 64, 64, 2, 2, LAY, PRO, CF32>(p, grid_m, st);
