@@ -11,8 +11,10 @@ EfficientNet-B5 + BioClinicalBERT, 32 pairs per GPU, 1520x912 images, 256-token 
 Per-GPU work is fixed as N grows (weak scaling: global batch = 32 N).
 
 The JSON line carries, besides the contract fields:
-  roofline     -- the dominant HBM-bound kernel class (depthwise / BN streaming kernels: see DESIGN.md), timed live with
-                  HIP events on the launch stream inside the timed steps; achieved = algorithmic bytes / time
+  roofline     -- the dominant kernel of the step (largest share of GPU time in the rocprofv3 kernel stats under
+                  profiles/): bnact_bwd_k<true>, the HBM-bound BatchNorm(+SiLU) backward apply pass.  Every launch
+                  inside the timed steps is bracketed by HIP events on the launch stream;
+                  achieved = algorithmic bytes per launch / average launch duration
   cpu_baseline -- the CPU oracle (oracle/, torch-fp32 restatement of the reference) timed on this box's host cores
                   on a bounded sample of the same workload (rank 0, N = 1 only)
 """
@@ -38,9 +40,10 @@ WORKLOADS = {
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 MFMA_PEAK_TFS = 2500.0         # dense bf16 MFMA peak
 
-# The dominant kernel of the step (rocprofv3 --kernel-trace --stats, profiles/r01_cfg3_kernel_stats.csv: 12.2 % of GPU
-# time): bnact_bwd_apply_k, the BatchNorm(+SiLU) backward "apply" pass  dx = A*dz + B*x + C  (reads the saved conv
-# output x and the upstream gradient g, writes dx): HBM-bound, 3 x rows x channels x 2 B algorithmic bytes per launch.
+# The dominant kernel of the step (rocprofv3 --kernel-trace --stats, profiles/r01_cfg3_kernel_stats.csv: the largest
+# single kernel by GPU time): bnact_bwd_k<true>, the BatchNorm(+SiLU) backward "apply" pass  dx = A*dz + B*x + C  (reads
+# the saved conv output x and the upstream gradient g, writes dx): HBM-bound, 3 x rows x channels x 2 B algorithmic
+# bytes per launch.
 ROOFLINE_OP = "mc_bnact_bwd_apply"
 ROOFLINE_KERNEL = "bnact_bwd_k<true> (BatchNorm+SiLU backward apply pass)"
 STREAM_OPS = (ROOFLINE_OP,)
@@ -75,7 +78,7 @@ def cpu_baseline(arch_name, H, W, T, budget_s=30.0):
     """CPU oracle (port of the reference path), train-mode fwd + bwd on ONE pair-group sample, host cores of this box."""
     from oracle import arch as oarch, bert as obert, clip as oclip, loss as oloss, weights as ow
     cores = os.cpu_count() or 1
-    threads = min(cores, 64)
+    threads = min(cores, 128)
     torch.set_num_threads(threads)
     arch = oarch.build_arch(arch_name)
     cfg = obert.BertShape()

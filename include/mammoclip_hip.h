@@ -175,7 +175,10 @@ int mc_bn_eval_coeffs(const float* gamma, const float* beta, const float* runnin
 /* elementwise family on x[n_img * hw, c] (bf16):  z = x*scale[c] + shift[c];  y = act(z)  (act 0 none, 1 SiLU)
  * apply:  out = y * rowscale[img] + res            (rowscale = drop_connect keep/keep_prob, res = skip input)
  *         [ref: efficientnet_custom.py:123-131, efficient_net_custom_utils.py:129-154]
- * pool:   pooled[img, c] = mean_hw y               [ref: efficientnet_custom.py:115 (SE squeeze), :307 (_avg_pooling)] */
+ * pool:   pooled[img, c] = mean_hw y               [ref: efficientnet_custom.py:115 (SE squeeze), :307 (_avg_pooling)]
+ *         with args->out != NULL the pass also stores y (bf16) there and pools the stored values: the late-stage project
+ *         convolutions then read the activated tensor with a gate-only GEMM prologue instead of re-evaluating
+ *         BN+SiLU once per column tile (forward) and once per row tile (weight gradient) */
 typedef struct mc_bnact_args {
     const mc_bf16* x;
     long long n_img, hw;

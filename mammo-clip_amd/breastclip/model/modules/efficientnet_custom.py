@@ -161,15 +161,24 @@ class _MBConvFn(torch.autograd.Function):
         wkkc = ops.transpose_f32(blk._depthwise_conv.weight.view(a.cexp, k * k))
         d, part1 = ops.dwconv_fwd(dw_in, wkkc, n, h, w, a.cexp, k, s, l, t, oh, ow, pro=pro0, stats=True)
         st1 = _bn_stats(part1, n * ohw, blk._bn1, training)
-        pooled = ops.bnact_pool(d, n, ohw, a.cexp, st1.scale, st1.shift, 1)
+        # Late stages (project conv on the tiled GEMM): the squeeze pass also stores A = silu(bn1(d)); the project GEMM
+        # and its weight gradient then apply only the SE gate instead of re-evaluating BN+SiLU per output tile.
+        keep = not ops._rows_ok(n * ohw, a.cout, a.cexp, None, 0)
+        if keep:
+            pooled, act1 = ops.bnact_pool(d, n, ohw, a.cexp, st1.scale, st1.shift, 1, keep_act=True)
+        else:
+            pooled, act1 = ops.bnact_pool(d, n, ohw, a.cexp, st1.scale, st1.shift, 1), None
         gate = ops.se_fwd(pooled, blk._se_reduce.weight.view(a.cse, a.cexp), blk._se_reduce.bias,
                           blk._se_expand.weight.view(a.cexp, a.cse), blk._se_expand.bias)
         wp = ops.cast_bf16(blk._project_conv.weight.view(a.cout, a.cexp))
-        p, part2 = ops.linear_fwd(d, wp, stats=True, pro=(st1.scale, st1.shift, gate, ohw))
+        if keep:
+            p, part2 = ops.linear_fwd(act1, wp, stats=True, pro=(None, None, gate, ohw))
+        else:
+            p, part2 = ops.linear_fwd(d, wp, stats=True, pro=(st1.scale, st1.shift, gate, ohw))
         st2 = _bn_stats(part2, n * ohw, blk._bn2, training)
         y = ops.bnact_apply(p, n, ohw, a.cout, st2.scale, st2.shift, 0,
                             rowscale=rowscale if a.skip else None, res=x if a.skip else None)
-        saved.update(x=x, d=d, p=p, wkkc=wkkc, wp=wp, st1=st1, st2=st2, pooled=pooled, gate=gate,
+        saved.update(x=x, d=d, p=p, wkkc=wkkc, wp=wp, st1=st1, st2=st2, pooled=pooled, gate=gate, act1=act1,
                      rowscale=rowscale if a.skip else None, geo=(n, h, w, oh, ow))
         ctx.blk, ctx.saved = blk, saved
         blk._out_geo = (n, oh, ow)
@@ -191,7 +200,10 @@ class _MBConvFn(torch.autograd.Function):
         # project 1x1: p = A1 . wp^T, A1 = silu(bn1(d)) * gate   (A1 is recomputed inside the wgrad GEMM)
         wp_t = ops.cast_transpose_bf16(blk._project_conv.weight.view(a.cout, a.cexp))      # [cexp, cout]
         da1 = ops.linear_dgrad(dp, sv["wp"], w_t=wp_t)
-        dwp = ops.linear_wgrad(dp, d, pro=(st1.scale, st1.shift, gate, ohw))
+        if sv["act1"] is not None:
+            dwp = ops.linear_wgrad(dp, sv["act1"], pro=(None, None, gate, ohw))
+        else:
+            dwp = ops.linear_wgrad(dp, d, pro=(st1.scale, st1.shift, gate, ohw))
         # squeeze-excite
         # ONE pass over (d, dA1) yields d loss / d gate AND the ingredients of the bn1-backward reductions
         sums = ops.bnact_se_sums(d, da1, n, ohw, a.cexp, st1, 1)

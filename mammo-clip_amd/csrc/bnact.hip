@@ -121,15 +121,23 @@ __global__ __launch_bounds__(256) void bnact_img_reduce_k(const mc_bnact_args p)
             float s[8], t[8];
             load8f(p.scale + v * 8, s);
             load8f(p.shift + v * 8, t);
-            auto body = [&](const uint4& xv, const uint4& gv) {
+            bf16_t* ob = (MODE == 0 && p.out) ? p.out + img * p.hw * p.c + v * 8 : nullptr;   // optional: keep act(z)
+            auto body = [&](long long r, const uint4& xv, const uint4& gv) {
                 float f[8];
                 unpack8(xv, f);
                 if (MODE == 0) {
 #pragma unroll
                     for (int q = 0; q < 8; ++q) {
                         float z = f[q] * s[q] + t[q];
-                        acc[q] += (p.act == 1 ? silu_f(z) : z);
+                        f[q] = (p.act == 1 ? silu_f(z) : z);
                     }
+                    if (ob) {                       // the pooled mean is taken over the stored (bf16-rounded) values
+                        const uint4 o = pack8(f);
+                        *reinterpret_cast<uint4*>(ob + r * p.c) = o;
+                        unpack8(o, f);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) acc[q] += f[q];
                 } else {
                     float g[8];
                     unpack8(gv, g);
@@ -151,10 +159,10 @@ __global__ __launch_bounds__(256) void bnact_img_reduce_k(const mc_bnact_args p)
                     gv[u] = (MODE == 1) ? *reinterpret_cast<const uint4*>(gb + (r + u * rstride) * p.c + v * 8) : z4;
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) body(xv[u], gv[u]);
+                for (int u = 0; u < 4; ++u) body(r + u * rstride, xv[u], gv[u]);
             }
             for (; r < p.hw; r += rstride)
-                body(*reinterpret_cast<const uint4*>(xb + r * p.c + v * 8),
+                body(r, *reinterpret_cast<const uint4*>(xb + r * p.c + v * 8),
                      (MODE == 1) ? *reinterpret_cast<const uint4*>(gb + r * p.c + v * 8) : z4);
         }
 #pragma unroll

@@ -31,12 +31,15 @@ __device__ __forceinline__ uint4 keep4(bool ok, const uint4& a) {
 // fused prologue on a vector of 8 channels [ch0, ch0+8) of pixel `pix`:
 //   v' = silu(v * scale[c] + shift[c]) * gate[(pix / rows_per_img) * nch + c]
 __device__ __forceinline__ uint4 apply_prologue(uint4 v, const mc_gemm_args& p, long long pix, int ch0) {
-    float f[8], s[8], t[8];
+    float f[8];
     unpack8(v, f);
-    load8f(p.pro_scale + ch0, s);
-    load8f(p.pro_shift + ch0, t);
+    if (p.pro_scale) {                 // (null: the operand is already activated, only the gate is applied)
+        float s[8], t[8];
+        load8f(p.pro_scale + ch0, s);
+        load8f(p.pro_shift + ch0, t);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) f[i] = silu_f(f[i] * s[i] + t[i]);
+        for (int i = 0; i < 8; ++i) f[i] = silu_f(f[i] * s[i] + t[i]);
+    }
     if (p.pro_gate) {
         long long img = pix / p.pro_rows_per_img;
         float g[8];
@@ -556,7 +559,8 @@ extern "C" int mc_gemm_bf16(const mc_gemm_args* a, void* stream) {
     MC_CHECK(p.splits == 1 || (p.c_f32 && (p.c_atomic || p.splitk_ws)), "gemm: split-K needs fp32 output + workspace or atomics");
     MC_CHECK(!(p.splits > 1 && p.splitk_ws) || (p.batch == 1 && !p.bias), "gemm: workspace split-K is unbatched, no bias");
     MC_CHECK(!(p.stat_partials && (p.c_f32 || p.batch != 1 || p.splits != 1)), "gemm: stats need plain bf16 output");
-    MC_CHECK(p.pro_operand == 0 || (p.pro_scale && p.pro_shift), "gemm: prologue needs scale/shift");
+    MC_CHECK(p.pro_operand == 0 || (p.pro_scale && p.pro_shift) || (!p.pro_scale && !p.pro_shift && p.pro_gate),
+             "gemm: prologue needs scale+shift (BN+SiLU) and/or a gate");
     MC_CHECK(p.pro_operand != 1 || (!p.a_kmajor && !p.b_kmajor && !p.c_f32), "gemm: A prologue is provided for NT, bf16 output");
     MC_CHECK(p.pro_operand != 2 || (p.a_kmajor && p.b_kmajor && p.c_f32), "gemm: B prologue is provided for TN, fp32 output");
     MC_CHECK(!p.R || (!p.c_f32 && p.ldr % 8 == 0), "gemm: residual needs bf16 output and ldr % 8 == 0");

@@ -105,7 +105,7 @@ def linear_fwd(x, w, bias=None, act=0, residual=None, stats=False, pro=None, out
     M, K = x.shape
     N = w.shape[0]
     y = out if out is not None else empty((M, N), BF16, x)
-    if _rows_ok(M, N, K, bias, act):
+    if _rows_ok(M, N, K, bias, act) and (pro is None or pro[0] is not None):
         part = empty((L.load().mc_gemm_rows_blocks(M), 2, N), torch.float32, x) if stats else None
         gemm_rows(x, w, y, residual=residual, pro=pro, stat_partials=part, kind="fwd_rows")
         return (y, part) if stats else y
@@ -151,7 +151,7 @@ def linear_wgrad(dy, x, pro=None, out=None):
     M, N = dy.shape
     K = x.shape[1]
     dw = out if out is not None else empty((N, K), torch.float32, dy)
-    if M >= ROWS_MIN_M and L.load().mc_wgrad_rows_supported(N, K):
+    if M >= ROWS_MIN_M and L.load().mc_wgrad_rows_supported(N, K) and (pro is None or pro[0] is not None):
         a = L.WgradRowsArgs()
         a.dY, a.N, a.lddy = _p(dy), N, dy.stride(0)
         a.X, a.K, a.ldx, a.M = _p(x), K, x.stride(0), M
@@ -320,14 +320,19 @@ def _split_ws(a, x, n_img, c, planes=1):
     return ws
 
 
-def bnact_pool(x, n_img, hw, c, scale, shift, act):
+def bnact_pool(x, n_img, hw, c, scale, shift, act, keep_act=False):
+    """pooled[n_img, c] = mean over the image of act(x*scale+shift); keep_act -> also returns act(.) as bf16"""
     a = _bnact(x, n_img, hw, c, scale, shift, act)
     pooled = empty((n_img, c), torch.float32, x)
     a.pooled = _p(pooled)
+    y = None
+    if keep_act:
+        y = empty((n_img * hw, c), BF16, x)
+        a.out = _p(y)
     ws = _split_ws(a, x, n_img, c)  # noqa: F841  (kept alive until the launch is enqueued)
-    _note(2 * n_img * hw * c)
+    _note((4 if keep_act else 2) * n_img * hw * c)
     L.call("mc_bnact_pool", C.byref(a), _st())
-    return pooled
+    return (pooled, y) if keep_act else pooled
 
 
 def bnact_se_dgate(x, g, n_img, hw, c, scale, shift, act):

@@ -55,7 +55,9 @@ def test_abi_argument_validation_without_gpu():
     d = L.DwconvArgs()
     assert lib.mc_dwconv_fwd(ctypes.byref(d), None) != 0
     assert lib.mc_gemm_rows_supported(240, 40) == 1 and lib.mc_gemm_rows_supported(40, 240) == 1
-    assert lib.mc_gemm_rows_supported(384, 64) == 0 and lib.mc_gemm_rows_supported(24, 20) == 0
+    assert lib.mc_gemm_rows_supported(384, 64) == 1 and lib.mc_gemm_rows_supported(1056, 176) == 1   # 128-column tiles
+    assert lib.mc_gemm_rows_supported(1824, 304) == 0 and lib.mc_gemm_rows_supported(24, 20) == 0
+    assert lib.mc_gemm_rows_supported(176, 1056) == 0
     assert lib.mc_wgrad_rows_supported(240, 40) == 1 and lib.mc_wgrad_rows_supported(512, 3072) == 0
     with pytest.raises(L.MammoClipHipError):
         L.call("mc_sgemm", None, 0, 0, None, 0, 0, None, 0, 0, 0, 0, 1.0, 0.0, None, None, None)
