@@ -607,6 +607,263 @@ __global__ __launch_bounds__(256, 2) void dwconv_march_bww_kernel(const mc_dwcon
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Stride-2 data gradient, marching form.  With (iy + pad_t) = 2*o' + f and (ix + pad_l) = 2*j + e the transposed
+// convolution is a STRIDE-1 stencil over "super pixels" (o', j) of 2x2 outputs:
+//     dx[2o'-pt+f, 2j-pl+e] = sum_{d,d'} dy[o'-d, j-d'] * w[f+2d, e+2d']          (taps with f+2d, e+2d' < K)
+// so the forward kernel's structure applies with D = ceil(K/2) live super-rows per lane: a lane owns NJ adjacent
+// super-columns of its channels, each staged dy row is read once (NJ+D-1 reads), scattered into the D super-rows it
+// touches (all K*K taps of the lane's channels, held in registers, are used once per dy row), and super-row o' is
+// complete - four output pixels per super-column - as soon as dy row o' has been processed.  The kernel is bound by
+// the 4x larger dx write stream.
+template <int K, int CPL, int LP, int NJ> struct MarchBwdCfg {
+    static constexpr int H2 = CPL / 2;
+    static constexpr int PXW = 64 / LP;
+    static constexpr int D = (K + 1) / 2;                  // super-taps per dimension = live super-rows
+    static constexpr int TOWJ = 4 * PXW * NJ;              // super-columns per strip
+    static constexpr int IW_T = TOWJ + D - 1;              // staged dy columns
+    static constexpr int NIN = NJ + D - 1;
+    static constexpr int TCH = LP * CPL;
+    static constexpr int PXB = TCH * 2;
+    static constexpr int VPP = PXB / 16;
+    static constexpr int PSB = (CPL == 2 && LP == 32 && NJ == 2) ? 192 : PXB;      // conflict-free 4-byte reads
+    static constexpr int NR_ = (16384 + D * IW_T * PXB / 2) / (D * IW_T * PXB);
+    static constexpr int NR = NR_ < 1 ? 1 : NR_;
+    static constexpr int RB = D * NR;                      // dy rows per staged block
+    static constexpr int TS = 256 - 256 % VPP;
+    static constexpr int NV = (RB * IW_T * VPP + TS - 1) / TS;
+    static constexpr int BUF_BYTES = RB * IW_T * PSB;
+};
+
+template <int K, int CPL, int LP, int NJ>
+__global__ __launch_bounds__(256, 2) void dwconv_march_bwd_s2_kernel(const mc_dwconv_args p, int strips, int segs, int seg_rows,
+                                                                     int ctiles, int gy) {
+    using C = MarchBwdCfg<K, CPL, LP, NJ>;
+    typedef typename std::conditional<CPL == 4, uint2, uint32_t>::type ldsv_t;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[C::BUF_BYTES];
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int ct = slot % ctiles, y = (slot / ctiles) * 8 + xcd;
+    if (y >= gy) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lq = lane % LP, px = lane / LP;
+    const bool lane_ok = px < C::PXW;
+    const int c0 = ct * C::TCH;
+    const int cl = c0 + lq * CPL;
+    const bool ch_ok = lane_ok && cl < p.c;
+    const int jl0 = (wave * C::PXW + (lane_ok ? px : 0)) * NJ;       // strip-local first super-column
+    const int lbase = jl0 * C::PSB + lq * (CPL * 2);
+    const int ohv = (p.h + p.pad_t + 1) >> 1;              // super-rows / super-columns that cover the image
+    const int owv = (p.w + p.pad_l + 1) >> 1;
+
+    f32x2_t w[K * K][C::H2];
+#pragma unroll
+    for (int t = 0; t < K * K; ++t)
+#pragma unroll
+        for (int h = 0; h < C::H2; ++h) {
+            w[t][h] = f32x2_t{0.f, 0.f};
+            if (ch_ok) w[t][h] = *reinterpret_cast<const f32x2_t*>(p.w_kkc + (long long)t * p.c + cl + 2 * h);
+        }
+    const int vv = tid % C::VPP;
+    const int cs = c0 + vv * 8;
+    const bool st_ok = tid < C::TS && cs < p.c;
+    const long long g_row_pitch = (long long)p.ow * p.c;
+    unsigned meta[C::NV];                                  // row | col << 8 | (LDS byte offset / 16) << 16
+#pragma unroll
+    for (int i = 0; i < C::NV; ++i) {
+        const int v = tid + i * C::TS;
+        const int row = v / (C::IW_T * C::VPP), col = (v / C::VPP) % C::IW_T;
+        meta[i] = (unsigned)row | ((unsigned)col << 8) | ((unsigned)(((row * C::IW_T + col) * C::PSB + vv * 16) >> 4) << 16);
+        if (v >= C::RB * C::IW_T * C::VPP) meta[i] = 0xffu;
+    }
+    f32x2_t acc[C::D][NJ][4][C::H2];                       // [super-row slot][super-column][f*2+e][channel pair]
+
+    const int nitems = p.n * strips * segs;
+    auto item_geom = [&](int it, int& img, int& j0, int& s0, int& nrows, int& nblk) {
+        const int strip = it % strips;
+        const int seg = (it / strips) % segs;
+        img = it / (strips * segs);
+        j0 = strip * C::TOWJ;
+        s0 = seg * seg_rows;
+        nrows = ohv - s0 < seg_rows ? ohv - s0 : seg_rows;             // super-rows owned by the item
+        nblk = (nrows + C::D - 1 + C::RB - 1) / C::RB;                 // dy rows s0-(D-1) .. s0+nrows-1
+    };
+    uint4 vals[C::NV];
+    unsigned inb = 0, colmask = 0;
+    auto stage_load = [&](int img, int j0, int s0, int b, bool new_item) {
+        const int oy0 = s0 - (C::D - 1) + b * C::RB, ox0 = j0 - (C::D - 1);
+        if (new_item) {
+            colmask = 0;
+#pragma unroll
+            for (int i = 0; i < C::NV; ++i) {
+                const int ox = ox0 + (int)((meta[i] >> 8) & 0xffu);
+                if (st_ok && ox >= 0 && ox < p.ow) colmask |= 1u << i;
+            }
+        }
+        const bf16_t* org = p.dy + ((long long)img * p.oh + oy0) * g_row_pitch + (long long)ox0 * p.c + c0;
+        inb = 0;
+#pragma unroll
+        for (int i = 0; i < C::NV; ++i) {
+            const int oy = oy0 + (int)(meta[i] & 0xffu);
+            const bool ok = ((colmask >> i) & 1u) && oy >= 0 && oy < p.oh;
+            const unsigned goff = (meta[i] & 0xffu) * (unsigned)g_row_pitch + ((meta[i] >> 8) & 0xffu) * (unsigned)p.c + vv * 8;
+            const bf16_t* a = ok ? org + goff : p.dy;
+            vals[i] = *reinterpret_cast<const uint4*>(a);
+            inb |= (ok ? 1u : 0u) << i;
+        }
+    };
+    auto stage_store = [&]() {
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+#pragma unroll
+        for (int i = 0; i < C::NV; ++i) {
+            if (tid < C::TS && (meta[i] & 0xffu) != 0xffu) {
+                const bool real = (inb >> i) & 1u;
+                const uint4 val = make_uint4(real ? vals[i].x : 0u, real ? vals[i].y : 0u, real ? vals[i].z : 0u, real ? vals[i].w : 0u);
+                *reinterpret_cast<uint4*>(smem + ((meta[i] >> 16) << 4)) = val;
+            }
+        }
+    };
+
+    int it = y, img = 0, j0 = 0, s0 = 0, nrows = 0, nblk = 0, b = 0;
+    if (it >= nitems) return;
+    item_geom(it, img, j0, s0, nrows, nblk);
+    stage_load(img, j0, s0, 0, true);
+    int sr_next = 0;                                       // super-row (item-relative) completed by the next dy row
+    bf16_t* optr = nullptr;                                // lane's pixel (f = 0, e = 0 of its first super-column) in that super-row
+    unsigned ok_mask = 0;                                  // bit (i*2+e): output column exists
+    const long long row_pitch = (long long)p.w * p.c;
+    while (true) {
+        __syncthreads();
+        stage_store();
+        __syncthreads();
+        int it2 = it, img2 = img, j2 = j0, s2 = s0, nrows2 = nrows, nblk2 = nblk, b2 = b + 1;
+        if (b2 >= nblk) {
+            it2 = it + gy; b2 = 0;
+            if (it2 < nitems) item_geom(it2, img2, j2, s2, nrows2, nblk2);
+        }
+        const bool more = it2 < nitems;
+        if (more) stage_load(img2, j2, s2, b2, b2 == 0);
+
+        if (b == 0) {
+#pragma unroll
+            for (int a = 0; a < C::D; ++a)
+#pragma unroll
+                for (int i = 0; i < NJ; ++i)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int h = 0; h < C::H2; ++h) acc[a][i][q][h] = f32x2_t{0.f, 0.f};
+            sr_next = -(C::D - 1);
+            const long long iy = 2LL * (s0 + sr_next) - p.pad_t, ix = 2LL * (j0 + jl0) - p.pad_l;
+            optr = reinterpret_cast<bf16_t*>(p.out) + (((long long)img * p.h + iy) * p.w + ix) * p.c + cl;
+            ok_mask = 0;
+#pragma unroll
+            for (int i = 0; i < NJ; ++i)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const long long x = ix + 2 * i + e;
+                    if (ch_ok && x >= 0 && x < p.w) ok_mask |= 1u << (i * 2 + e);
+                }
+        }
+#pragma unroll 1
+        for (int sb = 0; sb < C::NR; ++sb) {
+            const unsigned char* lp = smem + lbase + sb * (C::D * C::IW_T * C::PSB);
+#pragma unroll
+            for (int jr = 0; jr < C::D; ++jr) {            // dy row jr of the period: enters super-rows jr .. jr+D-1 (mod D)
+                f32x2_t in[C::NIN][C::H2];
+#pragma unroll
+                for (int i = 0; i < C::NIN; ++i) {
+                    const ldsv_t v = *reinterpret_cast<const ldsv_t*>(lp + (jr * C::IW_T + i) * C::PSB);
+                    if constexpr (CPL == 4) {
+                        in[i][0] = f32x2_t{bf_lo(v.x), bf_hi(v.x)};
+                        in[i][1] = f32x2_t{bf_lo(v.y), bf_hi(v.y)};
+                    } else {
+                        in[i][0] = f32x2_t{bf_lo(v), bf_hi(v)};
+                    }
+                }
+                // staged column index of dy column (j - d') for the lane's super-column i:  (D-1) + i - d'
+#pragma unroll
+                for (int d = 0; d < C::D; ++d) {
+                    const int sl = (jr + d) % C::D;
+#pragma unroll
+                    for (int f = 0; f < 2; ++f) {
+                        if (f + 2 * d >= K) continue;
+#pragma unroll
+                        for (int dd = 0; dd < C::D; ++dd)
+#pragma unroll
+                            for (int e = 0; e < 2; ++e) {
+                                if (e + 2 * dd >= K) continue;
+#pragma unroll
+                                for (int i = 0; i < NJ; ++i)
+#pragma unroll
+                                    for (int h = 0; h < C::H2; ++h)
+                                        acc[sl][i][f * 2 + e][h] = __builtin_elementwise_fma(
+                                            w[(f + 2 * d) * K + e + 2 * dd][h], in[C::D - 1 + i - dd][h], acc[sl][i][f * 2 + e][h]);
+                            }
+                    }
+                }
+                {   // super-row sr_next is complete
+                    const int sl = jr % C::D;
+                    if (sr_next >= 0 && sr_next < nrows) {
+                        const long long iy0 = 2LL * (s0 + sr_next) - p.pad_t;
+#pragma unroll
+                        for (int f = 0; f < 2; ++f) {
+                            if (iy0 + f >= 0 && iy0 + f < p.h) {
+#pragma unroll
+                                for (int i = 0; i < NJ; ++i)
+#pragma unroll
+                                    for (int e = 0; e < 2; ++e) {
+                                        if ((ok_mask >> (i * 2 + e)) & 1u) {
+                                            bf16_t* o = optr + f * row_pitch + (long long)(2 * i + e) * p.c;
+                                            if constexpr (CPL == 4)
+                                                *reinterpret_cast<uint2*>(o) =
+                                                    make_uint2(pack_bf2(acc[sl][i][f * 2 + e][0].x, acc[sl][i][f * 2 + e][0].y),
+                                                               pack_bf2(acc[sl][i][f * 2 + e][1].x, acc[sl][i][f * 2 + e][1].y));
+                                            else
+                                                *reinterpret_cast<uint32_t*>(o) = pack_bf2(acc[sl][i][f * 2 + e][0].x, acc[sl][i][f * 2 + e][0].y);
+                                        }
+                                    }
+                            }
+                        }
+                    }
+                    ++sr_next;
+                    optr += 2 * row_pitch;
+#pragma unroll
+                    for (int i = 0; i < NJ; ++i)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+#pragma unroll
+                            for (int h = 0; h < C::H2; ++h) acc[sl][i][q][h] = f32x2_t{0.f, 0.f};
+                }
+            }
+        }
+        if (!more) break;
+        it = it2; img = img2; j0 = j2; s0 = s2; nrows = nrows2; nblk = nblk2; b = b2;
+    }
+}
+
+template <int K, int CPL, int LP, int NJ> int launch_march_bwd_s2(const mc_dwconv_args& p, hipStream_t st) {
+    using C = MarchBwdCfg<K, CPL, LP, NJ>;
+    const int ohv = (p.h + p.pad_t + 1) >> 1, owv = (p.w + p.pad_l + 1) >> 1;
+    const int strips = mc_div_up(owv, C::TOWJ), ctiles = mc_div_up(p.c, C::TCH);
+    long long base = (long long)p.n * strips * ctiles;
+    int segs = (int)((2048 + base - 1) / base);
+    int max_segs = ohv / 16 > 0 ? ohv / 16 : 1;
+    if (segs > max_segs) segs = max_segs;
+    if (segs < 1) segs = 1;
+    const int seg_rows = mc_div_up(mc_div_up(ohv, segs), C::RB) * C::RB;
+    segs = mc_div_up(ohv, seg_rows);
+    long long nitems = (long long)p.n * strips * segs;
+    long long cap = 512 / ctiles;
+    if (cap < 8) cap = 8;
+    long long per = (nitems + cap - 1) / cap;
+    const int gy = (int)((nitems + per - 1) / per);
+    const int gy8 = (gy + 7) / 8 * 8;
+    hipLaunchKernelGGL((dwconv_march_bwd_s2_kernel<K, CPL, LP, NJ>), dim3(gy8 * ctiles), dim3(256), 0, st, p, strips, segs, seg_rows,
+                       ctiles, gy);
+    MC_LAUNCH_CHECK();
+    return MC_OK;
+}
+
 struct MarchPlan { int strips, segs, seg_rows, ctiles, gy; };
 template <typename C> MarchPlan march_plan(const mc_dwconv_args& p) {
     MarchPlan m;
@@ -703,6 +960,14 @@ extern "C" int mc_dwconv_bwd_data(const mc_dwconv_args* a, void* stream) {
     const mc_dwconv_args& p = *a;
     if (int e = check_common(p)) return e;
     MC_CHECK(p.dy && p.w_kkc, "dwconv_bwd_data: null dy / w");
+    if (p.stride == 2) {                                               // marching form
+        hipStream_t st = (hipStream_t)stream;
+        if (p.k == 3) {
+            if (p.c % 48 == 0 && p.c < 192) return launch_march_bwd_s2<3, 4, 12, 1>(p, st);
+            return launch_march_bwd_s2<3, 4, 16, 1>(p, st);
+        }
+        return launch_march_bwd_s2<5, 2, 32, 2>(p, st);
+    }
     long long total = (long long)p.n * p.h * p.w * (p.c / 8);
     int blocks = mc_div_up(total, 256);
     if (blocks > 16384) blocks = 16384;
