@@ -368,9 +368,74 @@ def gen_e2e(tag, enc_name, arch_name, b, H, W, T):
     np.savez_compressed(os.path.join(HERE, f"{tag}.npz"), **store)
 
 
+def gen_traj(tag="traj_b5_small", enc_name="tf_efficientnet_b5_ns-detect", arch_name="efficientnet-b5", b=2, H=160, W=96, T=32,
+             steps=4):
+    """Row H (the hot loop): the reference's own build_optimizer / build_scheduler / call order for a few steps on a
+    fixed batch with every stochastic op off -> per-step losses and parameter deltas [ref: trainer_ddp.py:279-308]."""
+    from breastclip.model import build_model
+    from breastclip.loss import build_loss
+    from breastclip.optimizer import build_optimizer
+    from breastclip.scheduler import build_scheduler
+    from oracle import arch as oarch, weights as ow
+    from oracle.bert import BertShape
+    model_cfg = {"name": "clip_custom", "temperature": 0.07,
+                 "image_encoder": {"source": "cnn", "name": enc_name, "pretrained": True, "model_type": "cnn"},
+                 "text_encoder": {"source": "huggingface", "name": "emilyalsentzer/Bio_ClinicalBERT",
+                                  "pretrained": False, "gradient_checkpointing": False, "pooling": "eos",
+                                  "cache_dir": "/tmp/none", "trust_remote_code": True, "mlm_head": True},
+                 "projection_head": {"name": "linear", "dropout": 0.1, "proj_dim": 512}}
+    loss_cfg = {"breast_clip": dict(label_smoothing=0.0, i2i_weight=1.0, t2t_weight=0.5, loss_ratio=1.0)}
+    torch.manual_seed(10)
+    model = build_model(model_cfg, loss_cfg, types.SimpleNamespace(vocab_size=28996))
+    shapes = ow.clip_shapes(oarch.build_arch(arch_name), BertShape())
+    sd = ow.synth_state_dict(shapes, seed=10)
+    model.load_state_dict(sd, strict=True)
+    model.image_encoder._dropout.p = 0.0
+    model.image_encoder._global_params = model.image_encoder._global_params._replace(drop_connect_rate=0.0)
+    for mod in model.text_encoder.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    model.text_encoder.text_encoder.config.attention_probs_dropout_prob = 0.0
+    model.text_encoder.text_encoder.config.hidden_dropout_prob = 0.0
+    batch = ow.synth_batch(b, H, W, T, seed=10)
+    lf = build_loss(loss_cfg)
+    lr, wd, total, warm = 1e-5, 1e-4, 10, 2          # large enough that the steps visibly move the loss, small enough to stay smooth
+    opt = build_optimizer(model, {"name": "adamw", "config": {"lr": lr, "weight_decay": wd}})
+    sch = build_scheduler(opt, {"name": "cosine", "config": {"total_steps": total, "warmup_steps": warm}})
+
+    class BE(dict):
+        def to(self, device):
+            return self
+
+    watch = ["logit_scale", "image_projection.projection.weight", "text_projection.projection.bias",
+             "image_encoder._bn0.weight", "image_encoder._conv_head.weight",
+             "text_encoder.text_encoder.encoder.layer.11.output.dense.bias"]
+    p0 = {k: v.detach().clone() for k, v in model.named_parameters() if k in watch}
+    losses, lrs = [], []
+    model.train()
+    for _ in range(steps):
+        opt.zero_grad(set_to_none=True)
+        bt = {"images": batch["images"], "image_views": batch["image_views"],
+              "text_tokens": BE(batch["text_tokens"]), "text_tokens2": BE(batch["text_tokens2"])}
+        out = model(bt, torch.device("cpu"))
+        ld = lf(**out, is_train=True)
+        ld["total"].backward()
+        lrs.append(opt.param_groups[0]["lr"])
+        opt.step()
+        sch.step()
+        losses.append(float(ld["total"].detach()))
+    store = {"meta": np.array([b, H, W, T, steps], dtype=np.int64), "hyper": np.array([lr, wd, total, warm]),
+             "losses": np.array(losses), "lrs": np.array(lrs)}
+    pd = dict(model.named_parameters())
+    for k in watch:
+        store["delta/" + k] = np_((pd[k].detach() - p0[k]).reshape(-1)[:4096])     # leading slice: small fixture
+    print(tag, "losses", losses, "lrs", lrs)
+    np.savez_compressed(os.path.join(HERE, f"{tag}.npz"), **store)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["arch", "mbconv", "bert", "loss", "e2e_b2", "e2e_b5"]
+    which = sys.argv[1:] or ["arch", "mbconv", "bert", "loss", "e2e_b2", "e2e_b5", "traj"]
     import_reference()
     if "arch" in which:
         gen_arch_tables()
@@ -382,5 +447,7 @@ if __name__ == "__main__":
         gen_loss_kats()
     if "e2e_b2" in which:
         gen_e2e("e2e_b2_cfg1", "tf_efficientnetv2-detect", "efficientnet-b2", 4, 224, 224, 64)
+    if "traj" in which:
+        gen_traj()
     if "e2e_b5" in which:
         gen_e2e("e2e_b5_small", "tf_efficientnet_b5_ns-detect", "efficientnet-b5", 2, 160, 96, 32)

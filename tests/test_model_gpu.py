@@ -279,3 +279,50 @@ def test_e2e_vs_reference(tag, enc, arch_name, eval_tol):
     pooler = pd["text_encoder.text_encoder.pooler.dense.weight"].grad
     assert pooler is None or float(pooler.abs().max()) == 0.0   # unused, like the reference (text_encoder.py:49)
     print(tag, rep)
+
+
+def test_hot_loop_trajectory_vs_reference():
+    """Row H: Trainer.step (zero_grad -> fwd -> loss -> bwd -> AdamW -> scheduler, trainer_ddp.py:279-308) against the
+    reference's own loop run for 4 steps on the same batch (tests/golden/traj_b5_small.npz, all stochastic ops off).
+    AdamW's first updates are +-lr per element, so the parameter deltas pin optimizer, weight-decay and schedule
+    wiring; the losses pin the whole loop (train-mode bf16 tolerance, see test_e2e_vs_reference)."""
+    from mammo_clip_amd import engine
+    from mammo_clip_amd.breastclip.optimizer import build_optimizer
+    from mammo_clip_amd.breastclip.scheduler import LinearWarmupCosineAnnealingLR
+    z = np.load(os.path.join(GOLDEN, "traj_b5_small.npz"))
+    b, H, W, T, steps = [int(v) for v in z["meta"]]
+    lr, wd, total, warm = [float(v) for v in z["hyper"]]
+    model, lossf, sd = _build("tf_efficientnet_b5_ns-detect", "efficientnet-b5")
+    util.GlobalEnv.reset()
+    opt = build_optimizer(model, {"name": "adamw", "config": {"lr": lr, "weight_decay": wd}})
+    sch = LinearWarmupCosineAnnealingLR(opt, total_steps=int(total), warmup_steps=int(warm))
+    trainer = engine.Trainer(model, lossf, opt, sch, DEV)
+    batch = ow.synth_batch(b, H, W, T, seed=10)
+    bt = {"images": batch["images"].to(DEV), "image_views": batch["image_views"].to(DEV),
+          "text_tokens": {k: v.to(DEV) for k, v in batch["text_tokens"].items()},
+          "text_tokens2": {k: v.to(DEV) for k, v in batch["text_tokens2"].items()}}
+    watch = [k[len("delta/"):] for k in z.files if k.startswith("delta/")]
+    p0 = {k: v.detach().clone() for k, v in model.named_parameters() if k in watch}
+    losses, lrs = [], []
+    for _ in range(steps):
+        lrs.append(opt.param_groups[0]["lr"])
+        losses.append(float(trainer.step(bt)["total"]))
+    assert np.allclose(lrs, z["lrs"], rtol=0, atol=1e-12), (lrs, z["lrs"])          # schedule [ref: warmup_cosine.py:41-50]
+    ref = z["losses"]
+    assert abs(losses[0] - ref[0]) <= 0.06 and abs(losses[1] - ref[1]) <= 0.06, (losses, ref)   # lr = 0 in step 0: unchanged
+    assert abs(losses[0] - losses[1]) < 1e-6                                       # bit-reproducible forward, no update yet
+    for t in range(2, steps):                                                       # the updates move the loss like the reference's
+        assert abs(losses[t] - ref[t]) <= 0.15 * abs(ref[1] - ref[t]) + 0.06, (losses, ref)
+    pd = dict(model.named_parameters())
+    rep = {}
+    for k in watch:
+        d = (pd[k].detach() - p0[k]).reshape(-1)[:4096].float().cpu()
+        r = torch.as_tensor(z["delta/" + k]).float()
+        cos = float(torch.nn.functional.cosine_similarity(d, r, dim=0))
+        rep[k] = (round(cos, 3), round(float(d.norm()) / float(r.norm()), 3))
+    print("trajectory", dict(hip=losses, ref=list(ref)), rep)
+    for k, (cos, ratio) in rep.items():
+        # Adam's early updates are ~ lr * sign(g): elements whose gradient is below the bf16 noise floor flip sign, so the
+        # direction agrees on the bulk (cos) and the step LENGTH (set by lr, weight decay and the schedule) is exact
+        assert cos >= 0.5, (k, cos)
+        assert abs(ratio - 1.0) <= 0.2, (k, ratio)
