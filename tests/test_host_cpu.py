@@ -113,6 +113,31 @@ def test_factories_error_behaviour_matches_reference():
     assert [l.name for l in lf.loss_list] == ["contrastive"] and lf.loss_list[0].loss_ratio == 1.0
 
 
+def test_checkpoint_round_trip_reference_layout(tmp_path):
+    """.tar checkpoints use the reference's dict layout and state_dict keys (trainer.py:215-237)"""
+    from mammo_clip_amd.checkpoint import load_checkpoint, save_checkpoint
+    model = build_model(_cfg(), {"breast_clip": {}}, types.SimpleNamespace(vocab_size=28996))
+    shapes = ow.clip_shapes(oarch.build_arch("efficientnet-b2"), obert.BertShape())
+    model.load_state_dict(ow.synth_state_dict(shapes, seed=5), strict=True)
+    opt = torch.optim.AdamW(model.parameters(), lr=5e-5, weight_decay=1e-4)
+    sch = LinearWarmupCosineAnnealingLR(opt, total_steps=10, warmup_steps=2)
+    path = str(tmp_path / "model-epoch-3.tar")
+    save_checkpoint(path, model, opt, sch, config={"base": {"seed": 10}}, epoch=3, train_loss=1.25, best=True)
+    raw = torch.load(path, map_location="cpu", weights_only=False)
+    assert sorted(raw.keys()) == ["config", "epoch", "model", "optimizer", "scheduler", "train_loss"]
+    assert list(raw["model"].keys()) == list(shapes.keys()) and raw["epoch"] == 3
+    assert all(v.dtype == torch.float32 for k, v in raw["model"].items() if "num_batches" not in k and "position_ids" not in k)
+    assert (tmp_path / "model-best.tar").exists()
+    other = build_model(_cfg(), {"breast_clip": {}}, types.SimpleNamespace(vocab_size=28996))
+    ck = load_checkpoint(path, other, strict=True)
+    assert ck["train_loss"] == 1.25
+    for (k, a), (_, b) in zip(model.state_dict().items(), other.state_dict().items()):
+        assert torch.equal(a, b), k
+    # a DDP-wrapped save ("module." prefix) loads too
+    torch.save({"model": {"module." + k: v for k, v in raw["model"].items()}}, str(tmp_path / "ddp.tar"))
+    load_checkpoint(str(tmp_path / "ddp.tar"), other, strict=True)
+
+
 def test_no_cpu_fallback():
     """the product path refuses CPU tensors instead of silently computing somewhere else"""
     model = build_model(_cfg(), {"breast_clip": {}}, types.SimpleNamespace(vocab_size=28996))
