@@ -285,10 +285,13 @@ int mc_eos_scatter(const float* dout, const long long* mask, int b, int t, int h
 /* ------------------------------------------------------------------------------------------------
  * fp32 small GEMM with arbitrary strides: C[m,n] = alpha * sum_k A[m*ars + k*acs] * B[k*brs + n*bcs] + beta*C + bias[n]
  * [ref: model/modules/projection.py:23-29 (LinearProjectionHead); loss/breast_clip.py:46-100 (logits)] */
-/* alpha_dev (optional): device scalar multiplied into alpha (e.g. the learnable logit scale) */
+/* alpha_dev (optional): device scalar multiplied into alpha (e.g. the learnable logit scale).
+ * ws (optional): float[mc_sgemm_ws_floats(m, n, k)] scratch; lets few-tile / long-k products (projection heads, their
+ * weight gradients) spread over the chip by split-K, partials combined in split order (deterministic) */
+long long mc_sgemm_ws_floats(int m, int n, int k);
 int mc_sgemm(const float* a, long long ars, long long acs, const float* b, long long brs, long long bcs,
              float* c, long long ldc, int m, int n, int k, float alpha, float beta, const float* bias,
-             const float* alpha_dev, void* stream);
+             const float* alpha_dev, float* ws, void* stream);
 /* y[i] = x[i] * (*scalar_dev) * alpha */
 int mc_scale_f32(const float* x, const float* scalar_dev, float alpha, float* y, long long n, void* stream);
 /* y = x / ||x||_2 per row (no epsilon) [ref: model/clip.py:90-91]; bwd: dx = (dy - y*(y.dy)) / ||x|| */

@@ -13,20 +13,23 @@ __global__ __launch_bounds__(256) void sgemm_k(const float* __restrict__ a, long
                                                const float* __restrict__ b, long long brs, long long bcs,
                                                float* __restrict__ c, long long ldc, int m, int n, int k, float alpha,
                                                float beta, const float* __restrict__ bias,
-                                               const float* __restrict__ alpha_dev) {
+                                               const float* __restrict__ alpha_dev, float* __restrict__ ws) {
     if (alpha_dev) alpha *= alpha_dev[0];
     __shared__ float sa[TS][TS + 1], sb[TS][TS + 1];
     const int tx = threadIdx.x % 16, ty = threadIdx.x / 16;       // 16 x 16 threads, 2 x 2 outputs each
     const int m0 = blockIdx.y * TS, n0 = blockIdx.x * TS;
     float acc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
-    for (int k0 = 0; k0 < k; k0 += TS) {
+    // split-K (gridDim.z > 1): this workgroup reduces k in [kb, ke) and leaves its partial in ws[z][m][n]
+    const int kper = ((k + (int)gridDim.z - 1) / (int)gridDim.z + TS - 1) / TS * TS;
+    const int kb = blockIdx.z * kper, ke = kb + kper < k ? kb + kper : k;
+    for (int k0 = kb; k0 < ke; k0 += TS) {
         for (int e = threadIdx.x; e < TS * TS; e += 256) {
             int r = e / TS, cc = e % TS;
             // choose the faster-varying index by stride to keep loads coalesced where possible
             int mi = m0 + r, ki = k0 + cc;
-            sa[r][cc] = (mi < m && ki < k) ? a[mi * ars + ki * acs] : 0.f;
+            sa[r][cc] = (mi < m && ki < ke) ? a[mi * ars + ki * acs] : 0.f;
             int kj = k0 + r, nj = n0 + cc;
-            sb[r][cc] = (kj < k && nj < n) ? b[kj * brs + nj * bcs] : 0.f;
+            sb[r][cc] = (kj < ke && nj < n) ? b[kj * brs + nj * bcs] : 0.f;
         }
         __syncthreads();
 #pragma unroll 8
@@ -44,12 +47,28 @@ __global__ __launch_bounds__(256) void sgemm_k(const float* __restrict__ a, long
         for (int j = 0; j < 2; ++j) {
             int mi = m0 + ty + i * 16, nj = n0 + tx + j * 16;
             if (mi < m && nj < n) {
+                if (gridDim.z > 1) { ws[((long long)blockIdx.z * m + mi) * n + nj] = acc[i][j]; continue; }
                 float v = alpha * acc[i][j];
                 if (bias) v += bias[nj];
                 if (beta != 0.f) v += beta * c[mi * ldc + nj];
                 c[mi * ldc + nj] = v;
             }
         }
+}
+// combine the split-K partials in split order (deterministic) and apply the epilogue
+__global__ __launch_bounds__(256) void sgemm_splitk_finish_k(const float* __restrict__ ws, int splits, float* __restrict__ c,
+                                                             long long ldc, int m, int n, float alpha, float beta,
+                                                             const float* __restrict__ bias, const float* __restrict__ alpha_dev) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)m * n) return;
+    if (alpha_dev) alpha *= alpha_dev[0];
+    float s = 0.f;
+    for (int z = 0; z < splits; ++z) s += ws[(long long)z * m * n + i];
+    const int mi = (int)(i / n), nj = (int)(i % n);
+    float v = alpha * s;
+    if (bias) v += bias[nj];
+    if (beta != 0.f) v += beta * c[mi * ldc + nj];
+    c[mi * ldc + nj] = v;
 }
 
 __global__ void l2norm_fwd_k(const float* __restrict__ x, int rows, int d, float* __restrict__ y, float* __restrict__ norm) {
@@ -101,14 +120,32 @@ __global__ void ce_fwd_bwd_k(float* __restrict__ logits, int rows, int n, int la
 
 }  // namespace
 
+static int sgemm_splits(int m, int n, int k) {
+    const long long tiles = (long long)mc_div_up(n, TS) * mc_div_up(m, TS);
+    long long s = 512 / tiles;                      // aim at ~2 workgroups per CU
+    const long long kmax = k / (4 * TS);            // at least 4 k-tiles per split
+    if (s > kmax) s = kmax;
+    if (s > 32) s = 32;
+    return s < 2 ? 1 : (int)s;
+}
+extern "C" long long mc_sgemm_ws_floats(int m, int n, int k) {
+    const int s = sgemm_splits(m, n, k);
+    return s > 1 ? (long long)s * m * n : 0;
+}
 extern "C" int mc_sgemm(const float* a, long long ars, long long acs, const float* b, long long brs, long long bcs,
                         float* c, long long ldc, int m, int n, int k, float alpha, float beta, const float* bias,
-                        const float* alpha_dev, void* stream) {
+                        const float* alpha_dev, float* ws, void* stream) {
     MC_CHECK(a && b && c && m > 0 && n > 0 && k > 0, "sgemm: bad args");
-    dim3 grid(mc_div_up(n, TS), mc_div_up(m, TS));
+    const int splits = ws ? sgemm_splits(m, n, k) : 1;
+    dim3 grid(mc_div_up(n, TS), mc_div_up(m, TS), splits);
     hipLaunchKernelGGL(sgemm_k, grid, dim3(256), 0, (hipStream_t)stream, a, ars, acs, b, brs, bcs, c, ldc, m, n, k, alpha,
-                       beta, bias, alpha_dev);
+                       beta, bias, alpha_dev, ws);
     MC_LAUNCH_CHECK();
+    if (splits > 1) {
+        hipLaunchKernelGGL(sgemm_splitk_finish_k, dim3(mc_div_up((long long)m * n, 256)), dim3(256), 0, (hipStream_t)stream, ws,
+                           splits, c, ldc, m, n, alpha, beta, bias, alpha_dev);
+        MC_LAUNCH_CHECK();
+    }
     return MC_OK;
 }
 __global__ void scale_f32_k(const float* __restrict__ x, const float* __restrict__ sd, float alpha, float* __restrict__ y,

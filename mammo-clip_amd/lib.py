@@ -123,7 +123,8 @@ _SIGS = {
     "mc_mask_bias": ([P, P, LL, P], I),
     "mc_eos_gather": ([P, P, I, I, I, P, P], I),
     "mc_eos_scatter": ([P, P, I, I, I, P, P], I),
-    "mc_sgemm": ([P, LL, LL, P, LL, LL, P, LL, I, I, I, F, F, P, P, P], I),
+    "mc_sgemm": ([P, LL, LL, P, LL, LL, P, LL, I, I, I, F, F, P, P, P, P], I),
+    "mc_sgemm_ws_floats": ([I, I, I], LL),
     "mc_scale_f32": ([P, P, F, P, LL, P], I),
     "mc_l2norm_fwd": ([P, I, I, P, P, P], I),
     "mc_l2norm_bwd": ([P, P, P, I, I, P, P], I),

@@ -511,8 +511,10 @@ def eos_scatter(dout, mask, b, t, h):
 
 # ------------------------------------------------------------------------------------------- heads / loss
 def sgemm(a, ars, acs, b, brs, bcs, c, ldc, m, n, k, alpha=1.0, beta=0.0, bias=None, alpha_dev=None):
+    nws = L.load().mc_sgemm_ws_floats(m, n, k)
+    ws = empty((nws,), torch.float32, c) if nws > 0 else None
     L.call("mc_sgemm", _p(a), ars, acs, _p(b), brs, bcs, _p(c), ldc, m, n, k, float(alpha), float(beta), _p(bias),
-           _p(alpha_dev), _st())
+           _p(alpha_dev), _p(ws), _st())
 
 
 def scale_f32(x, scalar_dev=None, alpha=1.0):

@@ -60,7 +60,7 @@ def test_abi_argument_validation_without_gpu():
     assert lib.mc_gemm_rows_supported(176, 1056) == 0
     assert lib.mc_wgrad_rows_supported(240, 40) == 1 and lib.mc_wgrad_rows_supported(512, 3072) == 0
     with pytest.raises(L.MammoClipHipError):
-        L.call("mc_sgemm", None, 0, 0, None, 0, 0, None, 0, 0, 0, 0, 1.0, 0.0, None, None, None)
+        L.call("mc_sgemm", None, 0, 0, None, 0, 0, None, 0, 0, 0, 0, 1.0, 0.0, None, None, None, None)
 
 
 def test_struct_layouts_match_header():
