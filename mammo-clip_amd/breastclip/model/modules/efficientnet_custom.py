@@ -158,7 +158,7 @@ class _MBConvFn(torch.autograd.Function):
             saved.update(we=we, e=e, st0=st0)
         else:
             dw_in, pro0 = x, None
-        wkkc = ops.transpose_f32(blk._depthwise_conv.weight.view(a.cexp, k * k))
+        wkkc = ops.transpose_f32(blk._depthwise_conv.weight.view(a.cexp, k * k), cache=True)
         d, part1 = ops.dwconv_fwd(dw_in, wkkc, n, h, w, a.cexp, k, s, l, t, oh, ow, pro=pro0, stats=True)
         st1 = _bn_stats(part1, n * ohw, blk._bn1, training)
         # Late stages (project conv on the tiled GEMM): the squeeze pass also stores A = silu(bn1(d)); the project GEMM

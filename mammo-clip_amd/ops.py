@@ -6,6 +6,8 @@ bf16 activations in row-major [rows, channels] (NHWC) layout unless noted, fp32 
 import ctypes as C
 import math
 
+import weakref
+
 import torch
 
 from . import lib as L
@@ -92,12 +94,37 @@ def _rows_ok(M, N, K, bias, act):
     return bias is None and act == 0 and M >= ROWS_MIN_M and L.load().mc_gemm_rows_supported(N, K)
 
 
+# Derived weight images (bf16 casts / transposes of fp32 master parameters) are reused until the parameter changes:
+# within one step both image views, the forward and the backward pass need the same image.  Only (views of) leaf
+# tensors are cached; an entry is tied to the owning tensor OBJECT through a weak reference (addresses and ids are
+# recycled by the allocator) and to its version counter (bumped by the optimizer's in-place update / load_state_dict).
+_WCACHE = {}
+
+
+def _cached(kind, src, make):
+    base = src._base if src._base is not None else src
+    if not base.is_leaf:
+        return make()
+    key = (kind, id(base), src.data_ptr(), tuple(src.shape), tuple(src.stride()))
+    hit = _WCACHE.get(key)
+    if hit is not None and hit[0]() is base and hit[1] == base._version and hit[2].device == src.device:
+        return hit[2]
+    val = make()
+    if len(_WCACHE) > 4096:
+        for k in [k for k, v in _WCACHE.items() if v[0]() is None]:
+            del _WCACHE[k]
+    _WCACHE[key] = (weakref.ref(base), base._version, val)
+    return val
+
+
 def cast_transpose_bf16(src2d):
     """fp32 [rows, cols] -> bf16 [cols, rows]"""
-    rows, cols = src2d.shape
-    dst = empty((cols, rows), BF16, src2d)
-    L.call("mc_cast_transpose_f32_bf16", _p(src2d.contiguous()), _p(dst), rows, cols, _st())
-    return dst
+    def make():
+        rows, cols = src2d.shape
+        dst = empty((cols, rows), BF16, src2d)
+        L.call("mc_cast_transpose_f32_bf16", _p(src2d.contiguous()), _p(dst), rows, cols, _st())
+        return dst
+    return _cached("ct", src2d, make)
 
 
 def linear_fwd(x, w, bias=None, act=0, residual=None, stats=False, pro=None, out=None):
@@ -185,10 +212,12 @@ def colsum(x, out=None, accumulate=False):
 
 
 def cast_bf16(src, out=None):
-    src = src.contiguous()
-    dst = out if out is not None else empty(src.shape, BF16, src)
-    L.call("mc_cast_f32_bf16", _p(src), _p(dst), src.numel(), _st())
-    return dst
+    def make():
+        s_ = src.contiguous()
+        dst = out if out is not None else empty(s_.shape, BF16, s_)
+        L.call("mc_cast_f32_bf16", _p(s_), _p(dst), s_.numel(), _st())
+        return dst
+    return make() if out is not None else _cached("c", src, make)
 
 
 def cast_f32(src):
@@ -198,11 +227,13 @@ def cast_f32(src):
     return dst
 
 
-def transpose_f32(src):
-    rows, cols = src.shape
-    dst = empty((cols, rows), torch.float32, src)
-    L.call("mc_transpose_f32", _p(src.contiguous()), _p(dst), rows, cols, _st())
-    return dst
+def transpose_f32(src, cache=False):
+    def make():
+        rows, cols = src.shape
+        dst = empty((cols, rows), torch.float32, src)
+        L.call("mc_transpose_f32", _p(src.contiguous()), _p(dst), rows, cols, _st())
+        return dst
+    return _cached("t", src, make) if cache else make()
 
 
 # ------------------------------------------------------------------------------------------- stem
