@@ -70,6 +70,13 @@ typedef struct mc_gemm_args {
     int max_grid_m;          /* 0 = default */
     float* splitk_ws;        /* optional float[splits*M*N]: split-K partial tiles are combined by a second kernel
                                 (C = sum, or C += sum when c_atomic) instead of per-element atomics */
+    /* grouped split-K (weight gradient of a conv whose input carries a per-image, per-channel factor, e.g. the SE gate):
+     * the reduction index is cut at multiples of split_group_rows (rows per image), split_sub splits per group
+     * (splits = groups * split_sub), and partial s is multiplied by split_scale[s / split_sub][column] when the
+     * partials are combined:  dW[n][k] = sum_img gate[img][k] * sum_{m in img} dY[m][n] * A[m][k]  -- no prologue needed */
+    long long split_group_rows;
+    int split_sub;
+    const float* split_scale;
 } mc_gemm_args;
 int mc_gemm_bf16(const mc_gemm_args* args, void* stream);
 int mc_gemm_stat_rows(const mc_gemm_args* args);

@@ -132,8 +132,17 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8) ? 4 : 2) void gemm
     // K range of this split (multiples of BK)
     const long long ktiles = (p.K + BK - 1) / BK;
     const long long tps = (ktiles + p.splits - 1) / p.splits;
-    const long long kbeg = (long long)split * tps * BK;
+    long long kbeg = (long long)split * tps * BK;
     long long kend = kbeg + tps * BK;
+    if (p.split_group_rows > 0) {
+        // grouped split-K: the reduction index is cut at group (= image) boundaries, split_sub splits per group, so
+        // that a per-(group, column) factor can be applied when the partials are combined (see splitk_reduce_kernel)
+        const long long grp = split / p.split_sub, j = split % p.split_sub;
+        const long long chunk = (p.split_group_rows + p.split_sub - 1) / p.split_sub;
+        kbeg = grp * p.split_group_rows + j * chunk;
+        kend = kbeg + chunk;
+        if (kend > (grp + 1) * p.split_group_rows) kend = (grp + 1) * p.split_group_rows;
+    }
     if (kend > p.K) kend = p.K;
     const long long mtiles = (p.M + BM - 1) / BM;
     const bool n_full = n0 + BN <= p.N;
@@ -475,14 +484,20 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8) ? 4 : 2) void gemm
 }
 
 // C[m,n] (+)= sum_s ws[s][m][n]  (deterministic split-K combine; replaces per-element atomics)
+// scale (optional): float[splits / sub][n], partial k is multiplied by scale[k / sub][column] (grouped split-K)
 __global__ void splitk_reduce_kernel(const float* __restrict__ ws, int splits, long long mn, int n, float* __restrict__ C,
-                                     long long ldc, int accumulate) {
+                                     long long ldc, int accumulate, const float* __restrict__ scale, int sub) {
     long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i >= mn) return;
     if (i + 4 <= mn && (n & 3) == 0) {
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int col = (int)(i % n);
         for (int k = 0; k < splits; ++k) {
             float4 v = *reinterpret_cast<const float4*>(ws + (long long)k * mn + i);
+            if (scale) {
+                const float4 g = *reinterpret_cast<const float4*>(scale + (long long)(k / sub) * n + col);
+                v.x *= g.x; v.y *= g.y; v.z *= g.z; v.w *= g.w;
+            }
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         }
         long long m = i / n;
@@ -493,7 +508,8 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, int splits, l
     } else {
         for (long long j = i; j < mn && j < i + 4; ++j) {
             float s = 0.f;
-            for (int k = 0; k < splits; ++k) s += ws[(long long)k * mn + j];
+            for (int k = 0; k < splits; ++k)
+                s += ws[(long long)k * mn + j] * (scale ? scale[(long long)(k / sub) * n + j % n] : 1.f);
             float* d = C + (j / n) * ldc + (j % n);
             *d = accumulate ? *d + s : s;
         }
@@ -509,7 +525,8 @@ int launch(const mc_gemm_args& p, int grid_m, hipStream_t st) {
     if (p.splits > 1 && p.splitk_ws) {
         long long mn = p.M * p.N;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(mc_div_up(mc_div_up(mn, 4), NT)), dim3(NT), 0, st, p.splitk_ws,
-                           p.splits, mn, p.N, reinterpret_cast<float*>(p.C), p.ldc, p.c_atomic);
+                           p.splits, mn, p.N, reinterpret_cast<float*>(p.C), p.ldc, p.c_atomic, p.split_scale,
+                           p.split_sub > 0 ? p.split_sub : 1);
         MC_LAUNCH_CHECK();
     }
     return MC_OK;
@@ -558,6 +575,10 @@ extern "C" int mc_gemm_bf16(const mc_gemm_args* a, void* stream) {
     if (p.splits <= 0) p.splits = 1;
     MC_CHECK(p.splits == 1 || (p.c_f32 && (p.c_atomic || p.splitk_ws)), "gemm: split-K needs fp32 output + workspace or atomics");
     MC_CHECK(!(p.splits > 1 && p.splitk_ws) || (p.batch == 1 && !p.bias), "gemm: workspace split-K is unbatched, no bias");
+    MC_CHECK(p.split_group_rows == 0 || (p.splitk_ws && p.split_sub > 0 && p.splits % p.split_sub == 0 &&
+                                         (long long)(p.splits / p.split_sub) * p.split_group_rows >= p.K),
+             "gemm: grouped split-K needs the workspace, splits = groups * split_sub and groups * split_group_rows >= K");
+    MC_CHECK(!p.split_scale || p.split_group_rows > 0, "gemm: split_scale needs grouped split-K");
     MC_CHECK(!(p.stat_partials && (p.c_f32 || p.batch != 1 || p.splits != 1)), "gemm: stats need plain bf16 output");
     MC_CHECK(p.pro_operand == 0 || (p.pro_scale && p.pro_shift) || (!p.pro_scale && !p.pro_shift && p.pro_gate),
              "gemm: prologue needs scale+shift (BN+SiLU) and/or a gate");

@@ -32,6 +32,7 @@ class GemmArgs(C.Structure):
         ("stat_partials", P),
         ("max_grid_m", I),
         ("splitk_ws", P),
+        ("split_group_rows", LL), ("split_sub", I), ("split_scale", P),
     ]
 
 

@@ -42,8 +42,8 @@ def empty(shape, dtype, like):
 # ------------------------------------------------------------------------------------------- GEMM
 def gemm(A, B, C_out, M, N, K, lda, ldb, ldc, a_kmajor=0, b_kmajor=0, c_f32=0, c_atomic=0, splits=1,
          batch=1, nb2=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), bias=None, bias_stride1=0, act=0, R=None, ldr=0,
-         alpha=1.0, pro=None, stat_partials=None, max_grid_m=0, splitk_ws=None, kind=None):
-    """pro = (operand, scale, shift, gate or None, rows_per_img, nch)"""
+         alpha=1.0, pro=None, stat_partials=None, max_grid_m=0, splitk_ws=None, split_groups=None, kind=None):
+    """pro = (operand, scale, shift, gate or None, rows_per_img, nch); split_groups = (rows per group, sub-splits, scale)"""
     a = L.GemmArgs()
     a.A, a.B, a.C = _p(A), _p(B), _p(C_out)
     a.M, a.K, a.N = M, K, N
@@ -60,6 +60,8 @@ def gemm(A, B, C_out, M, N, K, lda, ldb, ldc, a_kmajor=0, b_kmajor=0, c_f32=0, c
     a.stat_partials = _p(stat_partials)
     a.max_grid_m = max_grid_m
     a.splitk_ws = _p(splitk_ws)
+    if split_groups is not None:
+        a.split_group_rows, a.split_sub, a.split_scale = split_groups[0], split_groups[1], _p(split_groups[2])
     _note(batch * (2 * M * K + 2 * N * K + (4 if c_f32 else 2) * M * N + (2 * M * N if R is not None else 0)),
           2 * batch * M * N * K)
     L.call("mc_gemm_bf16", C.byref(a), _st(), kind=kind)
@@ -188,6 +190,19 @@ def linear_wgrad(dy, x, pro=None, out=None):
             a.pro_scale, a.pro_shift, a.pro_gate, a.pro_rows_per_img = _p(pro[0]), _p(pro[1]), _p(pro[2]), pro[3]
         _note(2 * M * (N + K) + 4 * N * K, 2 * M * N * K)
         L.call("mc_wgrad_rows_bf16", C.byref(a), _st(), kind="wgrad_rows")
+        return dw
+    if pro is not None and pro[0] is None and M % pro[3] == 0:
+        # x is already activated and only carries the per-image gate: cut the reduction at image boundaries and apply
+        # the gate when the partials are combined (dW = sum_img gate_img (.) dW_img) -- a plain TN GEMM, no prologue
+        n_img, hw = M // pro[3], pro[3]
+        tiles = math.ceil(N / 128) * math.ceil(K / 128)
+        sub = max(1, min(math.ceil(768 / (tiles * n_img)), hw // 512))
+        if (n_img * sub) % 8 and n_img * sub >= 16:
+            sub = max(1, sub - 1) if (n_img * (sub - 1)) % 8 == 0 and sub > 1 else sub
+        splits = n_img * sub
+        ws = empty((splits, N, K), torch.float32, dy)
+        gemm(dy, x, dw, N, K, M, dy.stride(0), x.stride(0), dw.stride(0), a_kmajor=1, b_kmajor=1, c_f32=1,
+             c_atomic=(1 if out is not None else 0), splits=splits, splitk_ws=ws, split_groups=(hw, sub, pro[2]), kind="wgrad")
         return dw
     p = None
     if pro is not None:
