@@ -101,7 +101,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8) ? 4 : 2) void gemm
     // from HBM once per row block and the other column tiles hit that XCD's L2 (grid.y is padded to a multiple of 8).
     // Only when there are enough row workgroups to keep the XCDs balanced (gm is then a multiple of 8).
     int bx = blockIdx.x, by = blockIdx.y;
-    if (gm >= 16) {
+    if (gm >= 16 && (gm & 7) == 0) {
         const int lin = blockIdx.y * gridDim.x + blockIdx.x;
         bx = (lin >> 3) % gridDim.x;
         by = ((lin >> 3) / gridDim.x) * 8 + (lin & 7);
@@ -252,6 +252,17 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8) ? 4 : 2) void gemm
                     uint4 v = keep4(full || b_valid(i, k0), rb[i]);
                     if (!BKM) {
                         const int row = c / KCH, kc = c % KCH;
+                        if (PRO == 3) {          // batch = image: the SE gate of this image scales the weight columns
+                            const long long k = k0 + kc * 8;
+                            if (k < kend) {
+                                float f[8], g[8];
+                                unpack8(v, f);
+                                load8f(p.pro_gate + (long long)b1 * p.pro_nch + k, g);
+#pragma unroll
+                                for (int q = 0; q < 8; ++q) f[q] *= g[q];
+                                v = pack8(f);
+                            }
+                        }
                         *reinterpret_cast<uint4*>(sB + row * ROWB + kc * 16) = v;
                     } else {
                         const int xc = c % (BN / 8), kr = c / (BN / 8);
@@ -475,7 +486,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8) ? 4 : 2) void gemm
             for (int r = 0; r < RPP; ++r) { s += red[(r * BN + c) * 2]; s2 += red[(r * BN + c) * 2 + 1]; }
             int n = n0 + c;
             if (n < p.N) {
-                float* dst = p.stat_partials + (long long)by * 2 * p.N;
+                float* dst = p.stat_partials + ((long long)bz * gm + by) * 2 * p.N;
                 dst[n] = s;
                 dst[p.N + n] = s2;
             }
@@ -549,13 +560,28 @@ int dispatch_tile(const mc_gemm_args& p, int grid_m, hipStream_t st) {
 
 }  // namespace
 
+// persistent row-block workgroups per (column tile, batch/split)
+static int pick_grid_m(const mc_gemm_args& p) {
+    long long mtiles = (p.M + 127) / 128;
+    long long cap = p.max_grid_m > 0 ? p.max_grid_m : 512;
+    long long gm = mtiles < cap ? mtiles : cap;
+    if (!p.stat_partials && p.max_grid_m <= 0) {
+        // persistent over row blocks only as far as it keeps >= ~4 workgroups per CU in the grid
+        long long nt = mc_div_up(p.N, 128) * (long long)(p.batch > 0 ? p.batch : 1) * (p.splits > 0 ? p.splits : 1);
+        long long want = 2048 / (nt > 0 ? nt : 1);
+        if (want < 1) want = 1;
+        gm = mtiles < want ? mtiles : want;
+    }
+    // XCD-aware placement (see gemm_kernel) wants a multiple of 8; only where every workgroup has several row blocks
+    if (gm >= 16 && mtiles >= 2 * gm) gm &= ~7LL;
+    return (int)gm;
+}
 extern "C" int mc_gemm_stat_rows(const mc_gemm_args* a) {
-    // number of partial rows the launch will write ( = gridDim.y )
-    long long mtiles = (a->M + 127) / 128;
-    long long cap = a->max_grid_m > 0 ? a->max_grid_m : 512;
-    int gm = (int)(mtiles < cap ? mtiles : cap);
-    if (gm >= 16) gm &= ~7;                             // XCD-aware placement (see gemm_kernel) wants a multiple of 8
-    return gm;
+    // number of partial rows the launch will write ( = row-block workgroups x batch )
+    mc_gemm_args q = *a;
+    static float dummy;
+    q.stat_partials = &dummy;                      // the row count of a launch WITH statistics
+    return pick_grid_m(q) * (a->batch > 0 ? a->batch : 1);
 }
 
 extern "C" int mc_gemm_bf16(const mc_gemm_args* a, void* stream) {
@@ -579,29 +605,22 @@ extern "C" int mc_gemm_bf16(const mc_gemm_args* a, void* stream) {
                                          (long long)(p.splits / p.split_sub) * p.split_group_rows >= p.K),
              "gemm: grouped split-K needs the workspace, splits = groups * split_sub and groups * split_group_rows >= K");
     MC_CHECK(!p.split_scale || p.split_group_rows > 0, "gemm: split_scale needs grouped split-K");
-    MC_CHECK(!(p.stat_partials && (p.c_f32 || p.batch != 1 || p.splits != 1)), "gemm: stats need plain bf16 output");
+    MC_CHECK(!(p.stat_partials && (p.c_f32 || p.splits != 1 || p.nb2 != 1)), "gemm: stats need plain bf16 output");
     MC_CHECK(p.pro_operand == 0 || (p.pro_scale && p.pro_shift) || (!p.pro_scale && !p.pro_shift && p.pro_gate),
              "gemm: prologue needs scale+shift (BN+SiLU) and/or a gate");
     MC_CHECK(p.pro_operand != 1 || (!p.a_kmajor && !p.b_kmajor && !p.c_f32), "gemm: A prologue is provided for NT, bf16 output");
     MC_CHECK(p.pro_operand != 2 || (p.a_kmajor && p.b_kmajor && p.c_f32), "gemm: B prologue is provided for TN, fp32 output");
+    MC_CHECK(p.pro_operand != 3 || (!p.a_kmajor && !p.b_kmajor && !p.c_f32 && p.pro_gate && !p.pro_scale && p.nb2 == 1),
+             "gemm: the per-batch weight gate is provided for NT, bf16 output, gate only");
     MC_CHECK(!p.R || (!p.c_f32 && p.ldr % 8 == 0), "gemm: residual needs bf16 output and ldr % 8 == 0");
     if (p.alpha == 0.f) p.alpha = 1.f;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    long long mtiles = (p.M + 127) / 128;
-    long long cap = p.max_grid_m > 0 ? p.max_grid_m : 512;
-    int grid_m = (int)(mtiles < cap ? mtiles : cap);
-    if (!p.stat_partials && p.max_grid_m <= 0) {
-        // persistent over row blocks only as far as it keeps >= ~4 workgroups per CU in the grid
-        long long nt = mc_div_up(p.N, 128) * (long long)p.batch * p.splits;
-        long long want = 2048 / (nt > 0 ? nt : 1);
-        if (want < 1) want = 1;
-        grid_m = (int)(mtiles < want ? mtiles : want);
-    }
-    if (grid_m >= 16) grid_m &= ~7;                     // persistent over row blocks: any count works; 8 | grid_m balances the XCDs
+    const int grid_m = pick_grid_m(p);
     const int lay = p.a_kmajor ? 2 : (p.b_kmajor ? 1 : 0);
     if (lay == 0) {
         if (p.c_f32) return dispatch_tile<0, 0, true>(p, grid_m, st);
         if (p.pro_operand == 1) return dispatch_tile<0, 1, false>(p, grid_m, st);
+        if (p.pro_operand == 3) return dispatch_tile<0, 3, false>(p, grid_m, st);
         return dispatch_tile<0, 0, false>(p, grid_m, st);
     }
     if (lay == 1) {

@@ -67,9 +67,9 @@ def gemm(A, B, C_out, M, N, K, lda, ldb, ldc, a_kmajor=0, b_kmajor=0, c_f32=0, c
     L.call("mc_gemm_bf16", C.byref(a), _st(), kind=kind)
 
 
-def gemm_stat_rows(M):
+def gemm_stat_rows(M, N=128, batch=1):
     a = L.GemmArgs()
-    a.M = M
+    a.M, a.N, a.batch = M, N, batch
     return L.load().mc_gemm_stat_rows(C.byref(a))
 
 
@@ -138,9 +138,17 @@ def linear_fwd(x, w, bias=None, act=0, residual=None, stats=False, pro=None, out
         part = empty((L.load().mc_gemm_rows_blocks(M), 2, N), torch.float32, x) if stats else None
         gemm_rows(x, w, y, residual=residual, pro=pro, stat_partials=part, kind="fwd_rows")
         return (y, part) if stats else y
+    if pro is not None and pro[0] is None and residual is None and bias is None and M % pro[3] == 0 and pro[3] >= 256:
+        # x is already activated and only carries the per-image gate: one GEMM per image (batched) whose weight tile
+        # is scaled by that image's gate while it is staged -- no per-row prologue on the big operand
+        hw, n_img = pro[3], M // pro[3]
+        part = empty((gemm_stat_rows(hw, N, n_img), 2, N), torch.float32, x) if stats else None
+        gemm(x, w, y, hw, N, K, x.stride(0), w.stride(0), y.stride(0), batch=n_img, sA=(hw * x.stride(0), 0),
+             sC=(hw * y.stride(0), 0), pro=(3, None, None, pro[2], hw, K), stat_partials=part, kind="fwd")
+        return (y, part) if stats else y
     part = None
     if stats:
-        part = empty((gemm_stat_rows(M), 2, N), torch.float32, x)
+        part = empty((gemm_stat_rows(M, N), 2, N), torch.float32, x)
     p = None
     if pro is not None:
         p = (1, pro[0], pro[1], pro[2], pro[3], K)

@@ -196,6 +196,29 @@ def test_wgrad_rows_streaming(M, N, K):
     check(dw3, dy.float().T @ a1, 2e-3, "wgrad rows prologue")
 
 
+@pytest.mark.parametrize("n_img,hw,N,K", [(4, 300, 176, 1056), (3, 1392, 304, 1824), (8, 256, 40, 768)])
+def test_gate_only_project_paths(n_img, hw, N, K):
+    """late-stage project conv on an already activated input: forward = one GEMM per image with the weight tile scaled by
+    that image's SE gate (+ BN statistics across the batch); weight gradient = split-K cut at image boundaries with the
+    gate applied when the partials are combined"""
+    M = n_img * hw
+    x, w = rnd(M, K, seed=101), rnd(N, K, seed=102, scale=K ** -0.5)
+    gate = torch.sigmoid(rnd(n_img, K, seed=103, dtype=torch.float32))
+    img = torch.arange(M, device=DEV) // hw
+    xg = x.float() * gate[img]
+    y, part = ops.linear_fwd(x, w, stats=True, pro=(None, None, gate, hw))
+    # the gate is folded into the bf16 weight tile: compare against gate-scaled, bf16-rounded weights per image
+    ref = torch.cat([x[i * hw:(i + 1) * hw].float() @ (w.float() * gate[i]).to(BF).float().T for i in range(n_img)])
+    check(y, ref, 1e-2, "gate-only fwd")
+    st = part.double().sum(0)
+    yf = y.float().double()
+    check(st[0].float(), yf.sum(0).float(), 1e-4, "gate-only colsum")
+    check(st[1].float(), (yf * yf).sum(0).float(), 1e-4, "gate-only colsumsq")
+    dy = rnd(M, N, seed=104)
+    dw = ops.linear_wgrad(dy, x, pro=(None, None, gate, hw))
+    check(dw, dy.float().T @ xg, 3e-3, "gate-only wgrad")
+
+
 # ------------------------------------------------------------------------------------------------ stem
 @pytest.mark.parametrize("nhwc_view", [False, True])
 def test_stem_im2col_gemm(nhwc_view):
