@@ -132,7 +132,7 @@ def main():
         for t in list(model.parameters()) + list(model.buffers()):
             dist.broadcast(t.data, 0)
     loss_func = build_loss(LOSS_CFG)
-    opt = build_optimizer(model, {"name": "adamw", "config": {"lr": 5e-5, "weight_decay": 1e-4, "fused": True}})
+    opt = build_optimizer(model, {"name": "adamw", "config": {"lr": 5e-5, "weight_decay": 1e-4}})
     sched = LinearWarmupCosineAnnealingLR(opt, total_steps=10000, warmup_steps=100)
     trainer = engine.Trainer(model, loss_func, opt, sched, device)
     batch = synth_batch_gpu(b, H, W, T, device, seed=10 + rank)

@@ -310,6 +310,23 @@ int mc_l2norm_bwd(const float* dy, const float* y, const float* norm, int rows, 
 int mc_ce_fwd_bwd(float* logits, int rows, int n, int label_offset, float w, float smoothing, float* loss_out,
                   void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * optimizer step of the hot loop [ref: breastclip/optimizer/__init__.py:28-29 ->
+ * torch.optim.AdamW(model.parameters(), lr, weight_decay); trainer_ddp.py:300-303].  Multi-tensor, in place, fp32:
+ *   p -= lr*wd*p;  m += (1-b1)(g-m);  v = b2*v + (1-b2) g*g;  p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+ * `tensors` is a HOST array of device pointers (one entry per parameter); `step` = t >= 1 (after increment).
+ * The LR schedule [ref: breastclip/scheduler/warmup_cosine.py:41-50] is a host scalar: pass the scheduled lr.
+ * Hyper-parameters are doubles: the derived scalars (1-b2, bias corrections) are formed in double as torch does. */
+typedef struct {
+    float* param;
+    const float* grad;
+    float* exp_avg;
+    float* exp_avg_sq;
+    long long numel;
+} mc_adamw_tensor;
+int mc_adamw_step(const mc_adamw_tensor* tensors, int n_tensors, double lr, double beta1, double beta2, double eps,
+                  double weight_decay, long long step, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

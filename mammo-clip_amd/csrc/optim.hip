@@ -1,0 +1,135 @@
+// Multi-tensor AdamW update for the hot loop's optimizer step [ref: breastclip/optimizer/__init__.py:28-29 builds
+// torch.optim.AdamW over ALL parameters; trainer_ddp.py:300-303 steps it once per iteration].
+// HBM-bound: 16 B read + 12 B written per element (param, grad, exp_avg, exp_avg_sq), ~3.9 GB for the 138 M-parameter
+// B5 + BERT model.  Up to MC_ADAMW_PACK tensors go into one launch (pointers travel as kernel arguments, no device
+// table to keep in sync); a workgroup owns one CHUNK of one tensor, found by a scan over the pack's chunk prefix.
+#include "common.cuh"
+#include "../../include/mammoclip_hip.h"
+
+namespace {
+
+constexpr int PACK = 48;             // tensors per launch: 48 * 36 B + scalars stays far below the 4 KB argument limit
+constexpr int CHUNK = 16384;         // elements per workgroup: 64 KB per stream in flight across its 256 lanes
+
+struct AdamPack {
+    float* p[PACK];
+    const float* g[PACK];
+    float* m[PACK];
+    float* v[PACK];
+    int first_chunk[PACK + 1];       // prefix of chunk counts
+    long long n[PACK];
+};
+
+struct AdamScalars {
+    float lr_wd;        // lr * weight_decay
+    float beta1, beta2;
+    float one_m_beta1, one_m_beta2;
+    float step_size;    // lr / (1 - beta1^t)
+    float inv_bc2_sqrt; // 1 / sqrt(1 - beta2^t)
+    float eps;
+};
+
+__device__ __forceinline__ void adamw1(float& p, float g, float& m, float& v, const AdamScalars& s) {
+    // same operation order as torch's AdamW: decoupled decay first, moments, then the bias-corrected step
+    p -= s.lr_wd * p;
+    m = m + s.one_m_beta1 * (g - m);
+    v = s.beta2 * v + s.one_m_beta2 * g * g;
+    const float denom = sqrtf(v) * s.inv_bc2_sqrt + s.eps;
+    p -= s.step_size * (m / denom);
+}
+
+__global__ void __launch_bounds__(256) adamw_multi_k(AdamPack pk, int count, AdamScalars s) {
+    int t = 0;
+    const int blk = blockIdx.x;
+    while (t + 1 < count && pk.first_chunk[t + 1] <= blk) ++t;       // uniform scan, <= PACK scalar compares
+    const long long n = pk.n[t];
+    const long long base = (long long)(blk - pk.first_chunk[t]) * CHUNK;
+    float* __restrict__ p = pk.p[t] + base;
+    const float* __restrict__ g = pk.g[t] + base;
+    float* __restrict__ m = pk.m[t] + base;
+    float* __restrict__ v = pk.v[t] + base;
+    const long long left = n - base;
+    const int len = left < CHUNK ? (int)left : CHUNK;
+    const bool vec = ((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) == 0;
+    int i = threadIdx.x * 4;
+    if (vec) {
+        // 2 float4 per array in flight per lane (8 loads) before the first use
+        for (; i + 1024 + 3 < len; i += 2048) {
+            float4 P0 = *(const float4*)(p + i), P1 = *(const float4*)(p + i + 1024);
+            float4 G0 = *(const float4*)(g + i), G1 = *(const float4*)(g + i + 1024);
+            float4 M0 = *(const float4*)(m + i), M1 = *(const float4*)(m + i + 1024);
+            float4 V0 = *(const float4*)(v + i), V1 = *(const float4*)(v + i + 1024);
+            adamw1(P0.x, G0.x, M0.x, V0.x, s); adamw1(P0.y, G0.y, M0.y, V0.y, s);
+            adamw1(P0.z, G0.z, M0.z, V0.z, s); adamw1(P0.w, G0.w, M0.w, V0.w, s);
+            adamw1(P1.x, G1.x, M1.x, V1.x, s); adamw1(P1.y, G1.y, M1.y, V1.y, s);
+            adamw1(P1.z, G1.z, M1.z, V1.z, s); adamw1(P1.w, G1.w, M1.w, V1.w, s);
+            *(float4*)(p + i) = P0; *(float4*)(p + i + 1024) = P1;
+            *(float4*)(m + i) = M0; *(float4*)(m + i + 1024) = M1;
+            *(float4*)(v + i) = V0; *(float4*)(v + i + 1024) = V1;
+        }
+        for (; i + 3 < len; i += 1024) {
+            float4 P0 = *(const float4*)(p + i), G0 = *(const float4*)(g + i);
+            float4 M0 = *(const float4*)(m + i), V0 = *(const float4*)(v + i);
+            adamw1(P0.x, G0.x, M0.x, V0.x, s); adamw1(P0.y, G0.y, M0.y, V0.y, s);
+            adamw1(P0.z, G0.z, M0.z, V0.z, s); adamw1(P0.w, G0.w, M0.w, V0.w, s);
+            *(float4*)(p + i) = P0; *(float4*)(m + i) = M0; *(float4*)(v + i) = V0;
+        }
+        // ragged tail of the chunk: the (< 4) elements after the last whole float4
+        const int done = len & ~3;
+        const int j = done + threadIdx.x;
+        if (j < len) {
+            float P = p[j], M = m[j], V = v[j];
+            adamw1(P, g[j], M, V, s);
+            p[j] = P; m[j] = M; v[j] = V;
+        }
+    } else {
+        for (int j = threadIdx.x; j < len; j += 256) {
+            float P = p[j], M = m[j], V = v[j];
+            adamw1(P, g[j], M, V, s);
+            p[j] = P; m[j] = M; v[j] = V;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int mc_adamw_step(const mc_adamw_tensor* tensors, int n_tensors, double lr, double beta1, double beta2,
+                             double eps, double weight_decay, long long step, void* stream) {
+    MC_CHECK(n_tensors >= 0 && (tensors || n_tensors == 0), "adamw: bad tensor list");
+    MC_CHECK(step >= 1 && beta1 >= 0.0 && beta1 < 1.0 && beta2 >= 0.0 && beta2 < 1.0 && eps >= 0.0, "adamw: bad hyper-parameters");
+    // scalars are derived in double like torch does on the host (1 - 0.999 in fp32 is already 1.3e-5 off)
+    AdamScalars s;
+    s.lr_wd = (float)(lr * weight_decay);
+    s.beta1 = (float)beta1; s.beta2 = (float)beta2;
+    s.one_m_beta1 = (float)(1.0 - beta1); s.one_m_beta2 = (float)(1.0 - beta2);
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+    s.step_size = (float)(lr / bc1);
+    s.inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+    s.eps = (float)eps;
+    AdamPack pk;
+    int cnt = 0, chunks = 0;
+    auto flush = [&]() -> int {
+        if (cnt == 0) return MC_OK;
+        pk.first_chunk[cnt] = chunks;
+        hipLaunchKernelGGL(adamw_multi_k, dim3(chunks), dim3(256), 0, (hipStream_t)stream, pk, cnt, s);
+        MC_LAUNCH_CHECK();
+        cnt = 0; chunks = 0;
+        return MC_OK;
+    };
+    for (int i = 0; i < n_tensors; ++i) {
+        const mc_adamw_tensor& t = tensors[i];
+        if (t.numel == 0) continue;
+        MC_CHECK(t.param && t.grad && t.exp_avg && t.exp_avg_sq && t.numel > 0, "adamw: null tensor pointer");
+        const long long nch = (t.numel + CHUNK - 1) / CHUNK;
+        MC_CHECK(nch < (1ll << 30), "adamw: tensor too large");
+        if (cnt == PACK || (long long)chunks + nch > (1ll << 30)) {
+            int r = flush();
+            if (r != MC_OK) return r;
+        }
+        pk.p[cnt] = t.param; pk.g[cnt] = t.grad; pk.m[cnt] = t.exp_avg; pk.v[cnt] = t.exp_avg_sq;
+        pk.n[cnt] = t.numel; pk.first_chunk[cnt] = chunks;
+        chunks += (int)nch;
+        ++cnt;
+    }
+    return flush();
+}

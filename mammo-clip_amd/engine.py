@@ -25,7 +25,7 @@ class GradBuckets:
         cur, cur_n = [], 0
         for p in reversed(self.params):
             cur.append(p)
-            cur_n += p.numel()
+            cur_n += -(-p.numel() // 64) * 64          # every slot starts 256-byte aligned (vector loads in AdamW)
             if cur_n * 4 >= bucket_bytes:
                 self._close(cur, cur_n)
                 cur, cur_n = [], 0
@@ -41,7 +41,7 @@ class GradBuckets:
         off, views = 0, []
         for p in plist:
             views.append(flat[off:off + p.numel()].view_as(p))
-            off += p.numel()
+            off += -(-p.numel() // 64) * 64
         idx = len(self.buckets)
         self.buckets.append((flat, plist, views))
         for p, v in zip(plist, views):

@@ -76,8 +76,13 @@ class BnactArgs(C.Structure):
     ]
 
 
+class AdamwTensor(C.Structure):
+    _fields_ = [("param", P), ("grad", P), ("exp_avg", P), ("exp_avg_sq", P), ("numel", LL)]
+
+
 _SIGS = {
     "mc_version": ([], I),
+    "mc_adamw_step": ([C.POINTER(AdamwTensor), I, D, D, D, D, D, LL, P], I),
     "mc_gemm_bf16": ([C.POINTER(GemmArgs), P], I),
     "mc_gemm_stat_rows": ([C.POINTER(GemmArgs)], I),
     "mc_gemm_rows_supported": ([I, I], I),

@@ -65,15 +65,16 @@ def test_abi_argument_validation_without_gpu():
 
 def test_struct_layouts_match_header():
     """ctypes mirrors must have the C struct sizes (checked against a C compile of the header)"""
-    src = '#include <stdio.h>\n#include "mammoclip_hip.h"\nint main(){printf("%zu %zu %zu %zu %zu\\n", sizeof(mc_gemm_args),' \
-          ' sizeof(mc_dwconv_args), sizeof(mc_bnact_args), sizeof(mc_gemm_rows_args), sizeof(mc_wgrad_rows_args));return 0;}\n'
+    src = '#include <stdio.h>\n#include "mammoclip_hip.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(mc_gemm_args),' \
+          ' sizeof(mc_dwconv_args), sizeof(mc_bnact_args), sizeof(mc_gemm_rows_args), sizeof(mc_wgrad_rows_args),' \
+          ' sizeof(mc_adamw_tensor));return 0;}\n'
     exe = os.path.join("/tmp", "mc_sizes_test")
     with open(exe + ".c", "w") as f:
         f.write(src)
     subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), exe + ".c", "-o", exe], check=True)
     sizes = [int(x) for x in subprocess.run([exe], check=True, capture_output=True, text=True).stdout.split()]
     assert sizes == [ctypes.sizeof(L.GemmArgs), ctypes.sizeof(L.DwconvArgs), ctypes.sizeof(L.BnactArgs),
-                     ctypes.sizeof(L.GemmRowsArgs), ctypes.sizeof(L.WgradRowsArgs)]
+                     ctypes.sizeof(L.GemmRowsArgs), ctypes.sizeof(L.WgradRowsArgs), ctypes.sizeof(L.AdamwTensor)]
 
 
 # ------------------------------------------------------------------------------------------------ host mirror
@@ -147,6 +148,14 @@ def test_no_cpu_fallback():
         model.text_encoder({"input_ids": torch.zeros(1, 8, dtype=torch.long), "attention_mask": torch.ones(1, 8, dtype=torch.long)})
     with pytest.raises(RuntimeError, match="HIP device"):
         model.image_projection(torch.zeros(2, 1408))
+    from mammo_clip_amd.breastclip.optimizer import AdamW
+    w = torch.nn.Parameter(torch.zeros(4))
+    w.grad = torch.ones(4)
+    with pytest.raises(L.MammoClipHipError, match="only path"):
+        AdamW([w], lr=1e-3).step()
+    lib = L.load()
+    assert lib.mc_adamw_step(None, 3, 1e-3, 0.9, 0.999, 1e-8, 0.0, 1, None) != 0     # null list
+    assert lib.mc_adamw_step(None, 0, 1e-3, 0.9, 0.999, 1e-8, 0.0, 0, None) != 0     # step must be >= 1
 
 
 def test_global_env_and_scheduler():
