@@ -119,3 +119,30 @@ def init_distributed():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group(backend="nccl", init_method="env://", world_size=world, rank=rank, device_id=device)
     return rank, local, world, device
+
+
+@torch.no_grad()
+def validate(model, loss_func, dataloader_dict: Dict, device=None, max_batches: int = 11) -> Dict[str, Dict[str, float]]:
+    """Validation pass of the hot loop's caller [ref: trainer_ddp.py:346-409]: eval mode, ``is_train=False`` losses,
+    mean over ranks per batch (the reference's all_reduce(SUM)/world, C5 -- here ONE collective per batch for the
+    whole loss dict), accumulated per loss key and divided by ``len(dataloader)``.  Reference quirk kept: at most 11
+    batches (``idx == 10: break``) are evaluated but the average still divides by the full loader length."""
+    model.eval()
+    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    out = {}
+    for name, loader in dataloader_dict.items():
+        keys = ["total"] + [l.name for l in loss_func.loss_list if l.name != "total"]
+        acc = None
+        for idx, batch in enumerate(loader):
+            ld = loss_func(**model(batch, device), is_train=False)
+            vec = torch.stack([ld[k].detach().float().reshape(()) for k in keys])
+            if world > 1:
+                dist.all_reduce(vec, op=dist.ReduceOp.SUM)
+                vec = vec / world
+            acc = vec if acc is None else acc + vec          # stays on the device: one host sync per dataset
+            if idx + 1 >= max_batches:
+                break
+        n = max(len(loader), 1)
+        vals = (acc / n).cpu().tolist() if acc is not None else [0.0] * len(keys)
+        out[name] = dict(zip(keys, vals))
+    return out

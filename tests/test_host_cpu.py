@@ -2,6 +2,7 @@
 LR schedule, and the world_size-2 collectives (gloo).  No HIP kernel is launched here."""
 import ctypes
 import math
+import numpy as np
 import os
 import re
 import subprocess
@@ -176,6 +177,40 @@ def test_global_env_and_scheduler():
     assert all(abs(a - b) < 1e-9 for a, b in zip(lrs, ref))
 
 
+class _ToyModel(torch.nn.Module):
+    def forward(self, batch, device=None):
+        assert not self.training and not torch.is_grad_enabled()
+        return {"x": batch["x"]}
+
+
+class _ToyLoss:
+    loss_list = [types.SimpleNamespace(name="contrastive", loss_ratio=1.0)]
+
+    def __call__(self, x, is_train):
+        assert is_train is False
+        return {"contrastive": x * 2.0, "total": x}
+
+
+def test_validate_matches_reference_loop_semantics():
+    """row N3 [ref: trainer_ddp.py:346-409]: eval mode + no_grad, is_train=False, per-key accumulation, the
+    ``idx == 10: break`` quirk (11 batches evaluated) with division by the FULL loader length"""
+    from mammo_clip_amd.engine import validate
+    loader = [{"x": torch.tensor(float(i))} for i in range(13)]
+    m = _ToyModel().train()
+    res = validate(m, _ToyLoss(), {"vindr": loader, "upmc": loader[:2]})
+    assert not m.training
+    assert abs(res["vindr"]["total"] - sum(range(11)) / 13) < 1e-6
+    assert abs(res["vindr"]["contrastive"] - 2 * sum(range(11)) / 13) < 1e-6
+    assert abs(res["upmc"]["total"] - 0.5) < 1e-6
+    from mammo_clip_amd.breastclip.evaluator import Evaluator
+    rng = np.random.default_rng(0)
+    a, b = rng.standard_normal((5, 16)), rng.standard_normal((3, 16))
+    from scipy.special import softmax
+    from sklearn import metrics
+    np.testing.assert_allclose(Evaluator.zeroshot_scores(a, b), softmax(metrics.pairwise.cosine_similarity(a, b), axis=1),
+                               rtol=1e-12, atol=1e-12)                  # evaluator.py:171
+
+
 # ------------------------------------------------------------------------------------------------ world_size = 2 (gloo)
 def _w2_worker(rank, port, ret):
     import torch.distributed as dist
@@ -215,6 +250,10 @@ def _w2_worker(rank, port, ret):
     gb.finish()
     ok = ok and all(torch.allclose(p.grad, torch.full((4,), 1.5 * (i + 1))) for i, p in enumerate(params[:4]))
     ok = ok and params[4].grad is None
+    # validation pass: per-batch mean over ranks [ref: trainer_ddp.py:384-387]
+    from mammo_clip_amd.engine import validate
+    res = validate(_ToyModel(), _ToyLoss(), {"d": [{"x": torch.tensor(float(rank + 1 + i))} for i in range(3)]})
+    ok = ok and abs(res["d"]["total"] - (1.5 + 2.5 + 3.5) / 3) < 1e-6
     ret[rank] = bool(ok)
     dist.destroy_process_group()
 

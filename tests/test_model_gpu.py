@@ -326,3 +326,34 @@ def test_hot_loop_trajectory_vs_reference():
         # direction agrees on the bulk (cos) and the step LENGTH (set by lr, weight decay and the schedule) is exact
         assert cos >= 0.5, (k, cos)
         assert abs(ratio - 1.0) <= 0.2, (k, ratio)
+
+
+def test_evaluator_entry_points(tmp_path):
+    """row N3 [ref: evaluator.py:126-144]: Evaluator.encode_image / encode_text = eval-mode normalised projected
+    embeddings as numpy, equal to the reference's golden eval embeddings (config #1 tolerance, cosine >= 0.9998)."""
+    from mammo_clip_amd.breastclip.evaluator import Evaluator
+    z = np.load(os.path.join(GOLDEN, "e2e_b2_cfg1.npz"))
+    b, H, W, T = [int(v) for v in z["meta"]]
+    model, lossf, sd = _build("tf_efficientnetv2-detect", "efficientnet-b2")
+    model.train()                                              # the evaluator must switch to eval itself
+    ev = Evaluator(model=model, device=DEV)
+    batch = ow.synth_batch(b, H, W, T, seed=10)
+    img = ev.encode_image(batch["images"])
+    txt = ev.encode_text(batch["text_tokens"])
+    assert isinstance(img, np.ndarray) and img.shape == (b, 512) and txt.shape == (b, 512)
+    assert _cos(torch.from_numpy(img), z["eval/image_embeddings"]) >= 0.9998
+    assert _cos(torch.from_numpy(txt), z["eval/text_embeddings"]) >= 0.9998
+    np.testing.assert_allclose(np.linalg.norm(img, axis=1), 1.0, atol=1e-5)
+    p = Evaluator.zeroshot_scores(img, txt)
+    assert p.shape == (b, b) and np.allclose(p.sum(1), 1.0)
+    with pytest.raises(TypeError):
+        ev.encode_text(["a report"])
+    # built from a reference-layout checkpoint [ref: evaluator.py:24-27,52-58] incl. the optimizer state (row N1/N2)
+    from mammo_clip_amd import checkpoint
+    from mammo_clip_amd.breastclip.optimizer import build_optimizer
+    opt = build_optimizer(model, {"name": "adamw", "config": {"lr": 1e-5, "weight_decay": 1e-4}})
+    path = checkpoint.save_checkpoint(str(tmp_path / "m.tar"), model, optimizer=opt,
+                                      config={"model": model.model_config, "loss": {"breast_clip": {}}})
+    ev2 = Evaluator(ckpt_path=path, tokenizer=types.SimpleNamespace(vocab_size=28996), device=DEV)
+    np.testing.assert_array_equal(ev2.encode_image(batch["images"]), img)
+    np.testing.assert_array_equal(ev2.encode_text(batch["text_tokens"]), txt)
