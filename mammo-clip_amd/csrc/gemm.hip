@@ -17,6 +17,7 @@
 // The bf16 epilogue goes back through LDS so global stores are 16-byte row segments, and can emit per-column
 // sum / sum-of-squares partials (training-mode BatchNorm statistics of the conv output).
 #include "common.cuh"
+#include <cstdlib>
 #include <type_traits>
 #include "../../include/mammoclip_hip.h"
 
@@ -73,8 +74,22 @@ __device__ unsigned long long g_gemm_prof[8];      // developer phase profile (s
 #define GPROF(i)
 #endif
 
-template <int BM, int BN, int BK, int WGM, int WGN, int LAY, int PRO, bool CF32>
+// GL = operands go global -> LDS directly (global_load_lds_dwordx4, no register staging, no ds_write pass).  The DMA
+// writes a wave-instruction's 64 x 16 B lane-linearly, so the LDS image is plain [row][8 x 16 B] (BK = 64) and the
+// bank-conflict swizzle is applied on the SOURCE side: the lane that fills slot s of row r fetches chunk
+// s ^ ((r >> 1) & 7) (still the same 128-byte line per row); ds_read_b128 of a fragment then spreads 16 rows x one
+// chunk over all 64 banks.  Chunks outside the matrices are fetched from a 16-byte zero block.  Plain NT only.
+__device__ __attribute__((aligned(16))) unsigned int g_gemm_zero16[4];
+typedef __attribute__((address_space(3))) unsigned int lds_u32_t;
+typedef __attribute__((address_space(1))) const unsigned int glb_u32_t;
+__device__ __forceinline__ void glds16(const void* src, unsigned char* dst_wave_base) {
+    __builtin_amdgcn_global_load_lds((glb_u32_t*)src, (lds_u32_t*)dst_wave_base, 16, 0, 0);
+}
+
+template <int BM, int BN, int BK, int WGM, int WGN, int LAY, int PRO, bool CF32, bool GL = false>
 __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8) ? 4 : 2) void gemm_kernel(const mc_gemm_args p, const int gm) {
+    static_assert(!GL || (LAY == 0 && PRO == 0 && BK == 64 && BM % 32 == 0 && BN % 32 == 0 && WGM * WGN == 4),
+                  "direct-to-LDS staging: plain NT operands, 64-wide K tiles, 4 waves");
     // 8-wave tiles are held to <= 128 VGPRs so two workgroups (16 waves) fit a CU
     constexpr int NT = WGM * WGN * 64;                // threads per workgroup (4 or 8 waves)
     constexpr bool AKM = (LAY == 2), BKM = (LAY >= 1);
@@ -86,11 +101,14 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8) ? 4 : 2) void gemm
     constexpr int RSB = BN * 2 + tr_pad_bytes(BN);
     constexpr int A_REGS = AKM ? (BK * (BM / 8) + (NT - 1)) / NT : (BM * KCH + (NT - 1)) / NT;
     constexpr int B_REGS = BKM ? (BK * (BN / 8) + (NT - 1)) / NT : (BN * KCH + (NT - 1)) / NT;
-    constexpr int A_BYTES = AKM ? BK * RSA : BM * ROWB;
-    constexpr int B_BYTES = BKM ? BK * RSB : BN * ROWB;
-    constexpr int STAGE_BYTES = A_BYTES + B_BYTES + 64;
-    constexpr int CROW = (BN + 8) * 2;                // epilogue tile row bytes (bf16)
+    constexpr int A_BYTES = GL ? BM * 128 : (AKM ? BK * RSA : BM * ROWB);
+    constexpr int B_BYTES = GL ? BN * 128 : (BKM ? BK * RSB : BN * ROWB);
+    constexpr int STAGE_BYTES = A_BYTES + B_BYTES + (GL ? 0 : 64);
+    // epilogue tile row bytes (bf16).  GL: the tile must fit the stage that was just consumed (the other one is being
+    // filled), so rows are unpadded and the 16-byte chunk index is XOR-swizzled with the row instead
+    constexpr int CROW = GL ? BN * 2 : (BN + 8) * 2;
     constexpr int EPI_BYTES = CF32 ? 0 : BM * CROW;
+    static_assert(!GL || EPI_BYTES <= STAGE_BYTES, "epilogue tile must fit one stage");
     constexpr int LDS_BYTES = (2 * STAGE_BYTES > EPI_BYTES) ? 2 * STAGE_BYTES : EPI_BYTES;
     __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
 
@@ -316,8 +334,14 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8) ? 4 : 2) void gemm
     };
     // acc[i][j][r]: row m = wm*WM + i*16 + (lane & 15), col n = wn*WN + j*16 + (lane >> 4)*4 + r
 
+    int ebuf = 0;          // GL: the stage the epilogue may reuse (the one just consumed)
     auto epilogue = [&](const long long m0) __attribute__((always_inline)) {
         __syncthreads();   // all fragment reads done before smem is reused by the epilogue
+        unsigned char* const etile = GL ? smem + ebuf * STAGE_BYTES : smem;
+        // byte offset of 16-byte chunk `ch` (+ `in` bytes) in tile row `row`
+        auto eoff = [&](int row, int ch, int in) __attribute__((always_inline)) {
+            return row * CROW + ((GL ? (ch ^ (row & (BN / 8 - 1))) : ch) << 4) + in;
+        };
         const float alpha = p.alpha;
         const int mrow = wm * WM + (lane & 15);
         const int ncol = wn * WN + (lane >> 4) * 4;
@@ -356,7 +380,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8) ? 4 : 2) void gemm
                 for (int i = 0; i < FM; ++i) {
                     uint2 pk = make_uint2(pack_bf2(acc[i][j][0] * alpha + bv[0], acc[i][j][1] * alpha + bv[1]),
                                           pack_bf2(acc[i][j][2] * alpha + bv[2], acc[i][j][3] * alpha + bv[3]));
-                    *reinterpret_cast<uint2*>(smem + (mrow + i * 16) * CROW + (ncol + j * 16) * 2) = pk;
+                    *reinterpret_cast<uint2*>(etile + eoff(mrow + i * 16, (ncol + j * 16) >> 3, ((ncol + j * 16) & 7) * 2)) = pk;
                 }
             }
             __syncthreads();
@@ -369,7 +393,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8) ? 4 : 2) void gemm
                 for (int row = r0; row < BM; row += RPP) {
                     long long m = m0 + row;
                     if (m >= p.M) break;
-                    uint4 v = *reinterpret_cast<const uint4*>(smem + row * CROW + cc * 16);
+                    uint4 v = *reinterpret_cast<const uint4*>(etile + eoff(row, cc, 0));
                     if (p.R) {
                         float f[8], g[8];
                         unpack8(v, f);
@@ -392,7 +416,118 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8) ? 4 : 2) void gemm
         }
     };
 
+    // ---------------- direct-to-LDS main loop (GL) ----------------
+    // Per flat step: wait for this tile's DMA (the only one in flight), barrier (every wave's part has landed and every
+    // wave is done with the other stage), read ALL fragments of the tile into registers, issue the next tile's DMA into
+    // the other stage, then run the 2 x FM x FN MFMAs from registers while it lands.  No LDS read is ever issued while
+    // a DMA into LDS is outstanding, so the waits the compiler places for LDS-DMA coincide with the explicit one.
+    if constexpr (GL) {
+        constexpr int NI_A = BM / 32, NI_B = BN / 32;          // wave-instructions per thread and operand (8 rows each)
+        unsigned goffA[NI_A], goffB[NI_B];
+        int growA[NI_A], growB[NI_B], gkA[NI_A], gkB[NI_B];
+#pragma unroll
+        for (int i = 0; i < NI_A; ++i) {
+            const int row = (i * 4 + wave) * 8 + (lane >> 3);
+            const int ch = (lane & 7) ^ ((row >> 1) & 7);
+            growA[i] = row; gkA[i] = ch * 8; goffA[i] = (unsigned)(row * p.lda + ch * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < NI_B; ++i) {
+            const int row = (i * 4 + wave) * 8 + (lane >> 3);
+            const int ch = (lane & 7) ^ ((row >> 1) & 7);
+            growB[i] = row; gkB[i] = ch * 8; goffB[i] = (unsigned)(row * p.ldb + ch * 8);
+        }
+        const bf16_t* const zero = reinterpret_cast<const bf16_t*>(g_gemm_zero16);
+        auto issue = [&](int stage, long long m0, long long k0) __attribute__((always_inline)) {
+            unsigned char* sA = smem + stage * STAGE_BYTES;
+            unsigned char* sB = sA + A_BYTES;
+            if (n_full && (m0 + BM <= p.M) && (k0 + BK <= kend)) {
+                const bf16_t* ab = A + m0 * p.lda + k0;
+                const bf16_t* bb = B + (long long)n0 * p.ldb + k0;
+#pragma unroll
+                for (int i = 0; i < NI_A; ++i) glds16(ab + goffA[i], sA + (i * 4 + wave) * 1024);
+#pragma unroll
+                for (int i = 0; i < NI_B; ++i) glds16(bb + goffB[i], sB + (i * 4 + wave) * 1024);
+            } else {
+#pragma unroll
+                for (int i = 0; i < NI_A; ++i) {
+                    const long long m = m0 + growA[i], k = k0 + gkA[i];
+                    glds16((m < p.M && k < kend) ? A + m * p.lda + k : zero, sA + (i * 4 + wave) * 1024);
+                }
+#pragma unroll
+                for (int i = 0; i < NI_B; ++i) {
+                    const long long n = n0 + growB[i], k = k0 + gkB[i];
+                    glds16((n < p.N && k < kend) ? B + n * p.ldb + k : zero, sB + (i * 4 + wave) * 1024);
+                }
+            }
+        };
+        const long long ktn = kbeg < kend ? (kend - kbeg + BK - 1) / BK : 0;
+        const long long my_mt = by < mtiles ? (mtiles - by + gm - 1) / gm : 0;
+        const long long total = my_mt * ktn;
+        if (ktn == 0) {
+            for (long long mt = by; mt < mtiles; mt += gm) {
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+                epilogue(mt * BM);
+            }
+        } else {
+        long long pm0 = (long long)by * BM, pk0 = kbeg;                  // position of the NEXT tile to fetch
+        auto advance = [&]() __attribute__((always_inline)) {
+            pk0 += BK;
+            if (pk0 >= kend) { pk0 = kbeg; pm0 += (long long)gm * BM; }
+        };
+        long long cm0 = pm0, ck0 = pk0;                                  // position of the tile being consumed
+        issue(0, pm0, pk0);
+        advance();
+        // fragment addresses: row r, chunk c -> r * 128 + ((c ^ ((r >> 1) & 7)) << 4); rows of a fragment are
+        // (lane & 15) + multiples of 16, so the swizzle term depends on the lane only
+        const int frow = lane & 15, fsw = (frow >> 1) & 7, fkg = lane >> 4;
+        const int aoff0 = (wm * WM + frow) * 128 + (((0 + fkg) ^ fsw) << 4), aoff1 = (wm * WM + frow) * 128 + (((4 + fkg) ^ fsw) << 4);
+        const int boff0 = (wn * WN + frow) * 128 + (((0 + fkg) ^ fsw) << 4), boff1 = (wn * WN + frow) * 128 + (((4 + fkg) ^ fsw) << 4);
+        for (long long i = 0; i < total; ++i) {
+            const int buf = (int)(i & 1);
+            if (ck0 == kbeg) {
+#pragma unroll
+                for (int a = 0; a < FM; ++a)
+#pragma unroll
+                    for (int b = 0; b < FN; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+            }
+            __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): my part of tile i has landed
+            __syncthreads();
+            const unsigned char* sA = smem + buf * STAGE_BYTES;
+            const unsigned char* sB = sA + A_BYTES;
+            bf16x8_t af[2][FM], bfr[2][FN];
+#pragma unroll
+            for (int a = 0; a < FM; ++a) {
+                af[0][a] = *reinterpret_cast<const bf16x8_t*>(sA + aoff0 + a * 16 * 128);
+                af[1][a] = *reinterpret_cast<const bf16x8_t*>(sA + aoff1 + a * 16 * 128);
+            }
+#pragma unroll
+            for (int b = 0; b < FN; ++b) {
+                bfr[0][b] = *reinterpret_cast<const bf16x8_t*>(sB + boff0 + b * 16 * 128);
+                bfr[1][b] = *reinterpret_cast<const bf16x8_t*>(sB + boff1 + b * 16 * 128);
+            }
+            __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0): fragments are in registers
+            if (i + 1 < total) { issue(buf ^ 1, pm0, pk0); advance(); }
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int a = 0; a < FM; ++a)
+#pragma unroll
+                    for (int b = 0; b < FN; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[kk][b], af[kk][a], acc[a][b], 0, 0, 0);
+            const bool last_k = ck0 + BK >= kend;
+            if (last_k) { ebuf = buf; epilogue(cm0); }
+            ck0 += BK;
+            if (last_k) { ck0 = kbeg; cm0 += (long long)gm * BM; }
+        }
+        }
+    }
+
     // ---------------- software-pipelined main loop ----------------
+    if constexpr (!GL) {
     // The (row block, K tile) pairs this workgroup owns form one flat sequence; two tiles are always in flight in
     // registers (global loads are issued two steps ahead of the LDS store that consumes them), across K tiles AND
     // across row blocks, so HBM/L2 latency is covered even when a row block has only one or two K tiles.
@@ -465,9 +600,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8) ? 4 : 2) void gemm
 #endif
     }
 
-#ifdef GEMM_PROF
-    // (pacc is scoped to the main loop above; flushed there)
-#endif
+    }   // !GL
     // ---------------- column statistics partials ----------------
     if (!CF32 && p.stat_partials) {
         constexpr int CPR = BN / 8;
@@ -527,11 +660,11 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, int splits, l
     }
 }
 
-template <int BM, int BN, int BK, int WGM, int WGN, int LAY, int PRO, bool CF32>
+template <int BM, int BN, int BK, int WGM, int WGN, int LAY, int PRO, bool CF32, bool GL = false>
 int launch(const mc_gemm_args& p, int grid_m, hipStream_t st) {
     constexpr int NT = WGM * WGN * 64;
     dim3 grid(mc_div_up(p.N, BN), grid_m, p.batch * p.splits);
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, WGM, WGN, LAY, PRO, CF32>), grid, dim3(NT), 0, st, p, grid_m);
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, WGM, WGN, LAY, PRO, CF32, GL>), grid, dim3(NT), 0, st, p, grid_m);
     MC_LAUNCH_CHECK();
     if (p.splits > 1 && p.splitk_ws) {
         long long mn = p.M * p.N;
@@ -543,14 +676,25 @@ int launch(const mc_gemm_args& p, int grid_m, hipStream_t st) {
     return MC_OK;
 }
 
+static bool mc_gemm_glds_enabled() {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("MC_GEMM_GLDS"); on = (e && e[0] == '0') ? 0 : 1; }   // developer A/B switch
+    return on == 1;
+}
+
 template <int LAY, int PRO, bool CF32>
 int dispatch_tile(const mc_gemm_args& p, int grid_m, hipStream_t st) {
     const bool small_k = p.K <= 48;
     // 128x128 tiles run with 8 waves (wave tile 64x32): half the accumulator / staging registers per thread,
     // twice the waves per CU to overlap global->LDS staging with MFMA issue
-    if (p.N > 64)
+    if (p.N > 64) {
+        if constexpr (LAY == 0 && PRO == 0) {
+            // plain NT operands: direct-to-LDS staging
+            if (!small_k && mc_gemm_glds_enabled()) return launch<128, 128, 64, 2, 2, LAY, PRO, CF32, true>(p, grid_m, st);
+        }
         return small_k ? launch<128, 128, 32, 2, 2, LAY, PRO, CF32>(p, grid_m, st)
                        : launch<128, 128, 64, 2, 2, LAY, PRO, CF32>(p, grid_m, st);
+    }
     if (p.N > 32)
         return small_k ? launch<128, 64, 32, 2, 2, LAY, PRO, CF32>(p, grid_m, st)
                        : launch<128, 64, 64, 2, 2, LAY, PRO, CF32>(p, grid_m, st);
