@@ -88,8 +88,8 @@ __device__ __forceinline__ void glds16(const void* src, unsigned char* dst_wave_
 
 template <int BM, int BN, int BK, int WGM, int WGN, int LAY, int PRO, bool CF32, bool GL = false>
 __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8) ? 4 : 2) void gemm_kernel(const mc_gemm_args p, const int gm) {
-    static_assert(!GL || (LAY == 0 && PRO == 0 && BK == 64 && BM % 32 == 0 && BN % 32 == 0 && WGM * WGN == 4),
-                  "direct-to-LDS staging: plain NT operands, 64-wide K tiles, 4 waves");
+    static_assert(!GL || ((LAY == 0 || LAY == 2) && PRO == 0 && BK == 64 && BM % 32 == 0 && BN % 32 == 0 && WGM * WGN == 4),
+                  "direct-to-LDS staging: plain operands (NT or both k-major), 64-wide K tiles, 4 waves");
     // 8-wave tiles are held to <= 128 VGPRs so two workgroups (16 waves) fit a CU
     constexpr int NT = WGM * WGN * 64;                // threads per workgroup (4 or 8 waves)
     constexpr bool AKM = (LAY == 2), BKM = (LAY >= 1);
@@ -117,9 +117,10 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8) ? 4 : 2) void gemm
     // XCD-aware tile placement: workgroups are dealt round-robin to the 8 XCDs by linear id, each with its own L2.
     // All column tiles of one row block get consecutive slots on the SAME XCD, so the activation rows are fetched
     // from HBM once per row block and the other column tiles hit that XCD's L2 (grid.y is padded to a multiple of 8).
-    // Only when there are enough row workgroups to keep the XCDs balanced (gm is then a multiple of 8).
+    // Only when there are enough row workgroups to keep the XCDs balanced; the launch pads grid.y to a multiple of 8
+    // (workgroups past gm exit), which keeps the remap a bijection for every gm.
     int bx = blockIdx.x, by = blockIdx.y;
-    if (gm >= 16 && (gm & 7) == 0) {
+    if (gm >= 16) {
         const int lin = blockIdx.y * gridDim.x + blockIdx.x;
         bx = (lin >> 3) % gridDim.x;
         by = ((lin >> 3) / gridDim.x) * 8 + (lin & 7);
@@ -422,28 +423,47 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8) ? 4 : 2) void gemm
     // the other stage, then run the 2 x FM x FN MFMAs from registers while it lands.  No LDS read is ever issued while
     // a DMA into LDS is outstanding, so the waits the compiler places for LDS-DMA coincide with the explicit one.
     if constexpr (GL) {
-        constexpr int NI_A = BM / 32, NI_B = BN / 32;          // wave-instructions per thread and operand (8 rows each)
+        constexpr int NI_A = BM / 32, NI_B = BN / 32;          // wave-instructions (1 KiB each) per thread and operand
+        // k-contiguous operand ([x][64 k], 128-byte rows, 8 rows per wave-instruction): slot s of row r holds chunk
+        //   s ^ ((r >> 1) & 7).  k-major operand ([64 k][x], 256-byte rows for x = 128, 4 rows per wave-instruction):
+        //   slot s of k-row r holds chunk s ^ (((r & 3) | ((r >> 1) & 4)) << 1), which keeps the 32-byte pairs the
+        //   transpose-read fetches together and spreads its 8 rows per 32-lane group over all banks.
+        // gx = offset along the operand's own rows (m or n), gk = offset along the reduction, in elements
         unsigned goffA[NI_A], goffB[NI_B];
-        int growA[NI_A], growB[NI_B], gkA[NI_A], gkB[NI_B];
+        int gxA[NI_A], gxB[NI_B], gkA[NI_A], gkB[NI_B];
 #pragma unroll
         for (int i = 0; i < NI_A; ++i) {
-            const int row = (i * 4 + wave) * 8 + (lane >> 3);
-            const int ch = (lane & 7) ^ ((row >> 1) & 7);
-            growA[i] = row; gkA[i] = ch * 8; goffA[i] = (unsigned)(row * p.lda + ch * 8);
+            if (!AKM) {
+                const int row = (i * 4 + wave) * 8 + (lane >> 3);
+                const int ch = (lane & 7) ^ ((row >> 1) & 7);
+                gxA[i] = row; gkA[i] = ch * 8; goffA[i] = (unsigned)(row * p.lda + ch * 8);
+            } else {
+                static_assert(!AKM || BM == 128, "k-major direct staging is laid out for 128-wide tiles");
+                const int row = (i * 4 + wave) * 4 + (lane >> 4);
+                const int ch = (lane & 15) ^ (((row & 3) | ((row >> 1) & 4)) << 1);
+                gxA[i] = ch * 8; gkA[i] = row; goffA[i] = (unsigned)(row * p.lda + ch * 8);
+            }
         }
 #pragma unroll
         for (int i = 0; i < NI_B; ++i) {
-            const int row = (i * 4 + wave) * 8 + (lane >> 3);
-            const int ch = (lane & 7) ^ ((row >> 1) & 7);
-            growB[i] = row; gkB[i] = ch * 8; goffB[i] = (unsigned)(row * p.ldb + ch * 8);
+            if (!BKM) {
+                const int row = (i * 4 + wave) * 8 + (lane >> 3);
+                const int ch = (lane & 7) ^ ((row >> 1) & 7);
+                gxB[i] = row; gkB[i] = ch * 8; goffB[i] = (unsigned)(row * p.ldb + ch * 8);
+            } else {
+                static_assert(!BKM || BN == 128, "k-major direct staging is laid out for 128-wide tiles");
+                const int row = (i * 4 + wave) * 4 + (lane >> 4);
+                const int ch = (lane & 15) ^ (((row & 3) | ((row >> 1) & 4)) << 1);
+                gxB[i] = ch * 8; gkB[i] = row; goffB[i] = (unsigned)(row * p.ldb + ch * 8);
+            }
         }
         const bf16_t* const zero = reinterpret_cast<const bf16_t*>(g_gemm_zero16);
         auto issue = [&](int stage, long long m0, long long k0) __attribute__((always_inline)) {
             unsigned char* sA = smem + stage * STAGE_BYTES;
             unsigned char* sB = sA + A_BYTES;
             if (n_full && (m0 + BM <= p.M) && (k0 + BK <= kend)) {
-                const bf16_t* ab = A + m0 * p.lda + k0;
-                const bf16_t* bb = B + (long long)n0 * p.ldb + k0;
+                const bf16_t* ab = AKM ? A + k0 * p.lda + m0 : A + m0 * p.lda + k0;
+                const bf16_t* bb = BKM ? B + k0 * p.ldb + n0 : B + (long long)n0 * p.ldb + k0;
 #pragma unroll
                 for (int i = 0; i < NI_A; ++i) glds16(ab + goffA[i], sA + (i * 4 + wave) * 1024);
 #pragma unroll
@@ -451,13 +471,13 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8) ? 4 : 2) void gemm
             } else {
 #pragma unroll
                 for (int i = 0; i < NI_A; ++i) {
-                    const long long m = m0 + growA[i], k = k0 + gkA[i];
-                    glds16((m < p.M && k < kend) ? A + m * p.lda + k : zero, sA + (i * 4 + wave) * 1024);
+                    const long long m = m0 + gxA[i], k = k0 + gkA[i];
+                    glds16((m < p.M && k < kend) ? (AKM ? A + k * p.lda + m : A + m * p.lda + k) : zero, sA + (i * 4 + wave) * 1024);
                 }
 #pragma unroll
                 for (int i = 0; i < NI_B; ++i) {
-                    const long long n = n0 + growB[i], k = k0 + gkB[i];
-                    glds16((n < p.N && k < kend) ? B + n * p.ldb + k : zero, sB + (i * 4 + wave) * 1024);
+                    const long long n = n0 + gxB[i], k = k0 + gkB[i];
+                    glds16((n < p.N && k < kend) ? (BKM ? B + k * p.ldb + n : B + n * p.ldb + k) : zero, sB + (i * 4 + wave) * 1024);
                 }
             }
         };
@@ -481,11 +501,31 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8) ? 4 : 2) void gemm
         long long cm0 = pm0, ck0 = pk0;                                  // position of the tile being consumed
         issue(0, pm0, pk0);
         advance();
-        // fragment addresses: row r, chunk c -> r * 128 + ((c ^ ((r >> 1) & 7)) << 4); rows of a fragment are
-        // (lane & 15) + multiples of 16, so the swizzle term depends on the lane only
+        // fragment addresses.  k-contiguous: row r, chunk c -> r * 128 + ((c ^ ((r >> 1) & 7)) << 4); the rows of a
+        // fragment are (lane & 15) + multiples of 16, so the swizzle term depends on the lane only.
+        // k-major (transpose-read, see tr_frag): lane (g, i) addresses k-row kk*32 + g*8 + (i >> 2) [+4 for the upper
+        // half], columns col0 + (i & 3) * 4 .. +3 -> 8 bytes inside chunk (col0 >> 3) + ((i & 3) >> 1).
         const int frow = lane & 15, fsw = (frow >> 1) & 7, fkg = lane >> 4;
-        const int aoff0 = (wm * WM + frow) * 128 + (((0 + fkg) ^ fsw) << 4), aoff1 = (wm * WM + frow) * 128 + (((4 + fkg) ^ fsw) << 4);
-        const int boff0 = (wn * WN + frow) * 128 + (((0 + fkg) ^ fsw) << 4), boff1 = (wn * WN + frow) * 128 + (((4 + fkg) ^ fsw) << 4);
+        const int ti = lane & 15, tg = lane >> 4;
+        auto kc_off = [&](int x0, int kk) __attribute__((always_inline)) {      // k-contiguous operand, tile row base x0
+            return (x0 + frow) * 128 + (((kk * 4 + fkg) ^ fsw) << 4);
+        };
+        auto km_off = [&](int col0, int kk, int hi) __attribute__((always_inline)) {   // k-major operand, 256-byte rows
+            const int r = kk * 32 + tg * 8 + (ti >> 2) + hi * 4;
+            const int sw = ((r & 3) | ((r >> 1) & 4)) << 1;
+            return r * 256 + ((((col0 >> 3) + ((ti & 3) >> 1)) ^ sw) << 4) + ((ti & 1) << 3);
+        };
+        typedef __attribute__((ext_vector_type(8))) short s8_t;
+        auto km_frag = [&](const unsigned char* tile, int col0, int kk) __attribute__((always_inline)) {
+            s4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_t*)(tile + km_off(col0, kk, 0)));
+            s4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_t*)(tile + km_off(col0, kk, 1)));
+            s8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            return __builtin_bit_cast(bf16x8_t, v);
+        };
+#ifdef GEMM_PROF
+        unsigned long long pacc[6] = {0, 0, 0, 0, 0, 0};
+        unsigned long long tprof = __builtin_amdgcn_s_memtime();
+#endif
         for (long long i = 0; i < total; ++i) {
             const int buf = (int)(i & 1);
             if (ck0 == kbeg) {
@@ -495,22 +535,28 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8) ? 4 : 2) void gemm
                     for (int b = 0; b < FN; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
             }
             __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): my part of tile i has landed
+            GPROF(0);
             __syncthreads();
+            GPROF(1);
             const unsigned char* sA = smem + buf * STAGE_BYTES;
             const unsigned char* sB = sA + A_BYTES;
             bf16x8_t af[2][FM], bfr[2][FN];
 #pragma unroll
-            for (int a = 0; a < FM; ++a) {
-                af[0][a] = *reinterpret_cast<const bf16x8_t*>(sA + aoff0 + a * 16 * 128);
-                af[1][a] = *reinterpret_cast<const bf16x8_t*>(sA + aoff1 + a * 16 * 128);
-            }
+            for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
-            for (int b = 0; b < FN; ++b) {
-                bfr[0][b] = *reinterpret_cast<const bf16x8_t*>(sB + boff0 + b * 16 * 128);
-                bfr[1][b] = *reinterpret_cast<const bf16x8_t*>(sB + boff1 + b * 16 * 128);
+                for (int a = 0; a < FM; ++a) {
+                    if (AKM) af[kk][a] = km_frag(sA, wm * WM + a * 16, kk);
+                    else af[kk][a] = *reinterpret_cast<const bf16x8_t*>(sA + kc_off(wm * WM + a * 16, kk));
+                }
+#pragma unroll
+                for (int b = 0; b < FN; ++b) {
+                    if (BKM) bfr[kk][b] = km_frag(sB, wn * WN + b * 16, kk);
+                    else bfr[kk][b] = *reinterpret_cast<const bf16x8_t*>(sB + kc_off(wn * WN + b * 16, kk));
+                }
             }
             __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0): fragments are in registers
             if (i + 1 < total) { issue(buf ^ 1, pm0, pk0); advance(); }
+            GPROF(2);
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
@@ -518,11 +564,20 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8) ? 4 : 2) void gemm
 #pragma unroll
                     for (int b = 0; b < FN; ++b)
                         acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[kk][b], af[kk][a], acc[a][b], 0, 0, 0);
+            GPROF(3);
             const bool last_k = ck0 + BK >= kend;
             if (last_k) { ebuf = buf; epilogue(cm0); }
+            GPROF(4);
+#ifdef GEMM_PROF
+            pacc[5] += 1;
+#endif
             ck0 += BK;
             if (last_k) { ck0 = kbeg; cm0 += (long long)gm * BM; }
         }
+#ifdef GEMM_PROF
+        if (tid == 0)
+            for (int q = 0; q < 6; ++q) atomicAdd(&g_gemm_prof[q], pacc[q]);
+#endif
         }
     }
 
@@ -663,7 +718,7 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, int splits, l
 template <int BM, int BN, int BK, int WGM, int WGN, int LAY, int PRO, bool CF32, bool GL = false>
 int launch(const mc_gemm_args& p, int grid_m, hipStream_t st) {
     constexpr int NT = WGM * WGN * 64;
-    dim3 grid(mc_div_up(p.N, BN), grid_m, p.batch * p.splits);
+    dim3 grid(mc_div_up(p.N, BN), grid_m >= 16 ? (grid_m + 7) / 8 * 8 : grid_m, p.batch * p.splits);   // see the XCD remap
     hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, WGM, WGN, LAY, PRO, CF32, GL>), grid, dim3(NT), 0, st, p, grid_m);
     MC_LAUNCH_CHECK();
     if (p.splits > 1 && p.splitk_ws) {
@@ -688,8 +743,8 @@ int dispatch_tile(const mc_gemm_args& p, int grid_m, hipStream_t st) {
     // 128x128 tiles run with 8 waves (wave tile 64x32): half the accumulator / staging registers per thread,
     // twice the waves per CU to overlap global->LDS staging with MFMA issue
     if (p.N > 64) {
-        if constexpr (LAY == 0 && PRO == 0) {
-            // plain NT operands: direct-to-LDS staging
+        if constexpr ((LAY == 0 || LAY == 2) && PRO == 0) {
+            // plain operands: direct-to-LDS staging
             if (!small_k && mc_gemm_glds_enabled()) return launch<128, 128, 64, 2, 2, LAY, PRO, CF32, true>(p, grid_m, st);
         }
         return small_k ? launch<128, 128, 32, 2, 2, LAY, PRO, CF32>(p, grid_m, st)
