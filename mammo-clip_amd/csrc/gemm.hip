@@ -82,14 +82,22 @@ __device__ unsigned long long g_gemm_prof[8];      // developer phase profile (s
 __device__ __attribute__((aligned(16))) unsigned int g_gemm_zero16[4];
 typedef __attribute__((address_space(3))) unsigned int lds_u32_t;
 typedef __attribute__((address_space(1))) const unsigned int glb_u32_t;
-__device__ __forceinline__ void glds16(const void* src, unsigned char* dst_wave_base) {
-    __builtin_amdgcn_global_load_lds((glb_u32_t*)src, (lds_u32_t*)dst_wave_base, 16, 0, 0);
+// Issued as inline assembly: the compiler then keeps no book on the DMA, so the kernel's own counted s_waitcnt vmcnt(N)
+// decides when a stage is ready and the transfers of LATER stages stay in flight across barriers and LDS reads (with
+// the builtin every LDS access after a DMA waits for vmcnt(0)).  dst_wave_base must be wave-uniform; lane l's 16 bytes
+// land at dst_wave_base + 16 l.  M0 (the LDS destination) is saved and restored around the instruction.
+__device__ __forceinline__ void glds16(const void* src, unsigned dst_wave_base) {     // dst: LDS byte address
+    const unsigned lds = __builtin_amdgcn_readfirstlane(dst_wave_base);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(src), "s"(lds) : "memory");
 }
 
 template <int BM, int BN, int BK, int WGM, int WGN, int LAY, int PRO, bool CF32, bool GL = false>
-__global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8) ? 4 : 2) void gemm_kernel(const mc_gemm_args p, const int gm) {
-    static_assert(!GL || ((LAY == 0 || LAY == 2) && PRO == 0 && BK == 64 && BM % 32 == 0 && BN % 32 == 0 && WGM * WGN == 4),
-                  "direct-to-LDS staging: plain operands (NT or both k-major), 64-wide K tiles, 4 waves");
+__global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 && !GL) ? 4 : 2) void gemm_kernel(const mc_gemm_args p, const int gm) {
+    static_assert(!GL || ((LAY == 0 || LAY == 2) && PRO == 0 && BK == 64 && BM % 64 == 0 && BN % 64 == 0 &&
+                          (WGM * WGN == 4 || (WGM * WGN == 8 && LAY == 0))),
+                  "direct-to-LDS staging: plain operands (NT or both k-major), 64-wide K tiles, 4 waves (NT: or 8)");
     // 8-wave tiles are held to <= 128 VGPRs so two workgroups (16 waves) fit a CU
     constexpr int NT = WGM * WGN * 64;                // threads per workgroup (4 or 8 waves)
     constexpr bool AKM = (LAY == 2), BKM = (LAY >= 1);
@@ -107,9 +115,13 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8) ? 4 : 2) void gemm
     // epilogue tile row bytes (bf16).  GL: the tile must fit the stage that was just consumed (the other one is being
     // filled), so rows are unpadded and the 16-byte chunk index is XOR-swizzled with the row instead
     constexpr int CROW = GL ? BN * 2 : (BN + 8) * 2;
-    constexpr int EPI_BYTES = CF32 ? 0 : BM * CROW;
+    constexpr int EH = (GL && !CF32 && BM * CROW > STAGE_BYTES) ? 2 : 1;      // epilogue passes (row halves of the tile)
+    constexpr int EROWS = BM / EH;
+    constexpr int EPI_BYTES = CF32 ? 0 : EROWS * CROW;
     static_assert(!GL || EPI_BYTES <= STAGE_BYTES, "epilogue tile must fit one stage");
-    constexpr int LDS_BYTES = (2 * STAGE_BYTES > EPI_BYTES) ? 2 * STAGE_BYTES : EPI_BYTES;
+    // GL stages: as many as fit beside nothing else in 160 KB at one (8-wave) or two (4-wave) workgroups per CU
+    constexpr int NS = GL ? ((WGM * WGN == 8) ? 3 : 2) : 2;
+    constexpr int LDS_BYTES = (NS * STAGE_BYTES > EPI_BYTES) ? NS * STAGE_BYTES : EPI_BYTES;
     __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -369,48 +381,54 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8) ? 4 : 2) void gemm
                 }
             }
         } else {
-#pragma unroll
-            for (int j = 0; j < FN; ++j) {
-                int n = n0 + ncol + j * 16;
-                float bv[4] = {0.f, 0.f, 0.f, 0.f};
-                if (bias) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) bv[r] = (n + r < p.N) ? bias[n + r] : 0.f;
-                }
-#pragma unroll
-                for (int i = 0; i < FM; ++i) {
-                    uint2 pk = make_uint2(pack_bf2(acc[i][j][0] * alpha + bv[0], acc[i][j][1] * alpha + bv[1]),
-                                          pack_bf2(acc[i][j][2] * alpha + bv[2], acc[i][j][3] * alpha + bv[3]));
-                    *reinterpret_cast<uint2*>(etile + eoff(mrow + i * 16, (ncol + j * 16) >> 3, ((ncol + j * 16) & 7) * 2)) = pk;
-                }
-            }
-            __syncthreads();
             bf16_t* C = reinterpret_cast<bf16_t*>(p.C) + coff;
             constexpr int CPR = BN / 8;                 // 16-byte chunks per tile row
             constexpr int RPP = NT / CPR;              // rows per pass
             const int cc = tid % CPR, r0 = tid / CPR;
             const int n = n0 + cc * 8;
-            if (n < p.N) {
-                for (int row = r0; row < BM; row += RPP) {
-                    long long m = m0 + row;
-                    if (m >= p.M) break;
-                    uint4 v = *reinterpret_cast<const uint4*>(etile + eoff(row, cc, 0));
-                    if (p.R) {
-                        float f[8], g[8];
-                        unpack8(v, f);
-                        uint4 rv = *reinterpret_cast<const uint4*>(p.R + coff + m * p.ldr + n);
-                        unpack8(rv, g);
 #pragma unroll
-                        for (int q = 0; q < 8; ++q) f[q] += g[q];
-                        v = pack8(f);
-                    }
-                    if (p.stat_partials) {
-                        float f[8];
-                        unpack8(v, f);
+            for (int eh = 0; eh < EH; ++eh) {          // the tile goes out in EH row slabs of EROWS rows
+                if (eh > 0) __syncthreads();
+                if (EH == 1 || (wm * WM) / EROWS == eh) {
 #pragma unroll
-                        for (int q = 0; q < 8; ++q) { colsum[q] += f[q]; colsq[q] += f[q] * f[q]; }
+                    for (int j = 0; j < FN; ++j) {
+                        int nn = n0 + ncol + j * 16;
+                        float bv[4] = {0.f, 0.f, 0.f, 0.f};
+                        if (bias) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) bv[r] = (nn + r < p.N) ? bias[nn + r] : 0.f;
+                        }
+#pragma unroll
+                        for (int i = 0; i < FM; ++i) {
+                            uint2 pk = make_uint2(pack_bf2(acc[i][j][0] * alpha + bv[0], acc[i][j][1] * alpha + bv[1]),
+                                                  pack_bf2(acc[i][j][2] * alpha + bv[2], acc[i][j][3] * alpha + bv[3]));
+                            *reinterpret_cast<uint2*>(etile + eoff(mrow + i * 16 - eh * EROWS, (ncol + j * 16) >> 3, ((ncol + j * 16) & 7) * 2)) = pk;
+                        }
                     }
-                    *reinterpret_cast<uint4*>(C + m * p.ldc + n) = v;
+                }
+                __syncthreads();
+                if (n < p.N) {
+                    for (int row = r0; row < EROWS; row += RPP) {
+                        long long m = m0 + eh * EROWS + row;
+                        if (m >= p.M) break;
+                        uint4 v = *reinterpret_cast<const uint4*>(etile + eoff(row, cc, 0));
+                        if (p.R) {
+                            float f[8], g[8];
+                            unpack8(v, f);
+                            uint4 rv = *reinterpret_cast<const uint4*>(p.R + coff + m * p.ldr + n);
+                            unpack8(rv, g);
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) f[q] += g[q];
+                            v = pack8(f);
+                        }
+                        if (p.stat_partials) {
+                            float f[8];
+                            unpack8(v, f);
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) { colsum[q] += f[q]; colsq[q] += f[q] * f[q]; }
+                        }
+                        *reinterpret_cast<uint4*>(C + m * p.ldc + n) = v;
+                    }
                 }
             }
             __syncthreads();
@@ -423,7 +441,9 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8) ? 4 : 2) void gemm
     // the other stage, then run the 2 x FM x FN MFMAs from registers while it lands.  No LDS read is ever issued while
     // a DMA into LDS is outstanding, so the waits the compiler places for LDS-DMA coincide with the explicit one.
     if constexpr (GL) {
-        constexpr int NI_A = BM / 32, NI_B = BN / 32;          // wave-instructions (1 KiB each) per thread and operand
+        constexpr int NW = WGM * WGN;
+        constexpr int NI_A = BM / (8 * NW), NI_B = BN / (8 * NW);   // wave-instructions (1 KiB each) per thread and operand
+        constexpr int NL = NI_A + NI_B;                        // DMA instructions per thread and tile
         // k-contiguous operand ([x][64 k], 128-byte rows, 8 rows per wave-instruction): slot s of row r holds chunk
         //   s ^ ((r >> 1) & 7).  k-major operand ([64 k][x], 256-byte rows for x = 128, 4 rows per wave-instruction):
         //   slot s of k-row r holds chunk s ^ (((r & 3) | ((r >> 1) & 4)) << 1), which keeps the 32-byte pairs the
@@ -434,12 +454,12 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8) ? 4 : 2) void gemm
 #pragma unroll
         for (int i = 0; i < NI_A; ++i) {
             if (!AKM) {
-                const int row = (i * 4 + wave) * 8 + (lane >> 3);
+                const int row = (i * NW + wave) * 8 + (lane >> 3);
                 const int ch = (lane & 7) ^ ((row >> 1) & 7);
                 gxA[i] = row; gkA[i] = ch * 8; goffA[i] = (unsigned)(row * p.lda + ch * 8);
             } else {
                 static_assert(!AKM || BM == 128, "k-major direct staging is laid out for 128-wide tiles");
-                const int row = (i * 4 + wave) * 4 + (lane >> 4);
+                const int row = (i * NW + wave) * 4 + (lane >> 4);
                 const int ch = (lane & 15) ^ (((row & 3) | ((row >> 1) & 4)) << 1);
                 gxA[i] = ch * 8; gkA[i] = row; goffA[i] = (unsigned)(row * p.lda + ch * 8);
             }
@@ -447,37 +467,38 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8) ? 4 : 2) void gemm
 #pragma unroll
         for (int i = 0; i < NI_B; ++i) {
             if (!BKM) {
-                const int row = (i * 4 + wave) * 8 + (lane >> 3);
+                const int row = (i * NW + wave) * 8 + (lane >> 3);
                 const int ch = (lane & 7) ^ ((row >> 1) & 7);
                 gxB[i] = row; gkB[i] = ch * 8; goffB[i] = (unsigned)(row * p.ldb + ch * 8);
             } else {
                 static_assert(!BKM || BN == 128, "k-major direct staging is laid out for 128-wide tiles");
-                const int row = (i * 4 + wave) * 4 + (lane >> 4);
+                const int row = (i * NW + wave) * 4 + (lane >> 4);
                 const int ch = (lane & 15) ^ (((row & 3) | ((row >> 1) & 4)) << 1);
                 gxB[i] = ch * 8; gkB[i] = row; goffB[i] = (unsigned)(row * p.ldb + ch * 8);
             }
         }
         const bf16_t* const zero = reinterpret_cast<const bf16_t*>(g_gemm_zero16);
+        const unsigned smem_lds = (unsigned)(uintptr_t)(lds_u32_t*)smem;   // LDS address of the staging buffer
         auto issue = [&](int stage, long long m0, long long k0) __attribute__((always_inline)) {
-            unsigned char* sA = smem + stage * STAGE_BYTES;
-            unsigned char* sB = sA + A_BYTES;
+            const unsigned sA = smem_lds + stage * STAGE_BYTES;       // LDS byte addresses
+            const unsigned sB = sA + A_BYTES;
             if (n_full && (m0 + BM <= p.M) && (k0 + BK <= kend)) {
                 const bf16_t* ab = AKM ? A + k0 * p.lda + m0 : A + m0 * p.lda + k0;
                 const bf16_t* bb = BKM ? B + k0 * p.ldb + n0 : B + (long long)n0 * p.ldb + k0;
 #pragma unroll
-                for (int i = 0; i < NI_A; ++i) glds16(ab + goffA[i], sA + (i * 4 + wave) * 1024);
+                for (int i = 0; i < NI_A; ++i) glds16(ab + goffA[i], sA + (i * NW + wave) * 1024);
 #pragma unroll
-                for (int i = 0; i < NI_B; ++i) glds16(bb + goffB[i], sB + (i * 4 + wave) * 1024);
+                for (int i = 0; i < NI_B; ++i) glds16(bb + goffB[i], sB + (i * NW + wave) * 1024);
             } else {
 #pragma unroll
                 for (int i = 0; i < NI_A; ++i) {
                     const long long m = m0 + gxA[i], k = k0 + gkA[i];
-                    glds16((m < p.M && k < kend) ? (AKM ? A + k * p.lda + m : A + m * p.lda + k) : zero, sA + (i * 4 + wave) * 1024);
+                    glds16((m < p.M && k < kend) ? (AKM ? A + k * p.lda + m : A + m * p.lda + k) : zero, sA + (i * NW + wave) * 1024);
                 }
 #pragma unroll
                 for (int i = 0; i < NI_B; ++i) {
                     const long long n = n0 + gxB[i], k = k0 + gkB[i];
-                    glds16((n < p.N && k < kend) ? (BKM ? B + k * p.ldb + n : B + n * p.ldb + k) : zero, sB + (i * 4 + wave) * 1024);
+                    glds16((n < p.N && k < kend) ? (BKM ? B + k * p.ldb + n : B + n * p.ldb + k) : zero, sB + (i * NW + wave) * 1024);
                 }
             }
         };
@@ -499,8 +520,11 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8) ? 4 : 2) void gemm
             if (pk0 >= kend) { pk0 = kbeg; pm0 += (long long)gm * BM; }
         };
         long long cm0 = pm0, ck0 = pk0;                                  // position of the tile being consumed
-        issue(0, pm0, pk0);
-        advance();
+        constexpr int D = NS - 1;                                        // tiles in flight ahead of the one consumed
+        static_assert((D - 1) * NL < 16, "counted vmcnt wait is encoded in the low 4 bits");
+#pragma unroll
+        for (int t = 0; t < D; ++t)
+            if (t < total) { issue(t, pm0, pk0); advance(); }
         // fragment addresses.  k-contiguous: row r, chunk c -> r * 128 + ((c ^ ((r >> 1) & 7)) << 4); the rows of a
         // fragment are (lane & 15) + multiples of 16, so the swizzle term depends on the lane only.
         // k-major (transpose-read, see tr_frag): lane (g, i) addresses k-row kk*32 + g*8 + (i >> 2) [+4 for the upper
@@ -526,17 +550,21 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8) ? 4 : 2) void gemm
         unsigned long long pacc[6] = {0, 0, 0, 0, 0, 0};
         unsigned long long tprof = __builtin_amdgcn_s_memtime();
 #endif
+        int buf = 0, nbuf = D % NS;             // stage being consumed / stage the next issue goes to
+        bool drain = false;                     // stores of an epilogue are in the queue: count nothing, wait for all
         for (long long i = 0; i < total; ++i) {
-            const int buf = (int)(i & 1);
             if (ck0 == kbeg) {
 #pragma unroll
                 for (int a = 0; a < FM; ++a)
 #pragma unroll
                     for (int b = 0; b < FN; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
             }
-            __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): my part of tile i has landed
+            // tile i has landed once at most the D-1 tiles issued after it are still outstanding (loads return in order)
+            if (D > 1 && !drain && i + D - 1 < total) __builtin_amdgcn_s_waitcnt(0x0F70 | ((D - 1) * NL));
+            else __builtin_amdgcn_s_waitcnt(0x0F70);
+            drain = false;
             GPROF(0);
-            __syncthreads();
+            __builtin_amdgcn_s_barrier();       // every wave's part of tile i is in LDS; everyone is done with stage nbuf
             GPROF(1);
             const unsigned char* sA = smem + buf * STAGE_BYTES;
             const unsigned char* sB = sA + A_BYTES;
@@ -554,8 +582,10 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8) ? 4 : 2) void gemm
                     else bfr[kk][b] = *reinterpret_cast<const bf16x8_t*>(sB + kc_off(wn * WN + b * 16, kk));
                 }
             }
+#ifdef GL_WAIT_FRAGS
             __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0): fragments are in registers
-            if (i + 1 < total) { issue(buf ^ 1, pm0, pk0); advance(); }
+#endif
+            if (i + D < total) { issue(nbuf, pm0, pk0); advance(); }
             GPROF(2);
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk)
@@ -566,7 +596,9 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8) ? 4 : 2) void gemm
                         acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[kk][b], af[kk][a], acc[a][b], 0, 0, 0);
             GPROF(3);
             const bool last_k = ck0 + BK >= kend;
-            if (last_k) { ebuf = buf; epilogue(cm0); }
+            if (last_k) { ebuf = buf; epilogue(cm0); drain = true; }
+            buf = buf + 1 == NS ? 0 : buf + 1;
+            nbuf = nbuf + 1 == NS ? 0 : nbuf + 1;
             GPROF(4);
 #ifdef GEMM_PROF
             pacc[5] += 1;
@@ -731,10 +763,12 @@ int launch(const mc_gemm_args& p, int grid_m, hipStream_t st) {
     return MC_OK;
 }
 
-static bool mc_gemm_glds_enabled() {
+static int mc_gemm_glds_enabled() {
     static int on = -1;
-    if (on < 0) { const char* e = getenv("MC_GEMM_GLDS"); on = (e && e[0] == '0') ? 0 : 1; }   // developer A/B switch
-    return on == 1;
+    // developer A/B switch: 0 = register staging, 1 = direct-to-LDS 128x128 tiles (default), 2 = also 256x128 tiles
+    // (8 waves, 3 stages; measured 0.9-1.07x of the 128x128 configuration on the model's shapes -- not the default)
+    if (on < 0) { const char* e = getenv("MC_GEMM_GLDS"); on = e ? atoi(e) : 1; }
+    return on;
 }
 
 template <int LAY, int PRO, bool CF32>
@@ -745,7 +779,14 @@ int dispatch_tile(const mc_gemm_args& p, int grid_m, hipStream_t st) {
     if (p.N > 64) {
         if constexpr ((LAY == 0 || LAY == 2) && PRO == 0) {
             // plain operands: direct-to-LDS staging
-            if (!small_k && mc_gemm_glds_enabled()) return launch<128, 128, 64, 2, 2, LAY, PRO, CF32, true>(p, grid_m, st);
+            if (!small_k && mc_gemm_glds_enabled()) {
+                if constexpr (LAY == 0) {
+                    // 256 x 128 tiles (8 waves, 3 stages, one workgroup per CU) once there are >= 2 tiles per CU
+                    const long long t256 = ((p.M + 255) / 256) * mc_div_up(p.N, 128) * p.batch * p.splits;
+                    if (t256 >= 512 && mc_gemm_glds_enabled() == 2) return launch<256, 128, 64, 4, 2, LAY, PRO, CF32, true>(p, grid_m, st);
+                }
+                return launch<128, 128, 64, 2, 2, LAY, PRO, CF32, true>(p, grid_m, st);
+            }
         }
         return small_k ? launch<128, 128, 32, 2, 2, LAY, PRO, CF32>(p, grid_m, st)
                        : launch<128, 128, 64, 2, 2, LAY, PRO, CF32>(p, grid_m, st);
