@@ -146,6 +146,17 @@ int mc_stem_weight_prep(const float* w, mc_bf16* out, int c0, void* stream);
  * with static padding (pad_l, pad_t) [ref: efficientnet_custom.py:273, efficient_net_custom_utils.py:248-276] */
 int mc_stem_im2col(const float* x, long long sn, long long sc, long long sh, long long sw,
                    int n, int h, int w, int pad_l, int pad_t, int oh, int ow, mc_bf16* out, void* stream);
+/* input pipeline in front of the stem: raw 8-bit pixels instead of a normalised fp32
+ * batch.  [ref: data/datasets/imagetext.py:131-135]  x = float32(u8); x -= x.min(); x /= x.max(); (x - mean) / std
+ * per image, every step rounded to float32 in that order -- reproduced bit for bit, then the same patches as above.
+ * minmax: unsigned[2][n] workspace = per-image min, then per-image max (filled by mc_image_minmax_u8 from a DENSE
+ * per-image block of elems_per_image bytes at stride sn; the [b,1,H,W,3] -> [b,3,H,W] permute of
+ * trainer_ddp.py:288-291 is again just the (sc, sh, sw) element strides). */
+int mc_image_minmax_u8(const unsigned char* x, long long sn, long long elems_per_image, int n,
+                       unsigned int* minmax, void* stream);
+int mc_stem_im2col_u8(const unsigned char* x, long long sn, long long sc, long long sh, long long sw,
+                      const unsigned int* minmax, float mean, float std, int n, int h, int w, int pad_l,
+                      int pad_t, int oh, int ow, mc_bf16* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * depthwise k x k convolution, NHWC bf16, static asymmetric zero padding

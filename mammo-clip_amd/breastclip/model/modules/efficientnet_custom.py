@@ -122,13 +122,16 @@ class _StemFn(torch.autograd.Function):
         st = _bn_stats(part, n * oh * ow, mod._bn0, training)
         y = ops.bnact_apply(e, n, oh * ow, c0, st.scale, st.shift, 1)
         ctx.mod, ctx.st, ctx.geo = mod, st, (n, h, wd, oh, ow, c0)
-        ctx.save_for_backward(x, e)
+        ctx.raw = (x.mean, x.std) if isinstance(x, ops.RawImages) else None
+        ctx.save_for_backward(x.data if ctx.raw else x, e)
         mod._geo = (n, oh, ow)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, e = ctx.saved_tensors
+        if ctx.raw:
+            x = ops.RawImages(x, *ctx.raw)
         n, h, wd, oh, ow, c0 = ctx.geo
         mod = ctx.mod
         de, dgamma, dbeta = ops.bnact_bwd(e, n, oh * ow, c0, ctx.st, mod._bn0.weight, 1, g=dy.contiguous())
@@ -442,7 +445,7 @@ class EfficientNet(nn.Module):
     def _features_nhwc(self, inputs):
         if not inputs.is_cuda:
             raise RuntimeError("mammo_clip_amd.EfficientNet runs only on a HIP device (no CPU fallback)")
-        x = inputs if inputs.dtype == torch.float32 else inputs.float()
+        x = inputs if isinstance(inputs, ops.RawImages) or inputs.dtype == torch.float32 else inputs.float()
         seed = self.rng.next()
         self._last_seed = seed
         y = _StemFn.apply(x, self._conv_stem.weight, self._bn0.weight, self._bn0.bias, self)

@@ -65,20 +65,29 @@ __global__ void stem_weight_prep_k(const float* __restrict__ w, bf16_t* __restri
     }
 }
 
-// one thread per output pixel: gathers the 3x3x3 patch (k = cin*9 + kh*3 + kw) and writes 64 bytes
-__global__ void stem_im2col_k(const float* __restrict__ x, long long sn, long long sc, long long sh,
+// one thread per output pixel: gathers the 3x3x3 patch (k = cin*9 + kh*3 + kw) and writes 64 bytes.
+// SRC = float: the batch is already normalised.  SRC = unsigned char: raw 8-bit pixels; the dataset's normalisation
+// [ref: data/datasets/imagetext.py:131-135: x -= x.min(); x /= x.max(); (x - mean) / std, all in float32] is applied
+// on the fly with the same operation order and roundings (mm = per-image {min}[n], {max}[n] from image_minmax_u8_k).
+template <typename SRC>
+__global__ void stem_im2col_k(const SRC* __restrict__ x, long long sn, long long sc, long long sh,
                               long long sw, int n, int h, int w, int pad_l, int pad_t, int oh, int ow,
-                              bf16_t* __restrict__ out) {
+                              bf16_t* __restrict__ out, const unsigned int* __restrict__ mm, float mean, float stdv) {
     long long pix = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     long long total = (long long)n * oh * ow;
     if (pix >= total) return;
     int ox = (int)(pix % ow);
     int oy = (int)((pix / ow) % oh);
     long long img = pix / ((long long)ow * oh);
+    float lo = 0.f, range = 1.f;
+    if constexpr (sizeof(SRC) == 1) {
+        lo = (float)mm[img];
+        range = (float)mm[n + img] - lo;               // = max of the shifted image
+    }
     float v[32];
 #pragma unroll
     for (int i = 27; i < 32; ++i) v[i] = 0.f;
-    const float* base = x + img * sn;
+    const SRC* base = x + img * sn;
 #pragma unroll
     for (int c = 0; c < 3; ++c)
 #pragma unroll
@@ -88,13 +97,55 @@ __global__ void stem_im2col_k(const float* __restrict__ x, long long sn, long lo
             for (int kw = 0; kw < 3; ++kw) {
                 int ix = ox * 2 + kw - pad_l;
                 float val = 0.f;
-                if (iy >= 0 && iy < h && ix >= 0 && ix < w) val = base[c * sc + iy * sh + ix * sw];
+                if (iy >= 0 && iy < h && ix >= 0 && ix < w) {
+                    if constexpr (sizeof(SRC) == 1) {
+                        float t = (float)base[c * sc + iy * sh + ix * sw] - lo;
+                        t = __fdiv_rn(t, range);
+                        val = __fdiv_rn(__fsub_rn(t, mean), stdv);
+                    } else {
+                        val = base[c * sc + iy * sh + ix * sw];
+                    }
+                }
                 v[c * 9 + kh * 3 + kw] = val;
             }
         }
     uint4* o = reinterpret_cast<uint4*>(out + pix * 32);
 #pragma unroll
     for (int q = 0; q < 4; ++q) o[q] = pack8(v + q * 8);
+}
+
+// per-image min / max of a dense 8-bit image block (integer atomics: exact and order-independent)
+__global__ void image_minmax_u8_k(const unsigned char* __restrict__ x, long long sn, long long elems, int n,
+                                  unsigned int* __restrict__ mm) {
+    const int img = blockIdx.y;
+    const unsigned char* base = x + img * sn;
+    unsigned int lo = 255u, hi = 0u;
+    const long long nv = elems / 16;
+    const bool al = ((reinterpret_cast<uintptr_t>(base)) & 15) == 0;
+    if (al) {
+        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long long)gridDim.x * blockDim.x) {
+            const uint4 q = reinterpret_cast<const uint4*>(base)[i];
+            const unsigned int wds[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const unsigned int u = (wds[j] >> (8 * b)) & 0xffu;
+                    lo = u < lo ? u : lo; hi = u > hi ? u : hi;
+                }
+        }
+    }
+    for (long long i = (al ? nv * 16 : 0) + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < elems;
+         i += (long long)gridDim.x * blockDim.x) {
+        const unsigned int u = base[i];
+        lo = u < lo ? u : lo; hi = u > hi ? u : hi;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned int l2 = __shfl_xor(lo, o), h2 = __shfl_xor(hi, o);
+        lo = l2 < lo ? l2 : lo; hi = h2 > hi ? h2 : hi;
+    }
+    if ((threadIdx.x & 63) == 0) { atomicMin(&mm[img], lo); atomicMax(&mm[n + img], hi); }
 }
 
 __global__ void dropout_f32_k(const float* __restrict__ x, float* __restrict__ y, long long n, float p,
@@ -207,8 +258,33 @@ extern "C" int mc_stem_im2col(const float* x, long long sn, long long sc, long l
     MC_CHECK(x && out && n > 0 && h > 0 && w > 0 && oh > 0 && ow > 0, "stem_im2col: bad args");
     MC_CHECK(mc_aligned16(out), "stem_im2col: out must be 16-byte aligned");
     long long total = (long long)n * oh * ow;
-    hipLaunchKernelGGL(stem_im2col_k, dim3(mc_div_up(total, 256)), dim3(256), 0, (hipStream_t)stream, x, sn, sc,
-                       sh, sw, n, h, w, pad_l, pad_t, oh, ow, out);
+    hipLaunchKernelGGL(stem_im2col_k<float>, dim3(mc_div_up(total, 256)), dim3(256), 0, (hipStream_t)stream, x, sn, sc,
+                       sh, sw, n, h, w, pad_l, pad_t, oh, ow, out, (const unsigned int*)nullptr, 0.f, 1.f);
+    MC_LAUNCH_CHECK();
+    return MC_OK;
+}
+extern "C" int mc_image_minmax_u8(const unsigned char* x, long long sn, long long elems_per_image, int n,
+                                  unsigned int* minmax, void* stream) {
+    MC_CHECK(x && minmax && n > 0 && elems_per_image > 0 && sn >= elems_per_image, "image_minmax_u8: bad args");
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(minmax, 0xff, (size_t)n * 4, st) != hipSuccess || hipMemsetAsync(minmax + n, 0, (size_t)n * 4, st) != hipSuccess) {
+        mc_set_error("image_minmax_u8: memset failed");
+        return MC_ERR_LAUNCH;
+    }
+    long long per = mc_div_up(elems_per_image, 256 * 16 * 8);
+    int gx = (int)(per < 1 ? 1 : (per > 64 ? 64 : per));
+    hipLaunchKernelGGL(image_minmax_u8_k, dim3(gx, n), dim3(256), 0, st, x, sn, elems_per_image, n, minmax);
+    MC_LAUNCH_CHECK();
+    return MC_OK;
+}
+extern "C" int mc_stem_im2col_u8(const unsigned char* x, long long sn, long long sc, long long sh, long long sw,
+                                 const unsigned int* minmax, float mean, float std, int n, int h, int w, int pad_l,
+                                 int pad_t, int oh, int ow, mc_bf16* out, void* stream) {
+    MC_CHECK(x && minmax && out && n > 0 && h > 0 && w > 0 && oh > 0 && ow > 0 && std != 0.f, "stem_im2col_u8: bad args");
+    MC_CHECK(mc_aligned16(out), "stem_im2col_u8: out must be 16-byte aligned");
+    long long total = (long long)n * oh * ow;
+    hipLaunchKernelGGL(stem_im2col_k<unsigned char>, dim3(mc_div_up(total, 256)), dim3(256), 0, (hipStream_t)stream, x, sn,
+                       sc, sh, sw, n, h, w, pad_l, pad_t, oh, ow, out, minmax, mean, std);
     MC_LAUNCH_CHECK();
     return MC_OK;
 }

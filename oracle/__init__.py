@@ -17,4 +17,4 @@ reference's own outputs generated here.
 Each function cites the reference file:line (relative to /root/reference/src/codebase/breastclip)
 that it restates.
 """
-from . import arch, efficientnet, bert, clip, loss, weights  # noqa: F401
+from . import arch, efficientnet, bert, clip, loss, weights, inputs  # noqa: F401

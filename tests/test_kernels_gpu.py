@@ -592,3 +592,43 @@ def test_adamw_multi_tensor_vs_torch():
     om2.step(); ot2.step()
     for a, b in zip(mine, ref):
         torch.testing.assert_close(a, b, rtol=2e-6, atol=4e-7)
+
+
+def test_raw_u8_input_pipeline_matches_host_normalisation():
+    """row N4: uint8 pixels + (mean, std) through the stem's fused load == the dataset's host-side normalisation
+    [ref: imagetext.py:131-135] followed by the fp32 path, BIT for bit (same float32 operation order), for the
+    trainer's permuted [b,1,H,W,3] view (trainer_ddp.py:288-291) and for a plain NCHW batch; forward and the stem's
+    weight gradient.  Images with different ranges per sample, one of them with 3 distinct channels."""
+    import numpy as np
+    from oracle import inputs as oin
+    from mammo_clip_amd.breastclip.model.modules import load_image_encoder
+    rng = np.random.default_rng(5)
+    b, H, W = 3, 70, 54
+    mean, std = 0.3089279, 0.25053555408335154                      # pre_train_b5_clip.yaml:23-24
+    raw = np.stack([np.repeat(rng.integers(lo, hi, size=(H, W, 1), dtype=np.uint8), 3, axis=2)
+                    for lo, hi in ((0, 256), (17, 201), (90, 131))])
+    raw[2] = rng.integers(3, 250, size=(H, W, 3), dtype=np.uint8)
+    ref = np.stack([oin.normalize_u8(raw[i], mean, std) for i in range(b)])           # [b,H,W,3] float32
+    enc = load_image_encoder({"source": "cnn", "name": "tf_efficientnetv2-detect", "pretrained": False, "model_type": "cnn"}).to(DEV)
+    enc.eval()
+    x_f = torch.from_numpy(ref).to(DEV).unsqueeze(1).squeeze(1).permute(0, 3, 1, 2)    # trainer's view of [b,1,H,W,3]
+    u8 = torch.from_numpy(raw).to(DEV)
+    for x_u in (u8.unsqueeze(1).squeeze(1).permute(0, 3, 1, 2), u8.permute(0, 3, 1, 2).contiguous()):
+        l, r, t, bb = enc.stem_pad
+        oh, ow = (H + t + bb - 3) // 2 + 1, (W + l + r - 3) // 2 + 1
+        pa = ops.stem_im2col(x_f, l, t, oh, ow)
+        pb = ops.stem_im2col(ops.RawImages(x_u, mean, std), l, t, oh, ow)
+        assert torch.equal(pa, pb)
+        with torch.no_grad():
+            ya, yb = enc(x_f), enc(ops.RawImages(x_u, mean, std))
+        assert torch.equal(ya, yb)
+    mm = ops.image_minmax_u8(u8)
+    assert mm.tolist() == [[int(raw[i].min()) for i in range(b)], [int(raw[i].max()) for i in range(b)]]
+    enc.train()
+    ga = []
+    for x in (x_f, ops.RawImages(u8.permute(0, 3, 1, 2), mean, std)):
+        enc.zero_grad(set_to_none=True)
+        enc.rng.seed, enc.rng.calls = 1234, 0
+        enc(x).square().sum().backward()
+        ga.append(enc._conv_stem.weight.grad.clone())
+    assert torch.equal(ga[0], ga[1])
