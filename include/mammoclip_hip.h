@@ -146,6 +146,11 @@ int mc_stem_weight_prep(const float* w, mc_bf16* out, int c0, void* stream);
  * with static padding (pad_l, pad_t) [ref: efficientnet_custom.py:273, efficient_net_custom_utils.py:248-276] */
 int mc_stem_im2col(const float* x, long long sn, long long sc, long long sh, long long sw,
                    int n, int h, int w, int pad_l, int pad_t, int oh, int ow, mc_bf16* out, void* stream);
+/* out[img][n][k] = bf16(w[n][k] * gate[img][k]) (w dense [n,k] bf16, k % 8 == 0): per-image SE-gated copies of the
+ * projection weight [ref: efficientnet_custom.py:119,122  x = sigmoid(se) * x; _project_conv(x)] -- scaling the small
+ * operand instead of the activation tensor lets the projection run as a plain batched GEMM */
+int mc_gate_weights_bf16(const mc_bf16* w, const float* gate, int n_img, int n, int k, mc_bf16* out, void* stream);
+
 /* input pipeline in front of the stem: raw 8-bit pixels instead of a normalised fp32
  * batch.  [ref: data/datasets/imagetext.py:131-135]  x = float32(u8); x -= x.min(); x /= x.max(); (x - mean) / std
  * per image, every step rounded to float32 in that order -- reproduced bit for bit, then the same patches as above.

@@ -148,6 +148,24 @@ __global__ void image_minmax_u8_k(const unsigned char* __restrict__ x, long long
     if ((threadIdx.x & 63) == 0) { atomicMin(&mm[img], lo); atomicMax(&mm[n + img], hi); }
 }
 
+// wg[img][n][k] = bf16( w[n][k] * gate[img][k] ): per-image gated copies of a (small) weight matrix, so that the
+// project GEMM of the late stages runs as a plain batched GEMM (one image per batch entry) with direct-to-LDS staging.
+// Same rounding as scaling the weight tile while it is staged (fp32 product, one round to bf16).
+__global__ void gate_weights_k(const bf16_t* __restrict__ w, const float* __restrict__ gate, int n_img, int n, int k,
+                               bf16_t* __restrict__ out) {
+    const long long kv = k / 8, per = (long long)n * kv;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= per * n_img) return;
+    const long long img = i / per, r = i % per;
+    const int kc = (int)(r % kv);
+    float f[8], g[8];
+    unpack8(*reinterpret_cast<const uint4*>(w + r * 8), f);
+    load8f(gate + img * k + kc * 8, g);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) f[q] *= g[q];
+    *reinterpret_cast<uint4*>(out + i * 8) = pack8(f);
+}
+
 __global__ void dropout_f32_k(const float* __restrict__ x, float* __restrict__ y, long long n, float p,
                               unsigned long long seed, unsigned int sid) {
     long long i8 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -285,6 +303,15 @@ extern "C" int mc_stem_im2col_u8(const unsigned char* x, long long sn, long long
     long long total = (long long)n * oh * ow;
     hipLaunchKernelGGL(stem_im2col_k<unsigned char>, dim3(mc_div_up(total, 256)), dim3(256), 0, (hipStream_t)stream, x, sn,
                        sc, sh, sw, n, h, w, pad_l, pad_t, oh, ow, out, minmax, mean, std);
+    MC_LAUNCH_CHECK();
+    return MC_OK;
+}
+extern "C" int mc_gate_weights_bf16(const mc_bf16* w, const float* gate, int n_img, int n, int k, mc_bf16* out,
+                                    void* stream) {
+    MC_CHECK(w && gate && out && n_img > 0 && n > 0 && k > 0 && k % 8 == 0, "gate_weights: bad args");
+    MC_CHECK(mc_aligned16(w) && mc_aligned16(out) && mc_aligned16(gate), "gate_weights: operands must be 16-byte aligned");
+    const long long total = (long long)n_img * n * (k / 8);
+    hipLaunchKernelGGL(gate_weights_k, dim3(mc_div_up(total, 256)), dim3(256), 0, (hipStream_t)stream, w, gate, n_img, n, k, out);
     MC_LAUNCH_CHECK();
     return MC_OK;
 }

@@ -98,6 +98,7 @@ _SIGS = {
     "mc_stem_weight_prep": ([P, P, I, P], I),
     "mc_stem_im2col": ([P, LL, LL, LL, LL, I, I, I, I, I, I, I, P, P], I),
     "mc_image_minmax_u8": ([P, LL, LL, I, P, P], I),
+    "mc_gate_weights_bf16": ([P, P, I, I, I, P, P], I),
     "mc_stem_im2col_u8": ([P, LL, LL, LL, LL, P, F, F, I, I, I, I, I, I, I, P, P], I),
     "mc_dwconv_stat_rows": ([C.POINTER(DwconvArgs)], I),
     "mc_dwconv_fwd": ([C.POINTER(DwconvArgs), P], I),

@@ -143,8 +143,15 @@ def linear_fwd(x, w, bias=None, act=0, residual=None, stats=False, pro=None, out
         # is scaled by that image's gate while it is staged -- no per-row prologue on the big operand
         hw, n_img = pro[3], M // pro[3]
         part = empty((gemm_stat_rows(hw, N, n_img), 2, N), torch.float32, x) if stats else None
-        gemm(x, w, y, hw, N, K, x.stride(0), w.stride(0), y.stride(0), batch=n_img, sA=(hw * x.stride(0), 0),
-             sC=(hw * y.stride(0), 0), pro=(3, None, None, pro[2], hw, K), stat_partials=part, kind="fwd")
+        if N > 64 and K > 48 and w.is_contiguous():
+            # gated copies of the weight (n_img x N x K, a few MB) -> plain batched GEMM, direct-to-LDS staging
+            wg = empty((n_img, N, K), BF16, x)
+            L.call("mc_gate_weights_bf16", _p(w), _p(pro[2]), n_img, N, K, _p(wg), _st())
+            gemm(x, wg, y, hw, N, K, x.stride(0), K, y.stride(0), batch=n_img, sA=(hw * x.stride(0), 0), sB=(N * K, 0),
+                 sC=(hw * y.stride(0), 0), stat_partials=part, kind="fwd")
+        else:
+            gemm(x, w, y, hw, N, K, x.stride(0), w.stride(0), y.stride(0), batch=n_img, sA=(hw * x.stride(0), 0),
+                 sC=(hw * y.stride(0), 0), pro=(3, None, None, pro[2], hw, K), stat_partials=part, kind="fwd")
         return (y, part) if stats else y
     part = None
     if stats:

@@ -241,7 +241,7 @@ def test_stem_im2col_gemm(nhwc_view):
 # ------------------------------------------------------------------------------------------------ depthwise
 DW_CASES = [(3, 1, (1, 1, 1, 1), 2, 19, 23, 48), (5, 1, (2, 2, 2, 2), 2, 17, 9, 240), (3, 2, (0, 1, 0, 1), 2, 20, 18, 144),
             (5, 2, (1, 2, 1, 2), 1, 21, 19, 40), (3, 2, (1, 1, 1, 1), 2, 9, 9, 72), (5, 2, (2, 2, 2, 2), 1, 15, 15, 16),
-            (5, 1, (2, 2, 2, 2), 1, 40, 33, 16)]
+            (5, 1, (2, 2, 2, 2), 1, 40, 33, 16), (3, 1, (1, 1, 1, 1), 2, 37, 41, 240), (3, 2, (0, 1, 0, 1), 1, 26, 21, 240)]
 
 
 def _dw_ref(x_nhwc, w, k, s, pad, pro):
