@@ -371,6 +371,87 @@ __global__ __launch_bounds__(256) void softmax_bwd_k(const bf16_t* __restrict__ 
     }
 }
 
+// 8 keys per lane (t % 8 == 0, t / 8 a power of two <= 64): a row is G = t/8 adjacent lanes, a wave holds 64/G rows.
+// 32-byte score loads, 16-byte probability stores, ONE dropout draw (8 factors) per lane instead of one per element.
+template <int G>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+template <int G>
+__device__ __forceinline__ float group_max(float v) {
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+template <int G>
+__global__ __launch_bounds__(256) void softmax_fwd_v8_k(const float* __restrict__ sc, long long rows, float p,
+                                                        unsigned long long seed, unsigned int sid,
+                                                        bf16_t* __restrict__ probs, bf16_t* __restrict__ pd) {
+    constexpr int RPW = 64 / G;                                  // rows per wave
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane / G, gl = lane % G;
+    for (long long row0 = ((long long)blockIdx.x * 4 + wave) * RPW; row0 < rows; row0 += (long long)gridDim.x * 4 * RPW) {
+        const long long row = row0 + sub;
+        const bool ok = row < rows;
+        const long long e8 = (ok ? row : 0) * G + gl;            // index of this lane's 8-element group
+        float v[8];
+        load8f(sc + e8 * 8, v);
+        float mx = v[0];
+#pragma unroll
+        for (int q = 1; q < 8; ++q) mx = fmaxf(mx, v[q]);
+        mx = group_max<G>(mx);
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { v[q] = __expf(v[q] - mx); s += v[q]; }
+        s = 1.f / group_sum<G>(s);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] *= s;
+        if (!ok) continue;
+        *reinterpret_cast<uint4*>(probs + e8 * 8) = pack8(v);
+        if (p > 0.f) {
+            float ds[8];
+            dropout_scale8(seed, sid, (unsigned long long)e8, p, ds);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] *= ds[q];
+            *reinterpret_cast<uint4*>(pd + e8 * 8) = pack8(v);
+        } else if (pd != probs) {
+            *reinterpret_cast<uint4*>(pd + e8 * 8) = pack8(v);
+        }
+    }
+}
+template <int G>
+__global__ __launch_bounds__(256) void softmax_bwd_v8_k(const bf16_t* __restrict__ probs, const float* __restrict__ dpd,
+                                                        long long rows, float p, unsigned long long seed,
+                                                        unsigned int sid, float alpha, bf16_t* __restrict__ ds_out) {
+    constexpr int RPW = 64 / G;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane / G, gl = lane % G;
+    for (long long row0 = ((long long)blockIdx.x * 4 + wave) * RPW; row0 < rows; row0 += (long long)gridDim.x * 4 * RPW) {
+        const long long row = row0 + sub;
+        const bool ok = row < rows;
+        const long long e8 = (ok ? row : 0) * G + gl;
+        float pr[8], d[8];
+        unpack8(*reinterpret_cast<const uint4*>(probs + e8 * 8), pr);
+        load8f(dpd + e8 * 8, d);
+        if (p > 0.f) {
+            float dsc[8];
+            dropout_scale8(seed, sid, (unsigned long long)e8, p, dsc);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) d[q] *= dsc[q];
+        }
+        float dot = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) dot += pr[q] * d[q];
+        dot = group_sum<G>(dot);
+        if (!ok) continue;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) d[q] = pr[q] * (d[q] - dot) * alpha;
+        *reinterpret_cast<uint4*>(ds_out + e8 * 8) = pack8(d);
+    }
+}
+
 __global__ void gelu_fwd_k(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, long long n8) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
         float f[8];
@@ -490,8 +571,18 @@ extern "C" int mc_softmax_fwd(const float* scores, long long rows, int t, float 
                               unsigned int stream_id, mc_bf16* probs, mc_bf16* probs_drop, void* stream) {
     MC_CHECK(scores && probs && probs_drop && rows > 0 && t > 0 && t <= 512, "softmax_fwd: bad args (t <= 512)");
     MC_CHECK(p == 0.f || t % 8 == 0, "softmax_fwd: dropout needs t % 8 == 0");
-    hipLaunchKernelGGL(softmax_fwd_k, dim3(row_blocks(rows) * 2), dim3(256), 0, (hipStream_t)stream, scores, rows, t, p, seed,
-                       stream_id, probs, probs_drop);
+    const int g = t / 8;
+    const bool v8 = t % 8 == 0 && g >= 2 && g <= 64 && (g & (g - 1)) == 0 && mc_aligned16(scores) && mc_aligned16(probs) && mc_aligned16(probs_drop);
+    if (v8) {
+        const int blocks = row_blocks(mc_div_up(rows, 64 / g)) * 2;
+#define SM_FWD(G) hipLaunchKernelGGL(softmax_fwd_v8_k<G>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, scores, rows, p, seed, stream_id, probs, probs_drop)
+        switch (g) { case 2: SM_FWD(2); break; case 4: SM_FWD(4); break; case 8: SM_FWD(8); break; case 16: SM_FWD(16); break;
+                     case 32: SM_FWD(32); break; default: SM_FWD(64); break; }
+#undef SM_FWD
+    } else {
+        hipLaunchKernelGGL(softmax_fwd_k, dim3(row_blocks(rows) * 2), dim3(256), 0, (hipStream_t)stream, scores, rows, t, p, seed,
+                           stream_id, probs, probs_drop);
+    }
     MC_LAUNCH_CHECK();
     return MC_OK;
 }
@@ -499,8 +590,18 @@ extern "C" int mc_softmax_bwd(const mc_bf16* probs, const float* dprobs_drop, lo
                               unsigned long long seed, unsigned int stream_id, float alpha, mc_bf16* dscores,
                               void* stream) {
     MC_CHECK(probs && dprobs_drop && dscores && rows > 0 && t > 0 && t <= 512, "softmax_bwd: bad args (t <= 512)");
-    hipLaunchKernelGGL(softmax_bwd_k, dim3(row_blocks(rows) * 2), dim3(256), 0, (hipStream_t)stream, probs, dprobs_drop, rows,
-                       t, p, seed, stream_id, alpha, dscores);
+    const int g = t / 8;
+    const bool v8 = t % 8 == 0 && g >= 2 && g <= 64 && (g & (g - 1)) == 0 && mc_aligned16(probs) && mc_aligned16(dprobs_drop) && mc_aligned16(dscores);
+    if (v8) {
+        const int blocks = row_blocks(mc_div_up(rows, 64 / g)) * 2;
+#define SM_BWD(G) hipLaunchKernelGGL(softmax_bwd_v8_k<G>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, probs, dprobs_drop, rows, p, seed, stream_id, alpha, dscores)
+        switch (g) { case 2: SM_BWD(2); break; case 4: SM_BWD(4); break; case 8: SM_BWD(8); break; case 16: SM_BWD(16); break;
+                     case 32: SM_BWD(32); break; default: SM_BWD(64); break; }
+#undef SM_BWD
+    } else {
+        hipLaunchKernelGGL(softmax_bwd_k, dim3(row_blocks(rows) * 2), dim3(256), 0, (hipStream_t)stream, probs, dprobs_drop, rows,
+                           t, p, seed, stream_id, alpha, dscores);
+    }
     MC_LAUNCH_CHECK();
     return MC_OK;
 }
