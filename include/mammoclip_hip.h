@@ -339,6 +339,7 @@ typedef struct {
     float* exp_avg;
     float* exp_avg_sq;
     long long numel;
+    mc_bf16* bf16_image;   /* optional: bf16 copy of the updated parameter (same element order), or NULL */
 } mc_adamw_tensor;
 int mc_adamw_step(const mc_adamw_tensor* tensors, int n_tensors, double lr, double beta1, double beta2, double eps,
                   double weight_decay, long long step, void* stream);

@@ -28,8 +28,10 @@ class AdamW(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        from .. import ops
         for group in self.param_groups:
             by_step = {}
+            images = ops.cached_cast_images([p for p in group["params"] if p.grad is not None])
             for p in group["params"]:
                 if p.grad is None:
                     continue
@@ -51,11 +53,14 @@ class AdamW(torch.optim.Optimizer):
                 for i, (p, g, m, v) in enumerate(items):
                     a = arr[i]
                     a.param, a.grad, a.exp_avg, a.exp_avg_sq, a.numel = p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel()
+                    im = images.get(id(p))
+                    a.bf16_image = im[1].data_ptr() if im is not None else None
                 L.call("mc_adamw_step", arr, len(items), float(group["lr"]), float(b1), float(b2), float(group["eps"]),
                        float(group["weight_decay"]), t, stream)
                 # the kernel wrote through raw pointers: tell autograd (and the derived-weight-image cache in ops.py,
                 # which keys on the version counter) that these tensors changed in place
                 torch.autograd.graph.increment_version([it[0] for it in items])
+            ops.stamp_cast_images(images)      # the bf16 images written by the kernel are current for the new versions
         return loss
 
 

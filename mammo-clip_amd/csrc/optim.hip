@@ -1,17 +1,19 @@
 // Multi-tensor AdamW update for the hot loop's optimizer step [ref: breastclip/optimizer/__init__.py:28-29 builds
 // torch.optim.AdamW over ALL parameters; trainer_ddp.py:300-303 steps it once per iteration].
 // HBM-bound: 16 B read + 12 B written per element (param, grad, exp_avg, exp_avg_sq), ~3.9 GB for the 138 M-parameter
-// B5 + BERT model.  Up to MC_ADAMW_PACK tensors go into one launch (pointers travel as kernel arguments, no device
+// B5 + BERT model; a parameter that is consumed as a bf16 matrix gets its bf16 image rewritten by the same pass (+2 B)
+// instead of by a cast kernel of its own in the next forward.  Up to PACK tensors go into one launch (pointers travel as kernel arguments, no device
 // table to keep in sync); a workgroup owns one CHUNK of one tensor, found by a scan over the pack's chunk prefix.
 #include "common.cuh"
 #include "../../include/mammoclip_hip.h"
 
 namespace {
 
-constexpr int PACK = 48;             // tensors per launch: 48 * 36 B + scalars stays far below the 4 KB argument limit
+constexpr int PACK = 40;             // tensors per launch: 40 * 44 B + scalars stays far below the 4 KB argument limit
 constexpr int CHUNK = 16384;         // elements per workgroup: 64 KB per stream in flight across its 256 lanes
 
 struct AdamPack {
+    bf16_t* img[PACK];               // optional bf16 image of the updated parameter (nullptr: none)
     float* p[PACK];
     const float* g[PACK];
     float* m[PACK];
@@ -48,9 +50,11 @@ __global__ void __launch_bounds__(256) adamw_multi_k(AdamPack pk, int count, Ada
     const float* __restrict__ g = pk.g[t] + base;
     float* __restrict__ m = pk.m[t] + base;
     float* __restrict__ v = pk.v[t] + base;
+    bf16_t* __restrict__ img = pk.img[t] ? pk.img[t] + base : nullptr;      // base is a multiple of 16384: alignment kept
     const long long left = n - base;
     const int len = left < CHUNK ? (int)left : CHUNK;
-    const bool vec = ((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) == 0;
+    const bool vec = ((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) == 0 &&
+                     (((uintptr_t)img) & 7) == 0;
     int i = threadIdx.x * 4;
     if (vec) {
         // 2 float4 per array in flight per lane (8 loads) before the first use
@@ -66,6 +70,10 @@ __global__ void __launch_bounds__(256) adamw_multi_k(AdamPack pk, int count, Ada
             *(float4*)(p + i) = P0; *(float4*)(p + i + 1024) = P1;
             *(float4*)(m + i) = M0; *(float4*)(m + i + 1024) = M1;
             *(float4*)(v + i) = V0; *(float4*)(v + i + 1024) = V1;
+            if (img) {
+                *(uint2*)(img + i) = make_uint2(pack_bf2(P0.x, P0.y), pack_bf2(P0.z, P0.w));
+                *(uint2*)(img + i + 1024) = make_uint2(pack_bf2(P1.x, P1.y), pack_bf2(P1.z, P1.w));
+            }
         }
         for (; i + 3 < len; i += 1024) {
             float4 P0 = *(const float4*)(p + i), G0 = *(const float4*)(g + i);
@@ -73,6 +81,7 @@ __global__ void __launch_bounds__(256) adamw_multi_k(AdamPack pk, int count, Ada
             adamw1(P0.x, G0.x, M0.x, V0.x, s); adamw1(P0.y, G0.y, M0.y, V0.y, s);
             adamw1(P0.z, G0.z, M0.z, V0.z, s); adamw1(P0.w, G0.w, M0.w, V0.w, s);
             *(float4*)(p + i) = P0; *(float4*)(m + i) = M0; *(float4*)(v + i) = V0;
+            if (img) *(uint2*)(img + i) = make_uint2(pack_bf2(P0.x, P0.y), pack_bf2(P0.z, P0.w));
         }
         // ragged tail of the chunk: the (< 4) elements after the last whole float4
         const int done = len & ~3;
@@ -81,12 +90,14 @@ __global__ void __launch_bounds__(256) adamw_multi_k(AdamPack pk, int count, Ada
             float P = p[j], M = m[j], V = v[j];
             adamw1(P, g[j], M, V, s);
             p[j] = P; m[j] = M; v[j] = V;
+            if (img) img[j] = f2bf(P);
         }
     } else {
         for (int j = threadIdx.x; j < len; j += 256) {
             float P = p[j], M = m[j], V = v[j];
             adamw1(P, g[j], M, V, s);
             p[j] = P; m[j] = M; v[j] = V;
+            if (img) img[j] = f2bf(P);
         }
     }
 }
@@ -127,6 +138,7 @@ extern "C" int mc_adamw_step(const mc_adamw_tensor* tensors, int n_tensors, doub
             if (r != MC_OK) return r;
         }
         pk.p[cnt] = t.param; pk.g[cnt] = t.grad; pk.m[cnt] = t.exp_avg; pk.v[cnt] = t.exp_avg_sq;
+        pk.img[cnt] = t.bf16_image;
         pk.n[cnt] = t.numel; pk.first_chunk[cnt] = chunks;
         chunks += (int)nch;
         ++cnt;

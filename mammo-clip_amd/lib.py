@@ -77,7 +77,7 @@ class BnactArgs(C.Structure):
 
 
 class AdamwTensor(C.Structure):
-    _fields_ = [("param", P), ("grad", P), ("exp_avg", P), ("exp_avg_sq", P), ("numel", LL)]
+    _fields_ = [("param", P), ("grad", P), ("exp_avg", P), ("exp_avg_sq", P), ("numel", LL), ("bf16_image", P)]
 
 
 _SIGS = {

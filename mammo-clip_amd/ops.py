@@ -119,6 +119,31 @@ def _cached(kind, src, make):
     return val
 
 
+def cached_cast_images(params):
+    """{id(param): (cache key, bf16 image)} for parameters whose WHOLE tensor has a live plain-cast image in the cache:
+    the optimizer kernel rewrites these images in the pass that updates the parameter (see AdamW.step) and re-stamps
+    them with ``stamp_cast_images``, so the next forward finds them current."""
+    want = {id(p): p for p in params}
+    out = {}
+    for key, (ref, _ver, val) in _WCACHE.items():
+        if key[0] != "c":
+            continue
+        base = ref()
+        if base is None or id(base) not in want or base is not want[id(base)]:
+            continue
+        if key[2] == base.data_ptr() and val.numel() == base.numel() and val.is_contiguous() and base.is_contiguous():
+            out[id(base)] = (key, val)
+    return out
+
+
+def stamp_cast_images(found):
+    for key, _val in found.values():
+        ref, _ver, val = _WCACHE[key]
+        base = ref()
+        if base is not None:
+            _WCACHE[key] = (ref, base._version, val)
+
+
 def cast_transpose_bf16(src2d):
     """fp32 [rows, cols] -> bf16 [cols, rows]"""
     def make():

@@ -587,11 +587,15 @@ def test_adamw_multi_tensor_vs_torch():
             b.grad = v.clone()
             off += a.numel()
 
+    big = mine[-1]
+    img0 = ops.cast_bf16(big.view(300, 768))                        # a cached bf16 image of a parameter ...
     for step in range(6):
         set_grads(step)
         for o in (om, ot):
             o.param_groups[0]["lr"] = 3e-3 * (0.5 + 0.1 * step)
         om.step(); ot.step()
+        img = ops.cast_bf16(big.view(300, 768))                     # ... is rewritten by the optimizer kernel itself
+        assert img is img0 and torch.equal(img, big.detach().to(BF).view(300, 768)), step
     for a, b in zip(mine, ref):
         torch.testing.assert_close(a, b, rtol=2e-6, atol=2e-7)
         torch.testing.assert_close(om.state[a]["exp_avg_sq"], ot.state[b]["exp_avg_sq"], rtol=2e-6, atol=1e-12)
