@@ -21,6 +21,48 @@ class AdamW(torch.optim.Optimizer):
         if not 0.0 <= lr or not 0.0 <= eps or not 0.0 <= betas[0] < 1.0 or not 0.0 <= betas[1] < 1.0 or weight_decay < 0:
             raise ValueError("invalid AdamW hyper-parameters")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=False))
+        self._plans = {}          # group index -> host-side launch plan (pointer table, step counters)
+
+    # The per-parameter ``state["step"]`` tensors of torch.optim.AdamW are kept, but the hot loop counts in Python ints
+    # and writes them back only when the state is looked at (state_dict) -- 700 tiny CPU tensor updates per step are
+    # host time the small configurations cannot hide.
+    def _sync_steps(self):
+        for plan in self._plans.values():
+            for p, t in zip(plan["params"], plan["steps"]):
+                self.state[p]["step"].fill_(float(t))
+
+    def state_dict(self):
+        self._sync_steps()
+        return super().state_dict()
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._plans = {}
+
+    def _plan(self, gi, group):
+        params = [p for p in group["params"] if p.grad is not None]
+        plan = self._plans.get(gi)
+        if plan is not None and len(plan["params"]) == len(params) and all(a is b for a, b in zip(plan["params"], params)):
+            return plan
+        if plan is not None:
+            self._sync_steps()
+        steps = []
+        arr = (L.AdamwTensor * max(len(params), 1))()
+        for i, p in enumerate(params):
+            if not p.is_cuda or p.dtype != torch.float32 or p.grad.is_sparse or not p.is_contiguous():
+                raise L.MammoClipHipError("AdamW: parameters must be dense contiguous fp32 tensors on the GPU "
+                                          "(the HIP kernel is the only path)")
+            st = self.state[p]
+            if len(st) == 0:
+                st["step"] = torch.tensor(0.0, dtype=torch.float32)
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            steps.append(int(st["step"]))
+            a = arr[i]
+            a.param, a.exp_avg, a.exp_avg_sq, a.numel = p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel()
+        plan = {"params": params, "steps": steps, "arr": arr, "gen": -1, "images": {}, "keep": []}
+        self._plans[gi] = plan
+        return plan
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -29,38 +71,39 @@ class AdamW(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         from .. import ops
-        for group in self.param_groups:
-            by_step = {}
-            images = ops.cached_cast_images([p for p in group["params"] if p.grad is not None])
-            for p in group["params"]:
-                if p.grad is None:
-                    continue
-                if not p.is_cuda or p.dtype != torch.float32 or p.grad.is_sparse or not p.is_contiguous():
-                    raise L.MammoClipHipError("AdamW: parameters must be dense contiguous fp32 tensors on the GPU "
-                                              "(the HIP kernel is the only path)")
-                st = self.state[p]
-                if len(st) == 0:
-                    st["step"] = torch.tensor(0.0, dtype=torch.float32)
-                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                st["step"] += 1
-                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
-                by_step.setdefault(int(st["step"]), []).append((p, g, st["exp_avg"], st["exp_avg_sq"]))
+        for gi, group in enumerate(self.param_groups):
+            plan = self._plan(gi, group)
+            params, arr, steps = plan["params"], plan["arr"], plan["steps"]
+            if not params:
+                continue
+            if plan["gen"] != ops.cache_generation():          # bf16 images the kernel keeps current (see ops._cached)
+                plan["images"] = ops.cached_cast_images(params)
+                plan["gen"] = ops.cache_generation()
+                for i, p in enumerate(params):
+                    im = plan["images"].get(id(p))
+                    arr[i].bf16_image = im[1].data_ptr() if im is not None else None
+            keep = plan["keep"] = []
+            for i, p in enumerate(params):
+                g = p.grad
+                if not g.is_contiguous():
+                    g = g.contiguous()
+                    keep.append(g)
+                arr[i].grad = g.data_ptr()
+                steps[i] += 1
             b1, b2 = group["betas"]
             stream = torch.cuda.current_stream().cuda_stream
-            for t, items in by_step.items():
-                arr = (L.AdamwTensor * len(items))()
-                for i, (p, g, m, v) in enumerate(items):
-                    a = arr[i]
-                    a.param, a.grad, a.exp_avg, a.exp_avg_sq, a.numel = p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel()
-                    im = images.get(id(p))
-                    a.bf16_image = im[1].data_ptr() if im is not None else None
-                L.call("mc_adamw_step", arr, len(items), float(group["lr"]), float(b1), float(b2), float(group["eps"]),
-                       float(group["weight_decay"]), t, stream)
-                # the kernel wrote through raw pointers: tell autograd (and the derived-weight-image cache in ops.py,
-                # which keys on the version counter) that these tensors changed in place
-                torch.autograd.graph.increment_version([it[0] for it in items])
-            ops.stamp_cast_images(images)      # the bf16 images written by the kernel are current for the new versions
+            hyper = (float(group["lr"]), float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]))
+            if min(steps) == max(steps):
+                L.call("mc_adamw_step", arr, len(params), *hyper, steps[0], stream)
+            else:                                             # parameters that joined later: one launch set per step count
+                for t in sorted(set(steps)):
+                    idx = [i for i, s_ in enumerate(steps) if s_ == t]
+                    sub = (L.AdamwTensor * len(idx))(*[arr[i] for i in idx])
+                    L.call("mc_adamw_step", sub, len(idx), *hyper, t, stream)
+            # the kernel wrote through raw pointers: tell autograd (and the derived-weight-image cache in ops.py,
+            # which keys on the version counter) that these tensors changed in place
+            torch.autograd.graph.increment_version(params)
+            ops.stamp_cast_images(plan["images"])              # ... and that the images it rewrote are current
         return loss
 
 

@@ -101,6 +101,7 @@ def _rows_ok(M, N, K, bias, act):
 # tensors are cached; an entry is tied to the owning tensor OBJECT through a weak reference (addresses and ids are
 # recycled by the allocator) and to its version counter (bumped by the optimizer's in-place update / load_state_dict).
 _WCACHE = {}
+_WGEN = 0          # bumped whenever an image is (re)built: lets the optimizer reuse its parameter -> image map
 
 
 def _cached(kind, src, make):
@@ -116,6 +117,8 @@ def _cached(kind, src, make):
         for k in [k for k, v in _WCACHE.items() if v[0]() is None]:
             del _WCACHE[k]
     _WCACHE[key] = (weakref.ref(base), base._version, val)
+    global _WGEN
+    _WGEN += 1
     return val
 
 
@@ -142,6 +145,10 @@ def stamp_cast_images(found):
         base = ref()
         if base is not None:
             _WCACHE[key] = (ref, base._version, val)
+
+
+def cache_generation():
+    return _WGEN
 
 
 def cast_transpose_bf16(src2d):

@@ -596,6 +596,7 @@ def test_adamw_multi_tensor_vs_torch():
         om.step(); ot.step()
         img = ops.cast_bf16(big.view(300, 768))                     # ... is rewritten by the optimizer kernel itself
         assert img is img0 and torch.equal(img, big.detach().to(BF).view(300, 768)), step
+    om.state_dict()                                                  # step counters are materialised on demand
     for a, b in zip(mine, ref):
         torch.testing.assert_close(a, b, rtol=2e-6, atol=2e-7)
         torch.testing.assert_close(om.state[a]["exp_avg_sq"], ot.state[b]["exp_avg_sq"], rtol=2e-6, atol=1e-12)
