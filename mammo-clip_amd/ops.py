@@ -537,10 +537,11 @@ def se_bwd(pooled, gate, dgate, w1, b1, w2, b2):
     n, c = pooled.shape
     cs = w1.shape[0]
     dpooled = empty((n, c), torch.float32, pooled)
-    dw1 = torch.zeros((cs, c), dtype=torch.float32, device=pooled.device)
-    db1 = torch.zeros((cs,), dtype=torch.float32, device=pooled.device)
-    dw2 = torch.zeros((c, cs), dtype=torch.float32, device=pooled.device)
-    db2 = torch.zeros((c,), dtype=torch.float32, device=pooled.device)
+    # one zero-filled allocation for the four accumulated outputs (one memset instead of four); slices 16-byte aligned
+    n1, pad = cs * c, lambda v: (v + 3) // 4 * 4
+    flat = torch.zeros(2 * n1 + pad(cs) + pad(c), dtype=torch.float32, device=pooled.device)
+    dw1, dw2 = flat[:n1].view(cs, c), flat[n1:2 * n1].view(c, cs)
+    db1, db2 = flat[2 * n1:2 * n1 + cs], flat[2 * n1 + pad(cs):2 * n1 + pad(cs) + c]
     ws = empty((n, c + 2 * cs), torch.float32, pooled)
     L.call("mc_se_bwd", _p(pooled), _p(gate), _p(dgate), _p(w1), _p(b1), _p(w2), _p(b2), n, c, cs, _p(dpooled),
            _p(dw1), _p(db1), _p(dw2), _p(db2), _p(ws), _st())
@@ -590,7 +591,8 @@ def add_ln_fwd(x, res, gamma, beta, eps, p, seed, sid):
 def add_ln_bwd(dy, x, res, gamma, mean, rstd, p, seed, sid):
     rows, h = x.shape
     dx, dres = empty((rows, h), BF16, x), empty((rows, h), BF16, x)
-    dgamma, dbeta = torch.zeros_like(gamma), torch.zeros_like(gamma)
+    gb = torch.zeros((2,) + tuple(gamma.shape), dtype=gamma.dtype, device=gamma.device)
+    dgamma, dbeta = gb[0], gb[1]
     L.call("mc_add_ln_bwd", _p(dy), _p(x), _p(res), _p(gamma), _p(mean), _p(rstd), rows, h, float(p), int(seed),
            int(sid), _p(dx), _p(dres), _p(dgamma), _p(dbeta), _st())
     return dx, dres, dgamma, dbeta
