@@ -88,6 +88,33 @@ __global__ void stem_im2col_k(const SRC* __restrict__ x, long long sn, long long
 #pragma unroll
     for (int i = 27; i < 32; ++i) v[i] = 0.f;
     const SRC* base = x + img * sn;
+    // channels-last memory (the trainer's permuted view: sc == 1, sw == 3): the 3 pixels x 3 channels of one kernel row
+    // are 9 contiguous elements -- interior pixels fetch them as three 3-element loads per row instead of 27 scalars
+    const int ix0 = ox * 2 - pad_l, iy0 = oy * 2 - pad_t;
+    if (sc == 1 && sw == 3 && ix0 >= 0 && ix0 + 2 < w && iy0 >= 0 && iy0 + 2 < h) {
+        struct __attribute__((packed, aligned(sizeof(SRC)))) T3 { SRC a, b, c; };
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const SRC* rp = base + (long long)(iy0 + kh) * sh + (long long)ix0 * 3;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const T3 t3 = *reinterpret_cast<const T3*>(rp + kw * 3);
+                const SRC e[3] = {t3.a, t3.b, t3.c};
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    float val;
+                    if constexpr (sizeof(SRC) == 1) {
+                        float t = (float)e[c] - lo;
+                        t = __fdiv_rn(t, range);
+                        val = __fdiv_rn(__fsub_rn(t, mean), stdv);
+                    } else {
+                        val = e[c];
+                    }
+                    v[c * 9 + kh * 3 + kw] = val;
+                }
+            }
+        }
+    } else
 #pragma unroll
     for (int c = 0; c < 3; ++c)
 #pragma unroll
