@@ -2,6 +2,7 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 [-DGEMM_PROF] scripts/gemmbench.hip -o scripts/gemmbench.bin
 #include "../mammo-clip_amd/csrc/gemm.hip"
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 static char g_err_msg[256];
 extern "C" void mc_set_error(const char* m) { snprintf(g_err_msg, sizeof g_err_msg, "%s", m); }
@@ -26,7 +27,7 @@ int main() {
         if (wg) {   // dW[M x N] = A[K x M]^T B[K x N], fp32 out, split-K through the workspace
             a.a_kmajor = 1; a.b_kmajor = 1; a.c_f32 = 1; a.lda = s.M; a.ldb = s.N; a.ldc = s.N;
             long long tiles = ((s.M + 127) / 128) * ((s.N + 127) / 128), kt = (s.K + 63) / 64;
-            long long sp = (1024 + tiles - 1) / tiles; if (sp > kt / 8) sp = kt / 8; if (sp < 1) sp = 1; if (sp >= 16) sp -= sp % 8;
+            const char* tg = getenv("WG_TARGET"); long long target = tg ? atoll(tg) : 1024; long long sp = (target + tiles - 1) / tiles; if (sp > kt / 8) sp = kt / 8; if (sp < 1) sp = 1; if (sp >= 16) sp -= sp % 8;
             a.splits = (int)sp; a.splitk_ws = ws;
         } else { a.lda = s.K; a.ldb = s.K; a.ldc = s.N; }
         if (mc_gemm_bf16(&a, nullptr)) { printf("err %s\n", mc_last_error()); return 1; }
