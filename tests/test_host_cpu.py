@@ -62,6 +62,11 @@ def test_abi_argument_validation_without_gpu():
     assert lib.mc_wgrad_rows_supported(240, 40) == 1 and lib.mc_wgrad_rows_supported(512, 3072) == 0
     with pytest.raises(L.MammoClipHipError):
         L.call("mc_sgemm", None, 0, 0, None, 0, 0, None, 0, 0, 0, 0, 1.0, 0.0, None, None, None, None)
+    # entry points beside the path and the gated-weight helper
+    assert lib.mc_gate_weights_bf16(None, None, 1, 8, 8, None, None) != 0 and b"gate_weights" in lib.mc_last_error()
+    assert lib.mc_image_minmax_u8(None, 0, 0, 1, None, None) != 0 and b"image_minmax" in lib.mc_last_error()
+    assert lib.mc_stem_im2col_u8(None, 0, 0, 0, 0, None, 0.3, 0.0, 1, 8, 8, 0, 0, 4, 4, None, None) != 0
+    assert b"stem_im2col_u8" in lib.mc_last_error()
 
 
 def test_struct_layouts_match_header():
