@@ -586,12 +586,16 @@ __global__ __launch_bounds__(256) void split_sum_k(const float* __restrict__ ws,
     for (int k = 0; k < splits; ++k) s += ws[(long long)k * n + i];
     out[i] = s;
 }
-static int img_splits(const mc_bnact_args& p) {
+// row splits per image of the per-image reductions: enough workgroups to fill the chip (target / n_img), but not so many
+// that a workgroup's stream gets short.  Measured on the B5 shapes: the one-tensor pool pass is best around 1024
+// workgroups (c = 768: 72 -> 59 us), the two-tensor passes around 2048.  mc_bnact_img_splits() (workspace sizing)
+// reports the larger count.
+static int img_splits(const mc_bnact_args& p, long long target = 2048) {
     int cv = p.c / 8;
     int cvp = cv < 256 ? cv : 256;
     int rpb = 256 / cvp;
     long long per = (p.hw + (long long)rpb * 64 - 1) / ((long long)rpb * 64);
-    long long want = 2048 / (p.n_img > 0 ? p.n_img : 1);
+    long long want = target / (p.n_img > 0 ? p.n_img : 1);
     if (want < 1) want = 1;
     long long s = per < want ? per : want;
     if (s < 1) s = 1;
@@ -602,7 +606,7 @@ extern "C" int mc_bnact_pool(const mc_bnact_args* a, void* stream) {
     const mc_bnact_args& p = *a;
     if (int e = check_bnact(p)) return e;
     MC_CHECK(p.pooled, "bnact_pool: null pooled");
-    int sp = img_splits(p);
+    int sp = img_splits(p, 1024);
     MC_CHECK(sp == 1 || p.split_ws, "bnact_pool: split_ws needed (mc_bnact_img_splits() > 1)");
     hipLaunchKernelGGL((bnact_img_reduce_k<0>), dim3((unsigned)p.n_img, sp), dim3(256), 0, (hipStream_t)stream, p);
     MC_LAUNCH_CHECK();

@@ -69,6 +69,22 @@ def main(b=8, which=("gemm", "dw", "bn")):
                 ms = timeit(fn)
                 print(f"dw k{k}s{s} {kind:10s} c={c:5d} {h}x{w} {ms:8.3f} ms {by/ms/1e6:8.1f} GB/s", flush=True)
             del x, dy
+        if "bn" in which:
+            for (site, m_img, c) in (("dw-site", oh * ow, blk.cexp), ("expand-site", h * w, blk.cexp)):
+                if site == "expand-site" and blk.expand == 1:
+                    continue
+                x = torch.randn(b * m_img, c, device=DEV).to(BF)
+                g = torch.randn(b * m_img, c, device=DEV).to(BF)
+                gam, bet = torch.ones(c, device=DEV), torch.zeros(c, device=DEV)
+                _, part = ops.linear_fwd(torch.randn(4096, 64, device=DEV).to(BF), torch.randn(c, 64, device=DEV).to(BF), stats=True)
+                st = ops.bn_finalize(part, 4096, gam, bet, torch.zeros(c, device=DEV), torch.ones(c, device=DEV), 0.01, 1e-3, False)
+                el = 2.0 * b * m_img * c
+                for kind, fn, nt in (("pool", lambda: ops.bnact_pool(x, b, m_img, c, st.scale, st.shift, 1), 1),
+                                     ("se_sums", lambda: ops.bnact_se_sums(x, g, b, m_img, c, st, 1), 2),
+                                     ("bwd(red+apply)", lambda: ops.bnact_bwd(x, b, m_img, c, st, gam, 1, g=g), 5)):
+                    ms = timeit(fn)
+                    print(f"bn {site:11s} {kind:15s} c={c:5d} hw={m_img:7d} {ms:8.3f} ms {nt * el / ms / 1e6:8.1f} GB/s", flush=True)
+                del x, g
         torch.cuda.empty_cache()
 
 
