@@ -8,11 +8,33 @@
 
 namespace {
 
+// Thread layout of the row-streaming kernels: a 256-thread workgroup is rpb row-lanes x cvp channel-vector lanes (8
+// channels = 16 bytes per lane) and makes one pass over its rows per channel chunk.  Chunk widths: whole rows when that
+// keeps >= 70 % of the lanes busy; otherwise (squeeze pass) a power-of-two main chunk plus the remainder, each pass with
+// as many row-lanes as fit (cv = 132, 1056 channels: 128 x 2 row-lanes + 4 x 64 instead of 132 lanes of 256); above 256
+// vectors every kernel gives the remainder pass its own row-lanes (cv = 384: 256 x 1 + 128 x 2 instead of a half-empty
+// second pass).
+// The power-of-two split pays for the one-tensor squeeze pass only (1056 channels: 108 -> 89 us); the two-tensor
+// passes measured 3-10 % slower with it and keep whole rows up to 256 vectors (split_small = false).
+__host__ __device__ inline int rowmap_width(int cv, int cbase, bool split_small) {
+    if (cbase > 0) return (cv - cbase) < 256 ? (cv - cbase) : 256;
+    if (cv > 256) return 256;
+    if (!split_small || cv * (256 / cv) * 10 >= 256 * 7) return cv;
+    int a = 1;
+    while (a * 2 <= cv) a *= 2;
+    return a;
+}
+
 struct RowMap {
     int cv, cvp, rpb, rl, cl;
-    __device__ RowMap(int c) {
+    bool split_small;
+    __device__ RowMap(int c, bool split_small_ = false) {
         cv = c / 8;
-        cvp = cv < 256 ? cv : 256;
+        split_small = split_small_;
+        set(0);
+    }
+    __device__ void set(int cbase) {          // layout of the pass that starts at channel vector cbase
+        cvp = rowmap_width(cv, cbase, split_small);
         rpb = 256 / cvp;
         rl = threadIdx.x / cvp;
         cl = threadIdx.x % cvp;
@@ -105,7 +127,7 @@ __global__ __launch_bounds__(256) void bnact_apply_k(const mc_bnact_args p) {
 // per-image reductions over hw: MODE 0 = pool (mean of act(z)), MODE 1 = SE dgate (sum g*act(z))
 template <int MODE>
 __global__ __launch_bounds__(256) void bnact_img_reduce_k(const mc_bnact_args p) {
-    RowMap rm(p.c);
+    RowMap rm(p.c, MODE == 0);
     __shared__ float red[256 * 8];
     const long long img = blockIdx.x;
     const bf16_t* xb = p.x + img * p.hw * p.c;
@@ -113,6 +135,7 @@ __global__ __launch_bounds__(256) void bnact_img_reduce_k(const mc_bnact_args p)
     float* dst = (MODE == 0 ? p.pooled : p.dgate) + img * p.c;
     const float post = (MODE == 0) ? 1.0f / (float)p.hw : 1.0f;
     for (int cbase = 0; cbase < rm.cv; cbase += rm.cvp) {
+        rm.set(cbase);
         int v = cbase + rm.cl;
         float acc[8];
 #pragma unroll
@@ -196,6 +219,7 @@ __global__ __launch_bounds__(256) void bnact_se_sums_k(const mc_bnact_args p) {
     const bf16_t* gb = p.g + img * p.hw * p.c;
     const long long plane = p.n_img * p.c;
     for (int cbase = 0; cbase < rm.cv; cbase += rm.cvp) {
+        rm.set(cbase);
         int v = cbase + rm.cl;
         float acc[5][8];
 #pragma unroll
@@ -289,8 +313,9 @@ __global__ __launch_bounds__(256) void bnact_bwd_k(const mc_bnact_args p) {
     bf16_t* dxb = APPLY ? p.dx + img * p.hw * p.c : nullptr;
     const float rs = p.rowscale ? p.rowscale[img] : 1.f;
     const float asc = (p.add_scale == 0.f) ? 1.f : p.add_scale;
-    const long long rstride = (long long)gridDim.x * rm.rpb;
     for (int cbase = 0; cbase < rm.cv; cbase += rm.cvp) {
+        rm.set(cbase);
+        const long long rstride = (long long)gridDim.x * rm.rpb;
         const int v = cbase + rm.cl;
         const bool active = rm.rl < rm.rpb && v < rm.cv;
         float a0[8], a1[8];
@@ -561,7 +586,7 @@ extern "C" int mc_bn_eval_coeffs(const float* gamma, const float* beta, const fl
 }
 static int bwd_grid_x(const mc_bnact_args& p) {
     int cv = p.c / 8;
-    int cvp = cv < 256 ? cv : 256;
+    int cvp = rowmap_width(cv, 0, false);
     int rpb = 256 / (cvp > 0 ? cvp : 1);
     long long per = (p.hw + (long long)rpb * 32 - 1) / ((long long)rpb * 32);      // >= ~32 rows per thread
     long long cap = 4096 / (p.n_img > 0 ? p.n_img : 1);
@@ -592,7 +617,7 @@ __global__ __launch_bounds__(256) void split_sum_k(const float* __restrict__ ws,
 // reports the larger count.
 static int img_splits(const mc_bnact_args& p, long long target = 2048) {
     int cv = p.c / 8;
-    int cvp = cv < 256 ? cv : 256;
+    int cvp = rowmap_width(cv, 0, false);
     int rpb = 256 / cvp;
     long long per = (p.hw + (long long)rpb * 64 - 1) / ((long long)rpb * 64);
     long long want = target / (p.n_img > 0 ? p.n_img : 1);
