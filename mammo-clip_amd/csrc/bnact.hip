@@ -354,7 +354,7 @@ __global__ __launch_bounds__(256) void bnact_bwd_k(const mc_bnact_args p) {
                 if (APPLY) {
 #pragma unroll
                     for (int q = 0; q < 8; ++q) dz[q] = k0[q] * dz[q] + k1[q] * x[q] + k2[q];
-                    *reinterpret_cast<uint4*>(dxb + r * p.c + v * 8) = pack8(dz);
+                    nt_store16(dxb + r * p.c + v * 8, pack8(dz));
                 } else {
 #pragma unroll
                     for (int q = 0; q < 8; ++q) { a0[q] += dz[q]; a1[q] += dz[q] * (x[q] - k0[q]) * k1[q]; }
@@ -368,7 +368,7 @@ __global__ __launch_bounds__(256) void bnact_bwd_k(const mc_bnact_args p) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     xv[u] = *reinterpret_cast<const uint4*>(xb + (r + u * rstride) * p.c + v * 8);
-                    gv[u] = gb ? *reinterpret_cast<const uint4*>(gb + (r + u * rstride) * p.c + v * 8) : z4;
+                    gv[u] = gb ? nt_load16(gb + (r + u * rstride) * p.c + v * 8) : z4;
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) body(r + u * rstride, xv[u], gv[u]);

@@ -61,6 +61,17 @@ __device__ __forceinline__ void load8f(const float* p, float* f) {   // p 16-byt
     f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
 }
 
+// streaming (read-once / write-once) 16-byte accesses: non-temporal cache policy
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void nt_store16(void* p, const uint4& v) {
+    u32x4_t w = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(w, reinterpret_cast<u32x4_t*>(p));
+}
+__device__ __forceinline__ uint4 nt_load16(const void* p) {
+    u32x4_t w = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
+    return make_uint4(w.x, w.y, w.z, w.w);
+}
+
 // v_exp_f32 + v_rcp_f32 (1 ulp): no IEEE division sequence on the streaming paths
 __device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float silu_f(float x) { return x * sigmoid_f(x); }
