@@ -367,7 +367,7 @@ __global__ __launch_bounds__(256) void bnact_bwd_k(const mc_bnact_args p) {
                 uint4 xv[4], gv[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    xv[u] = *reinterpret_cast<const uint4*>(xb + (r + u * rstride) * p.c + v * 8);
+                    xv[u] = nt_load16(xb + (r + u * rstride) * p.c + v * 8);      // x and g are dead after this pass
                     gv[u] = gb ? nt_load16(gb + (r + u * rstride) * p.c + v * 8) : z4;
                 }
 #pragma unroll
