@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void bnact_apply_k(const mc_bnact_args p) {
         int cv = (int)(i % cvn);
         long long pix = i / cvn;
         float f[8], s[8], t[8];
-        unpack8(*reinterpret_cast<const uint4*>(p.x + pix * p.c + cv * 8), f);
+        unpack8(nt_load16(p.x + pix * p.c + cv * 8), f);        // pre-BN tensor and skip input: next read in the backward pass
         load8f(p.scale + cv * 8, s);
         load8f(p.shift + cv * 8, t);
         float rs = p.rowscale ? p.rowscale[pix / p.hw] : 1.f;
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void bnact_apply_k(const mc_bnact_args p) {
         }
         if (p.res) {
             float r[8];
-            unpack8(*reinterpret_cast<const uint4*>(p.res + pix * p.c + cv * 8), r);
+            unpack8(nt_load16(p.res + pix * p.c + cv * 8), r);
 #pragma unroll
             for (int q = 0; q < 8; ++q) f[q] += r[q];
         }
