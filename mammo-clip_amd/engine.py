@@ -7,7 +7,8 @@ the per-rank mean loss) -- but:
     still running (xGMI is point-to-point: few large collectives, not hundreds of small ones),
   * the loss dict stays on the device (no per-step .cpu() sync),
   * BatchNorm running statistics are per-rank like in the reference between its buffer broadcasts; rank 0's buffers
-    are what ``state_dict()`` saves.
+    are what ``state_dict()`` saves, and ``sync_buffers`` (called by ``validate``) puts them on every rank wherever
+    they are read -- the per-forward broadcast of DDP itself is not reproduced because training never reads them.
 """
 import os
 from typing import Dict, List, Optional
@@ -122,12 +123,33 @@ def init_distributed():
 
 
 @torch.no_grad()
+def sync_buffers(model, src: int = 0):
+    """BatchNorm running statistics (and every other buffer) of rank ``src`` on all ranks, like the buffer broadcast
+    torch DDP performs at the start of each forward in the reference [ref: trainer_ddp.py:134, DDP default
+    ``broadcast_buffers=True``].  Training itself uses batch statistics, so this only matters where running statistics
+    are READ: evaluation (``validate`` calls it) and checkpoints (rank 0 saves).  One collective per dtype."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return
+    by_dtype = {}
+    for b in model.buffers():
+        by_dtype.setdefault(b.dtype, []).append(b)
+    for bufs in by_dtype.values():
+        flat = torch.cat([b.reshape(-1) for b in bufs])
+        dist.broadcast(flat, src)
+        off = 0
+        for b in bufs:
+            b.copy_(flat[off:off + b.numel()].view_as(b))
+            off += b.numel()
+
+
+@torch.no_grad()
 def validate(model, loss_func, dataloader_dict: Dict, device=None, max_batches: int = 11) -> Dict[str, Dict[str, float]]:
     """Validation pass of the hot loop's caller [ref: trainer_ddp.py:346-409]: eval mode, ``is_train=False`` losses,
     mean over ranks per batch (the reference's all_reduce(SUM)/world, C5 -- here ONE collective per batch for the
     whole loss dict), accumulated per loss key and divided by ``len(dataloader)``.  Reference quirk kept: at most 11
     batches (``idx == 10: break``) are evaluated but the average still divides by the full loader length."""
     model.eval()
+    sync_buffers(model)
     world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
     out = {}
     for name, loader in dataloader_dict.items():

@@ -255,6 +255,12 @@ def _w2_worker(rank, port, ret):
     gb.finish()
     ok = ok and all(torch.allclose(p.grad, torch.full((4,), 1.5 * (i + 1))) for i, p in enumerate(params[:4]))
     ok = ok and params[4].grad is None
+    # buffers of rank 0 everywhere (DDP broadcast_buffers semantics), mixed dtypes
+    from mammo_clip_amd.engine import sync_buffers
+    bn = torch.nn.BatchNorm2d(3)
+    bn.running_mean.fill_(float(rank + 1)); bn.running_var.fill_(float(10 * (rank + 1))); bn.num_batches_tracked.fill_(7 * (rank + 1))
+    sync_buffers(bn)
+    ok = ok and float(bn.running_mean[0]) == 1.0 and float(bn.running_var[2]) == 10.0 and int(bn.num_batches_tracked) == 7
     # validation pass: per-batch mean over ranks [ref: trainer_ddp.py:384-387]
     from mammo_clip_amd.engine import validate
     res = validate(_ToyModel(), _ToyLoss(), {"d": [{"x": torch.tensor(float(rank + 1 + i))} for i in range(3)]})
