@@ -104,6 +104,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="pairs per GPU (0 = workload default)")
+    ap.add_argument("--micro-batches", type=int, default=1,
+                    help="cut the per-GPU batch into k micro-batches (one extra forward per step; for batches beyond one pass)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--op-profile", action="store_true", help="print a per-entry-point HIP-event breakdown (rank 0)")
     args = ap.parse_args()
@@ -144,13 +146,13 @@ def main():
             torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        ld = trainer.step(batch)
+        ld = trainer.step(batch, args.micro_batches)
     sync()
     timer = L.OpTimer(only=None if args.op_profile else STREAM_OPS)
     L.TIMER = timer
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        ld = trainer.step(batch)
+        ld = trainer.step(batch, args.micro_batches)
     sync()
     dt = time.perf_counter() - t0
     L.TIMER = None
@@ -178,7 +180,8 @@ def main():
             "config": {"workload": f"{args.workload}: {arch_name} + BioClinicalBERT(BERT-base), {b} pairs/GPU "
                                    f"(2 views + 2 reports each), {H}x{W} images, {T}-token reports, breast_clip loss, "
                                    f"AdamW; fwd+loss+bwd+optimizer; dropout/drop-connect on",
-                       "global_batch": b * world, "parallelism": f"dp{world}", "loss": round(loss_val, 5)},
+                       "global_batch": b * world, "parallelism": f"dp{world}" + (f" x {args.micro_batches} micro-batches" if args.micro_batches > 1 else ""),
+                       "loss": round(loss_val, 5)},
             "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel": ROOFLINE_KERNEL, "launches": sc,

@@ -33,6 +33,7 @@ class GradBuckets:
         if cur:
             self._close(cur, cur_n)
         self.seen = set()
+        self.enabled = True            # False: gradients are collected by reduce_all() after several backward calls
         for p in self.params:
             p.register_post_accumulate_grad_hook(self._hook)
 
@@ -54,6 +55,8 @@ class GradBuckets:
         self.seen = set()
 
     def _hook(self, p):
+        if not self.enabled:
+            return
         idx, v = self.bucket_of[p]
         flat = self.buckets[idx][0]
         v.copy_(p.grad)
@@ -69,6 +72,23 @@ class GradBuckets:
             self.handles.append((dist.all_reduce(flat, op=dist.ReduceOp.AVG, async_op=True), None))
         else:
             self.handles.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True), flat))
+
+    def reduce_all(self):
+        """Micro-batched steps run several backward calls per step, so the per-parameter hooks cannot tell when a
+        gradient is final: with ``enabled = False`` the accumulated gradients are moved into the buckets here, after the
+        last backward, and all buckets are reduced (no overlap with backward in that mode)."""
+        for flat, plist, views in self.buckets:
+            for p, v in zip(plist, views):
+                if p.grad is None:
+                    v.zero_()
+                else:
+                    v.copy_(p.grad)
+                    p.grad = v
+            self._reduce(flat)
+        for h, flat in self.handles:
+            h.wait()
+            if flat is not None:
+                flat.div_(dist.get_world_size())
 
     def finish(self):
         """Parameters that got no gradient (e.g. the unused BERT pooler) keep grad None, like under the reference's
@@ -92,7 +112,9 @@ class Trainer:
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self.buckets = GradBuckets(list(model.parameters()), bucket_mb << 20) if self.world > 1 else None
 
-    def step(self, batch: Dict) -> Dict[str, torch.Tensor]:
+    def step(self, batch: Dict, micro_batches: int = 1) -> Dict[str, torch.Tensor]:
+        if micro_batches > 1:
+            return self._step_micro(batch, micro_batches)
         self.model.train()
         self.optimizer.zero_grad(set_to_none=True)
         if self.buckets is not None:
@@ -106,6 +128,87 @@ class Trainer:
         if self.scheduler is not None:
             self.scheduler.step()
         return {k: v.detach() for k, v in loss_dict.items()}
+
+
+# ---------------------------------------------------------------------------------------- micro-batched step
+def _split_batch(batch: Dict, k: int):
+    """k equal slices along the batch dimension of every tensor (token dicts one level down)"""
+    n = batch["images"].shape[0]
+    assert n % k == 0, "the per-GPU batch must be divisible by the number of micro-batches"
+    b = n // k
+
+    def cut(v, i):
+        if torch.is_tensor(v) or hasattr(v, "data") and hasattr(v, "mean"):          # tensors, ops.RawImages
+            if torch.is_tensor(v):
+                return v[i * b:(i + 1) * b]
+            return type(v)(v.data[i * b:(i + 1) * b], v.mean, v.std)
+        if isinstance(v, (list, tuple)):
+            return v[i * b:(i + 1) * b]
+        return {kk: cut(vv, i) for kk, vv in v.items()} if hasattr(v, "items") else v
+    return [{key: cut(val, i) for key, val in batch.items()} for i in range(k)], b
+
+
+def _rng_counters(model):
+    """(image encoder, text model) call counters of the counter-based dropout / drop-connect seeds"""
+    te = model.text_encoder.text_encoder if hasattr(model.text_encoder, "text_encoder") else model.text_encoder
+    return model.image_encoder.rng, te
+
+
+def _step_micro(self, batch: Dict, k: int) -> Dict[str, torch.Tensor]:
+    """One optimizer step over a per-GPU batch that does not fit as one pass (global batch 1024):
+    the batch is cut into k micro-batches and the contrastive loss is still taken over ALL embeddings of the step
+    (and of all ranks) -- exactly the reference's semantics at k x as many data-parallel ranks, each with its own
+    BatchNorm batch statistics [ref: trainer_ddp.py:134 DDP without SyncBN; loss/breast_clip.py:29-127].
+      1. forward every micro-batch without a graph, keep only the embeddings (and the dropout seed counters);
+      2. loss over the concatenated embeddings -> d loss / d embeddings, d loss / d logit_scale;
+      3. re-run each micro-batch with the SAME seeds (counter-based masks: bit-identical forward) and with the
+         BatchNorm running-stat update switched off, and back-propagate its slice of the embedding gradients.
+    Cost: one extra forward per step; activation memory: one micro-batch."""
+    model = self.model
+    model.train()
+    self.optimizer.zero_grad(set_to_none=True)
+    if self.buckets is not None:
+        self.buckets.begin()
+        self.buckets.enabled = False
+    mbs, b = _split_batch(batch, k)
+    irng, trng = _rng_counters(model)
+    keys = ("image_embeddings", "text_embeddings", "text_embeddings2", "image_view_embeddings")
+    counters, parts = [], []
+    with torch.no_grad():
+        for mb in mbs:
+            counters.append((irng.calls, trng._calls))
+            out = model(mb, self.device)
+            parts.append({kk: out[kk] for kk in keys if kk in out})
+    after = (irng.calls, trng._calls)
+    leaf = {kk: torch.cat([p_[kk] for p_ in parts]).detach().requires_grad_(True) for kk in parts[0]}
+    n = next(iter(leaf.values())).shape[0]
+    outputs = dict(leaf, labels=torch.arange(n, device=self.device), logit_scale=model.logit_scale.exp())
+    loss_dict = self.loss_func(**outputs, is_train=True)
+    loss_dict["total"].backward()
+    bns = [m for m in model.modules() if hasattr(m, "track_update")]
+    for m in bns:
+        m.track_update = False
+    try:
+        for i, mb in enumerate(mbs):
+            irng.calls, trng._calls = counters[i]
+            out = model(mb, self.device)
+            ks = list(leaf)
+            torch.autograd.backward([out[kk] for kk in ks], [leaf[kk].grad[i * b:(i + 1) * b] for kk in ks])
+    finally:
+        for m in bns:
+            m.track_update = True
+        irng.calls, trng._calls = after
+        if self.buckets is not None:
+            self.buckets.enabled = True
+    if self.buckets is not None:
+        self.buckets.reduce_all()
+    self.optimizer.step()
+    if self.scheduler is not None:
+        self.scheduler.step()
+    return {kk: v.detach() for kk, v in loss_dict.items()}
+
+
+Trainer._step_micro = _step_micro
 
 
 def init_distributed():

@@ -255,6 +255,18 @@ def _w2_worker(rank, port, ret):
     gb.finish()
     ok = ok and all(torch.allclose(p.grad, torch.full((4,), 1.5 * (i + 1))) for i, p in enumerate(params[:4]))
     ok = ok and params[4].grad is None
+    # micro-batched steps: hooks off, several backward calls, one collection + reduction at the end
+    params2 = [torch.nn.Parameter(torch.full((3,), float(i))) for i in range(4)]
+    gb2 = GradBuckets(params2, bucket_bytes=16)
+    gb2.begin()
+    gb2.enabled = False
+    for rep in range(2):
+        for i, p in enumerate(params2[:3]):
+            (p.sum() * (rank + 1) * (i + 1)).backward()
+    gb2.enabled = True
+    gb2.reduce_all()
+    ok = ok and all(torch.allclose(p.grad, torch.full((3,), 2 * 1.5 * (i + 1))) for i, p in enumerate(params2[:3]))
+    ok = ok and params2[3].grad is None
     # buffers of rank 0 everywhere (DDP broadcast_buffers semantics), mixed dtypes
     from mammo_clip_amd.engine import sync_buffers
     bn = torch.nn.BatchNorm2d(3)

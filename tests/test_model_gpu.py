@@ -168,7 +168,7 @@ def test_loss_kats_vs_reference(cls_name, W):
 
 
 # ------------------------------------------------------------------------------------------------
-def _build(enc_name, arch_name):
+def _build(enc_name, arch_name, stochastic_off=True):
     cfg = {"name": "clip_custom", "temperature": 0.07,
            "image_encoder": {"source": "cnn", "name": enc_name, "pretrained": True, "model_type": "cnn"},
            "text_encoder": {"source": "huggingface", "name": "emilyalsentzer/Bio_ClinicalBERT", "pretrained": False,
@@ -179,7 +179,8 @@ def _build(enc_name, arch_name):
     arch = oarch.build_arch(arch_name)
     sd = ow.synth_state_dict(ow.clip_shapes(arch, obert.BertShape()), seed=10)
     model.load_state_dict(sd, strict=True)
-    set_stochastic_off(model)
+    if stochastic_off:
+        set_stochastic_off(model)
     return model.to(DEV), build_loss(loss_cfg), sd
 
 
@@ -364,3 +365,49 @@ def test_evaluator_entry_points(tmp_path):
     ev2 = Evaluator(ckpt_path=path, tokenizer=types.SimpleNamespace(vocab_size=28996), device=DEV)
     np.testing.assert_array_equal(ev2.encode_image(batch["images"]), img)
     np.testing.assert_array_equal(ev2.encode_text(batch["text_tokens"]), txt)
+
+
+def test_micro_batched_step_matches_full_graph():
+    """SURVEY 8e (global batch beyond one pass): Trainer.step(batch, micro_batches=2) must produce the gradients of the
+    loss over ALL embeddings with per-micro-batch BatchNorm statistics -- checked against plain autograd over both
+    micro-batches at once (graphs of both kept), dropout / drop-connect ON (the re-forward replays the seeds), running
+    statistics updated exactly once per micro-batch."""
+    from mammo_clip_amd import engine
+    z = np.load(os.path.join(GOLDEN, "e2e_b5_small.npz"))
+    _, H, W, T = [int(v) for v in z["meta"]]
+    b, k = 4, 2
+    batch = ow.synth_batch(b, H, W, T, seed=21)
+    bt = {"images": batch["images"].to(DEV), "image_views": batch["image_views"].to(DEV),
+          "text_tokens": {kk: v.to(DEV) for kk, v in batch["text_tokens"].items()},
+          "text_tokens2": {kk: v.to(DEV) for kk, v in batch["text_tokens2"].items()}}
+    mbs, bb = engine._split_batch(bt, k)
+    keys = ("image_embeddings", "text_embeddings", "text_embeddings2", "image_view_embeddings")
+
+    # ground truth: both micro-batches through autograd, one loss
+    model, lossf, sd = _build("tf_efficientnet_b5_ns-detect", "efficientnet-b5", stochastic_off=False)
+    util.GlobalEnv.reset()
+    model.train()
+    outs = [model(mb, DEV) for mb in mbs]
+    full = {kk: torch.cat([o[kk] for o in outs]) for kk in keys}
+    ld = lossf(**full, labels=torch.arange(b, device=DEV), logit_scale=model.logit_scale.exp(), is_train=True)
+    ld["total"].backward()
+    ref_loss = float(ld["total"])
+    ref_g = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+    ref_buf = {n: v.clone() for n, v in model.named_buffers()}
+
+    # micro-batched trainer step with a do-nothing optimizer
+    model2, lossf2, _ = _build("tf_efficientnet_b5_ns-detect", "efficientnet-b5", stochastic_off=False)
+    util.GlobalEnv.reset()
+    opt = torch.optim.SGD(model2.parameters(), lr=0.0)
+    tr = engine.Trainer(model2, lossf2, opt, None, DEV)
+    out = tr.step(bt, micro_batches=k)
+    assert abs(float(out["total"]) - ref_loss) < 2e-6              # (the loss sum itself is a float atomic reduction)
+    g2 = {n: p.grad for n, p in model2.named_parameters() if p.grad is not None}
+    assert g2.keys() == ref_g.keys()
+    for n in ref_g:
+        assert relerr(g2[n], ref_g[n]) < 2e-3, (n, relerr(g2[n], ref_g[n]))
+    for n, v in model2.named_buffers():
+        assert torch.equal(v, ref_buf[n]), n                      # running stats: one update per micro-batch, same order
+    assert int(dict(model2.named_buffers())["image_encoder._bn0.num_batches_tracked"]) == 2 * k
+    # the seed counters continue where the first pass left them
+    assert model2.image_encoder.rng.calls == model.image_encoder.rng.calls
