@@ -56,6 +56,11 @@ class _FusedGather(torch.autograd.Function):
         out = torch.empty(grad.shape[1:], dtype=grad.dtype, device=grad.device)
         if _tensor_collectives_ok():
             dist.reduce_scatter_tensor(out, grad.view((W * grad.shape[1],) + tuple(grad.shape[2:])), op=dist.ReduceOp.SUM)
+        elif grad.is_cuda:
+            # gloo with device tensors (single-GPU multi-process tests): no reduce_scatter -> all_reduce + own slice
+            full = grad.clone()
+            dist.all_reduce(full, op=dist.ReduceOp.SUM)
+            out.copy_(full[dist.get_rank()])
         else:
             dist.reduce_scatter(out, [g.contiguous() for g in grad.unbind(0)], op=dist.ReduceOp.SUM)
         return out

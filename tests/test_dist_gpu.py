@@ -82,3 +82,97 @@ def test_rccl_world1_exchange_steps(tmp_path):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, str(script), ROOT, "29877"], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0 and "RCCL-OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+WORKER2 = r'''
+import os, sys, types
+sys.path.insert(0, sys.argv[1])
+rank, port, outdir = int(sys.argv[2]), sys.argv[3], sys.argv[4]
+import torch, torch.distributed as dist
+dev = torch.device("cuda:0"); torch.cuda.set_device(dev)
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % port, rank=rank, world_size=2)
+import mammo_clip_amd
+from mammo_clip_amd import engine
+from mammo_clip_amd.breastclip import util as U
+from mammo_clip_amd.breastclip.loss import build_loss
+from mammo_clip_amd.breastclip.model import build_model
+from oracle import weights as ow
+cfg = {"name": "clip_custom", "temperature": 0.07,
+       "image_encoder": {"source": "cnn", "name": "tf_efficientnetv2-detect", "pretrained": False, "model_type": "cnn"},
+       "text_encoder": {"source": "huggingface", "name": "emilyalsentzer/Bio_ClinicalBERT", "pretrained": False,
+                        "gradient_checkpointing": False, "pooling": "eos", "cache_dir": "", "trust_remote_code": True},
+       "projection_head": {"name": "linear", "dropout": 0.1, "proj_dim": 512}}
+loss_cfg = {"breast_clip": dict(label_smoothing=0.0, i2i_weight=1.0, t2t_weight=0.5, loss_ratio=1.0)}
+U.GlobalEnv.reset()
+assert U.GlobalEnv.get().world_size == 2
+torch.manual_seed(0)
+model = build_model(cfg, loss_cfg, types.SimpleNamespace(vocab_size=28996)).to(dev)
+batch = ow.synth_batch(4, 64, 64, 16, seed=5)
+lo, hi = rank * 2, rank * 2 + 2
+bt = {"images": batch["images"][lo:hi].to(dev), "image_views": batch["image_views"][lo:hi].to(dev),
+      "text_tokens": {k: v[lo:hi].to(dev) for k, v in batch["text_tokens"].items()},
+      "text_tokens2": {k: v[lo:hi].to(dev) for k, v in batch["text_tokens2"].items()}}
+# the second rank replays the seeds the second MICRO-batch of the single-process run gets (2 encoder calls each)
+model.image_encoder.rng.calls = 2 * rank
+model.text_encoder.text_encoder._calls = 2 * rank
+tr = engine.Trainer(model, build_loss(loss_cfg), torch.optim.SGD(model.parameters(), lr=0.0), None, dev, bucket_mb=16)
+assert tr.buckets is not None
+out = tr.step(bt)
+torch.save({"loss": float(out["total"]), "grads": {n: p.grad.detach().cpu() for n, p in model.named_parameters() if p.grad is not None}},
+           os.path.join(outdir, "r%d.pt" % rank))
+dist.destroy_process_group()
+print("DP-OK")
+'''
+
+
+@pytest.mark.gpu
+def test_two_rank_step_equals_micro_batched_single_process(tmp_path):
+    """Data-parallel identity on the real model (2 processes sharing the one GPU, gloo): mean over ranks of the per-rank
+    loss == loss over the concatenated batch, and the bucket-averaged gradients == the gradients of that global loss
+    with per-rank BatchNorm statistics -- which is what the single-process micro-batched step computes (k = 2)."""
+    import torch
+    import types
+    script = tmp_path / "w2.py"
+    script.write_text(WORKER2)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(r), "29879", str(tmp_path)], stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True, env=env) for r in range(2)]
+    outs = [p.communicate(timeout=600) for p in procs]
+    assert all(p.returncode == 0 and "DP-OK" in o[0] for p, o in zip(procs, outs)), [o[1][-3000:] for o in outs]
+    r0, r1 = (torch.load(tmp_path / ("r%d.pt" % r)) for r in range(2))
+    for n in r0["grads"]:
+        assert torch.equal(r0["grads"][n], r1["grads"][n]), n            # all-reduced: identical on both ranks
+
+    sys.path.insert(0, ROOT)
+    import mammo_clip_amd  # noqa: F401
+    from mammo_clip_amd import engine
+    from mammo_clip_amd.breastclip import util as U
+    from mammo_clip_amd.breastclip.loss import build_loss
+    from mammo_clip_amd.breastclip.model import build_model
+    from oracle import weights as ow
+    dev = torch.device("cuda:0")
+    cfg = {"name": "clip_custom", "temperature": 0.07,
+           "image_encoder": {"source": "cnn", "name": "tf_efficientnetv2-detect", "pretrained": False, "model_type": "cnn"},
+           "text_encoder": {"source": "huggingface", "name": "emilyalsentzer/Bio_ClinicalBERT", "pretrained": False,
+                            "gradient_checkpointing": False, "pooling": "eos", "cache_dir": "", "trust_remote_code": True},
+           "projection_head": {"name": "linear", "dropout": 0.1, "proj_dim": 512}}
+    loss_cfg = {"breast_clip": dict(label_smoothing=0.0, i2i_weight=1.0, t2t_weight=0.5, loss_ratio=1.0)}
+    U.GlobalEnv.reset()
+    torch.manual_seed(0)
+    model = build_model(cfg, loss_cfg, types.SimpleNamespace(vocab_size=28996)).to(dev)
+    batch = ow.synth_batch(4, 64, 64, 16, seed=5)
+    bt = {"images": batch["images"].to(dev), "image_views": batch["image_views"].to(dev),
+          "text_tokens": {k: v.to(dev) for k, v in batch["text_tokens"].items()},
+          "text_tokens2": {k: v.to(dev) for k, v in batch["text_tokens2"].items()}}
+    tr = engine.Trainer(model, build_loss(loss_cfg), torch.optim.SGD(model.parameters(), lr=0.0), None, dev)
+    out = tr.step(bt, micro_batches=2)
+    assert abs(float(out["total"]) - 0.5 * (r0["loss"] + r1["loss"])) < 1e-5
+    worst = 0.0
+    for n, p in model.named_parameters():
+        if p.grad is None:
+            assert n not in r0["grads"] or float(r0["grads"][n].abs().max()) == 0.0
+            continue
+        g = p.grad.detach().cpu()
+        e = float((g - r0["grads"][n]).abs().max() / (g.abs().max() + 1e-12))
+        worst = max(worst, e)
+        assert e < 5e-3, (n, e)
