@@ -4,7 +4,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=/root/repo
 OUT=$R/gpurun_out; mkdir -p $OUT
-CMD="python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline"
+CMD="python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline"   # default workload: global batch 1024 = 32 micro-batches per step
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_kt -- $CMD > $OUT/prof_kt.log 2>&1
 cp $(ls /tmp/prof_kt/*/*kernel_stats.csv | head -1) $OUT/prof_kernel_stats.csv
 cp $(ls /tmp/prof_kt/*/*agent_info.csv | head -1) $OUT/prof_agent_info.csv
