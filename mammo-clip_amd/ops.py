@@ -64,6 +64,8 @@ def gemm(A, B, C_out, M, N, K, lda, ldb, ldc, a_kmajor=0, b_kmajor=0, c_f32=0, c
         a.split_group_rows, a.split_sub, a.split_scale = split_groups[0], split_groups[1], _p(split_groups[2])
     _note(batch * (2 * M * K + 2 * N * K + (4 if c_f32 else 2) * M * N + (2 * M * N if R is not None else 0)),
           2 * batch * M * N * K)
+    if L.TIMER is not None and not a_kmajor and not b_kmajor and pro is None and N > 64 and K > 48 and not c_f32:
+        kind = (kind or "") + "|glnt"       # lands on gemm_kernel<128,128,64,2,2,0,0,false,true> (direct-to-LDS NT tiles)
     L.call("mc_gemm_bf16", C.byref(a), _st(), kind=kind)
 
 
