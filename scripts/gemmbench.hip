@@ -13,6 +13,7 @@ int main() {
     struct Shape { const char* kind; long long M; int N; long long K; };   // GEMM dims as passed to mc_gemm_bf16
     std::vector<Shape> shapes = {
         {"fwd", 173280, 176, 1056}, {"fwd", 173280, 1056, 176}, {"fwd", 44544, 304, 1824}, {"fwd", 44544, 3072, 512}, {"fwd", 44544, 512, 3072},
+        {"fwd", 8192, 768, 768}, {"fwd", 8192, 3072, 768}, {"fwd", 8192, 768, 3072}, {"fwd", 44544, 1824, 304}, {"fwd", 173280, 768, 128}, {"fwd", 173280, 128, 768},
         {"wgrad", 1056, 176, 173280}, {"wgrad", 176, 1056, 173280}, {"wgrad", 1824, 304, 44544}, {"wgrad", 512, 3072, 44544}};
     size_t maxel = (size_t)173280 * 3072;
     bf16_t *A, *B, *C; float* ws;
