@@ -1,7 +1,12 @@
 #!/usr/bin/env python3
 """Headline benchmark: image-text pairs/s of the Mammo-CLIP contrastive pre-training step on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: one process per GPU over RCCL.  Either the driver launches the ranks (``python -m torch.distributed.run
+--nproc-per-node N ... bench.py --gpus N``: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* come from the environment), or a
+plain ``python bench.py --gpus N`` re-executes ITSELF under torch.distributed.run on 127.0.0.1 with a free port; rank 0
+prints the one JSON line either way.
 
 One "step" = one full training step of the hot path on one batch of synthetic data already resident in HBM:
 2 image views + 2 reports per pair through EfficientNet + BioClinicalBERT, projection, fused RCCL all-gather,
@@ -120,6 +125,18 @@ def main():
     ap.add_argument("--op-profile", action="store_true", help="print a per-entry-point HIP-event breakdown (rank 0)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: spawn the N ranks ourselves (one process per GPU, RCCL) and relay rank 0's line
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd, env=env))
+
     import mammo_clip_amd  # noqa: F401
     from mammo_clip_amd import lib as L
     from mammo_clip_amd import engine
@@ -145,9 +162,6 @@ def main():
     util.GlobalEnv.reset()
     torch.manual_seed(10)
     model = build_model(model_cfg(enc_name), LOSS_CFG, types.SimpleNamespace(vocab_size=28996)).to(device)
-    if world > 1:                                  # identical replicas: rank 0's random init everywhere
-        for t in list(model.parameters()) + list(model.buffers()):
-            dist.broadcast(t.data, 0)
     loss_func = build_loss(LOSS_CFG)
     opt = build_optimizer(model, {"name": "adamw", "config": {"lr": 5e-5, "weight_decay": 1e-4}})
     sched = LinearWarmupCosineAnnealingLR(opt, total_steps=10000, warmup_steps=100)

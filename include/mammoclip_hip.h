@@ -7,7 +7,7 @@
  * replaces one such operator call-site (or a fused group of them) and cites it as
  *   [ref: <file>:<lines>]  relative to  src/codebase/breastclip/ .
  * The host-side mirror of the reference's Python API (build_model / build_loss / BreastClip ...) lives in
- * mammo-clip_amd/breastclip/ and binds these symbols with ctypes.
+ * mammo_clip_amd/breastclip/ and binds these symbols with ctypes.
  *
  * Conventions
  *   - plain pointers and sizes only; all pointers are DEVICE pointers unless stated otherwise
@@ -320,11 +320,13 @@ int mc_scale_f32(const float* x, const float* scalar_dev, float alpha, float* y,
 /* y = x / ||x||_2 per row (no epsilon) [ref: model/clip.py:90-91]; bwd: dx = (dy - y*(y.dy)) / ||x|| */
 int mc_l2norm_fwd(const float* x, int rows, int d, float* y, float* norm, void* stream);
 int mc_l2norm_bwd(const float* dy, const float* y, const float* norm, int rows, int d, float* dx, void* stream);
-/* mean cross-entropy over rows of logits [rows, n] with labels row + label_offset, weight w:
+/* mean cross-entropy over rows of logits [rows, n], weight w; the target of row r is labels[r] + label_offset
+ * (labels: int64 device array or NULL = r):
  * loss_out[0] += w * mean_r CE_r (label smoothing `smoothing`);  dlogits = w/rows * (softmax - target)  (in place)
- * [ref: loss/breast_clip.py:50-100 (F.cross_entropy with labels + rank*batch)] */
-int mc_ce_fwd_bwd(float* logits, int rows, int n, int label_offset, float w, float smoothing, float* loss_out,
-                  void* stream);
+ * row_ws: `rows` floats of scratch -- per-row terms, summed in a fixed order (bit-reproducible, no float atomics)
+ * [ref: loss/breast_clip.py:43-100 (labels = labels + rank*batch; F.cross_entropy)] */
+int mc_ce_fwd_bwd(float* logits, int rows, int n, const long long* labels, int label_offset, float w, float smoothing,
+                  float* loss_out, float* row_ws, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * optimizer step of the hot loop [ref: breastclip/optimizer/__init__.py:28-29 ->

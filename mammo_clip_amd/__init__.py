@@ -1,7 +1,6 @@
 """mammo_clip_amd -- MI355X-native (gfx950) implementation of Mammo-CLIP's contrastive pre-training hot path.
 
-The directory is named ``mammo-clip_amd`` (not importable as-is); ``mammo_clip_amd.py`` at the repo root
-registers it under the module name ``mammo_clip_amd``.
+(``mammo-clip_amd`` at the repo root is a symlink to this directory: the layout name of the task, not importable.)
 
   lib.py         ctypes binding of libmammoclip_hip.so (C ABI: include/mammoclip_hip.h)
   ops.py         tensor-level wrappers (device memory + streams from torch, compute from HIP kernels)

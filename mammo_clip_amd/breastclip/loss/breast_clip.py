@@ -50,12 +50,12 @@ class BreastClip(nn.Module):
             terms_nosmooth += [(TXT2, TXT, 0.5 * self.t2t_weight, S_T2T), (TXT, TXT2, 0.5 * self.t2t_weight, S_T2T)]
         off = env.world_rank * b
         if ls == 0.0:
-            total, slots = InfoNCEFn.apply(logit_scale, terms + terms_nosmooth, off, 0.0, 4, *local, *gathered)
+            total, slots = InfoNCEFn.apply(logit_scale, terms + terms_nosmooth, off, 0.0, 4, *local, *gathered, labels)
         else:                                   # ICL / TCL never use label smoothing [ref: breast_clip.py:86-100]
-            t1, slots = InfoNCEFn.apply(logit_scale, terms, off, ls, 4, *local, *gathered)
+            t1, slots = InfoNCEFn.apply(logit_scale, terms, off, ls, 4, *local, *gathered, labels)
             total = t1
             if terms_nosmooth:
-                t2, slots2 = InfoNCEFn.apply(logit_scale, terms_nosmooth, off, 0.0, 4, *local, *gathered)
+                t2, slots2 = InfoNCEFn.apply(logit_scale, terms_nosmooth, off, 0.0, 4, *local, *gathered, labels)
                 total, slots = t1 + t2, slots + slots2
         self.last_terms = slots                 # weighted partial sums (device tensor; no host sync)
         _log(is_train, lambda: [

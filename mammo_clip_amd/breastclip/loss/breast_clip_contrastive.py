@@ -22,7 +22,7 @@ class BreastClip_contrastive(nn.Module):
         gathered = all_gather(local)
         ls = self.label_smoothing if is_train else 0.0
         total, slots = InfoNCEFn.apply(logit_scale, [(0, 1, 0.75, 0), (1, 0, 0.25, 1)], env.world_rank * b, ls, 2,
-                                       *local, *gathered)
+                                       *local, *gathered, labels)
         self.last_terms = slots
         _log(is_train, lambda: [("loss/contrastive/steps_i2t", slots[0] / 0.75), ("loss/contrastive/steps_t2i", slots[1] / 0.25)])
         return total

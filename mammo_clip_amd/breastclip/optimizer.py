@@ -43,7 +43,11 @@ class AdamW(torch.optim.Optimizer):
         params = [p for p in group["params"] if p.grad is not None]
         plan = self._plans.get(gi)
         if plan is not None and len(plan["params"]) == len(params) and all(a is b for a, b in zip(plan["params"], params)):
-            return plan
+            # the plan caches raw device pointers: it is only valid while every parameter / state tensor still lives
+            # where it did (model.to(), p.data = ..., a state moved or replaced by external code all change data_ptr)
+            if all(p.data_ptr() == ptrs[0] and self.state[p]["exp_avg"].data_ptr() == ptrs[1]
+                   and self.state[p]["exp_avg_sq"].data_ptr() == ptrs[2] for p, ptrs in zip(params, plan["ptrs"])):
+                return plan
         if plan is not None:
             self._sync_steps()
         steps = []
@@ -60,7 +64,8 @@ class AdamW(torch.optim.Optimizer):
             steps.append(int(st["step"]))
             a = arr[i]
             a.param, a.exp_avg, a.exp_avg_sq, a.numel = p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel()
-        plan = {"params": params, "steps": steps, "arr": arr, "gen": -1, "images": {}, "keep": []}
+        ptrs = [(a.param, a.exp_avg, a.exp_avg_sq) for a in arr[:len(params)]]
+        plan = {"params": params, "steps": steps, "arr": arr, "gen": -1, "images": {}, "keep": [], "ptrs": ptrs}
         self._plans[gi] = plan
         return plan
 
@@ -113,7 +118,5 @@ def build_optimizer(model: nn.Module, optim_config: Dict):
     if name == "sgd":
         return torch.optim.SGD(params, **optim_config["config"])
     if name == "adamw":
-        if all(p.is_cuda for p in params):
-            return AdamW(params, **optim_config["config"])
-        return torch.optim.AdamW(params, **optim_config["config"])     # host-side tests of the loop on CPU tensors
+        return AdamW(params, **optim_config["config"])      # HIP kernel only: .step() raises on CPU parameters
     raise NotImplementedError(f"Not implemented optimizer : {name}")

@@ -1,0 +1,81 @@
+"""All-gather with autograd over RCCL/xGMI [ref: util/dist_autograd.py:5-27]: forward all_gather in rank order,
+backward reduce_scatter(SUM) of the per-rank gradients.
+
+MI355X note: the 4 embedding tensors of one step are gathered with ONE collective (``all_gather_fused`` below,
+[4,b,D] in -> [W,4,b,D] out) instead of four latency-bound ones; xGMI is point-to-point, messages are <= 1 MiB."""
+import torch
+import torch.distributed as dist
+
+
+def _tensor_collectives_ok():
+    """RCCL ("nccl") has native all_gather_into_tensor / reduce_scatter_tensor; the gloo backend used by the CPU
+    tests gets the list forms of the same collectives."""
+    return dist.get_backend() == "nccl"
+
+
+def _gather_ranks(x):
+    """x [...] on every rank -> [W, ...] in rank order (one collective)"""
+    W = dist.get_world_size()
+    x = x.contiguous()
+    out = torch.empty((W,) + tuple(x.shape), dtype=x.dtype, device=x.device)
+    if _tensor_collectives_ok():
+        dist.all_gather_into_tensor(out.view(-1), x.reshape(-1))
+    else:
+        dist.all_gather(list(out.unbind(0)), x)
+    return out
+
+
+def _reduce_scatter_ranks(grad):
+    """grad [W, ...] on every rank -> sum over ranks of slice [rank] (one collective)"""
+    grad = grad.contiguous()
+    out = torch.empty(grad.shape[1:], dtype=grad.dtype, device=grad.device)
+    if _tensor_collectives_ok():
+        dist.reduce_scatter_tensor(out.view(-1), grad.view(-1), op=dist.ReduceOp.SUM)
+    elif grad.is_cuda:
+        # gloo with device tensors (single-GPU multi-process tests): no reduce_scatter -> all_reduce + own slice
+        full = grad.clone()
+        dist.all_reduce(full, op=dist.ReduceOp.SUM)
+        out.copy_(full[dist.get_rank()])
+    else:
+        dist.reduce_scatter(out, list(grad.unbind(0)), op=dist.ReduceOp.SUM)
+    return out
+
+
+class _FusedGather(torch.autograd.Function):
+    """stacked [k,b,D] -> [W,k,b,D] with ONE all-gather; backward ONE reduce-scatter(SUM)."""
+
+    @staticmethod
+    def forward(ctx, stacked):
+        return _gather_ranks(stacked)
+
+    @staticmethod
+    def backward(ctx, grad):
+        return _reduce_scatter_ranks(grad)
+
+
+def DistAutogradAllGatherFunction(partial=False):
+    """Name-compatible factory of the reference's per-tensor gather [ref: util/dist_autograd.py:5-27]:
+    ``F.apply(x)`` returns the tuple of the W ranks' tensors; backward sums every rank's gradient of this rank's slice
+    (``partial=True``: only this rank's own gradient, no collective).  The product path uses ``all_gather_fused``."""
+
+    class _PerTensorGather(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            return tuple(_gather_ranks(x).unbind(0))
+
+        @staticmethod
+        def backward(ctx, *grads):
+            if partial:
+                return grads[dist.get_rank()].clone()
+            return _reduce_scatter_ranks(torch.stack(grads, 0))
+
+    return _PerTensorGather
+
+
+def all_gather_fused(tensors):
+    """list of k local [b,D] tensors -> list of k gathered [W*b,D] tensors (rank order), one collective."""
+    stacked = torch.stack(tensors, 0)
+    g = _FusedGather.apply(stacked)                       # [W,k,b,D]
+    W, k, b, D = g.shape
+    g = g.permute(1, 0, 2, 3).reshape(k, W * b, D)
+    return [g[i] for i in range(k)]

@@ -4,7 +4,7 @@
 //       BertSelfOutput, BertIntermediate, BertOutput); model/clip.py:65-68 (eos pooling)]
 // One 64-lane wave owns one row (hidden <= 1024, keys <= 512); row reductions are wavefront shuffles;
 // dropout masks are Philox functions of (seed, stream id, element index) and are regenerated in backward.
-#include "common.cuh"
+#include "common_hip.h"
 #include "../../include/mammoclip_hip.h"
 
 namespace {

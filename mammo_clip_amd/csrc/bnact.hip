@@ -3,7 +3,7 @@
 //       efficient_net_custom_utils.py:64-80 (SwishImplementation fwd/bwd), :129-154 (drop_connect)]
 // All kernels are HBM-bound streaming passes: 16-byte (8-channel) vector accesses, per-channel parameters
 // in registers, reductions leave as small partial buffers finished by a tiny finalize kernel (fp64 sums).
-#include "common.cuh"
+#include "common_hip.h"
 #include "../../include/mammoclip_hip.h"
 
 namespace {

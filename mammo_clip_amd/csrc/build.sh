@@ -7,7 +7,7 @@ mkdir -p $OUT
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=fast -Wno-unused-result"
 pids=()
 for f in gemm gemm_rows gemm_wgrad_rows conv bnact bert head optim util; do
-  if [ ! -f $OUT/$f.o ] || [ $f.hip -nt $OUT/$f.o ] || [ common.cuh -nt $OUT/$f.o ] || [ ../../include/mammoclip_hip.h -nt $OUT/$f.o ]; then
+  if [ ! -f $OUT/$f.o ] || [ $f.hip -nt $OUT/$f.o ] || [ common_hip.h -nt $OUT/$f.o ] || [ ../../include/mammoclip_hip.h -nt $OUT/$f.o ]; then
     ( hipcc $FLAGS -c $f.hip -o $OUT/$f.o ) &
     pids+=($!)
   fi

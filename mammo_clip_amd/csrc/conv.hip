@@ -7,7 +7,7 @@
 // activation), partial output rows / tap accumulators held in registers.  Workgroups are persistent over their work
 // items so the per-channel sum / sum-of-squares for the following training-mode BatchNorm leave the forward kernel
 // as a small [workgroups][2][C] partial buffer (deterministic, no atomics).  The stride-2 data gradient is a gather.
-#include "common.cuh"
+#include "common_hip.h"
 #include <type_traits>
 #include "../../include/mammoclip_hip.h"
 

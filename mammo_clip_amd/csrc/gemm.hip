@@ -16,7 +16,7 @@
 // one barrier per K tile, register-staged tiles prefetched across K tiles AND across row blocks.
 // The bf16 epilogue goes back through LDS so global stores are 16-byte row segments, and can emit per-column
 // sum / sum-of-squares partials (training-mode BatchNorm statistics of the conv output).
-#include "common.cuh"
+#include "common_hip.h"
 #include <cstdlib>
 #include <type_traits>
 #include "../../include/mammoclip_hip.h"

@@ -13,7 +13,7 @@
 //   * optional fused BN+SiLU(+SE gate) prologue on the activations, optional per-column sum / sum-of-squares
 //     (training-mode BatchNorm statistics of the output) accumulated by persistent workgroups
 // No __syncthreads() in the main loop: waves run independently.
-#include "common.cuh"
+#include "common_hip.h"
 #include "../../include/mammoclip_hip.h"
 
 namespace {

@@ -9,7 +9,7 @@
 // BN+SiLU(+SE gate) prologue is applied to X on the way in) and every fragment is two transpose-reads -- no scalar
 // LDS transposes, no atomics: each persistent workgroup keeps its N x K partial in MFMA accumulators (the 16x16
 // output tiles are split over the 4 waves) and writes it once to a workspace that a tiny second kernel reduces.
-#include "common.cuh"
+#include "common_hip.h"
 #include "../../include/mammoclip_hip.h"
 
 namespace {

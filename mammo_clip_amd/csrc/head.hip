@@ -2,7 +2,7 @@
 // embeddings / logits / loss in fp32 even under autocast).
 // [ref: model/modules/projection.py:23-29, model/clip.py:86-91, loss/breast_clip.py:46-100]
 // These are tiny (b x 512 x W*b); a simple LDS-tiled VALU kernel with arbitrary strides serves every layout.
-#include "common.cuh"
+#include "common_hip.h"
 #include "../../include/mammoclip_hip.h"
 
 namespace {
@@ -92,9 +92,11 @@ __global__ void l2norm_bwd_k(const float* __restrict__ dy, const float* __restri
         dx[(long long)row * d + i] = (dy[(long long)row * d + i] - y[(long long)row * d + i] * s) * inv;
 }
 
-// one wave per row: lse, loss contribution, dlogits in place
-__global__ void ce_fwd_bwd_k(float* __restrict__ logits, int rows, int n, int label_offset, float w, float eps,
-                             float* __restrict__ loss_out) {
+// one wave per row: lse, per-row loss contribution (into row_loss), dlogits in place.
+// labels: optional int64 class index per row (the `labels` the loss was called with, loss/breast_clip.py:43-44);
+// the target of row r is labels[r] + label_offset (null: r + label_offset).
+__global__ void ce_fwd_bwd_k(float* __restrict__ logits, int rows, int n, const long long* __restrict__ labels,
+                             int label_offset, float w, float eps, float* __restrict__ row_loss) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= rows) return;
     float* lr = logits + (long long)row * n;
@@ -106,16 +108,29 @@ __global__ void ce_fwd_bwd_k(float* __restrict__ logits, int rows, int n, int la
     s = wave_sum(s);
     sx = wave_sum(sx);
     const float lse = mx + __logf(s);
-    const int label = row + label_offset;
+    const int label = (labels ? (int)labels[row] : row) + label_offset;
     const float scale = w / (float)rows;
     // label smoothing eps: target = (1-eps) * onehot + eps / n   (torch F.cross_entropy semantics)
-    if (lane == 0) atomicAdd(loss_out, ((1.f - eps) * (lse - lr[label]) + eps * (lse - sx / (float)n)) * scale);
+    if (lane == 0) row_loss[row] = ((1.f - eps) * (lse - lr[label]) + eps * (lse - sx / (float)n)) * scale;
     const float inv = 1.f / s;
     const float un = eps / (float)n;
     for (int i = lane; i < n; i += 64) {
         float pr = __expf(lr[i] - mx) * inv;
         lr[i] = (pr - (i == label ? 1.f - eps : 0.f) - un) * scale;
     }
+}
+// loss_out[0] += sum_r row_loss[r], in a fixed order (bit-reproducible: no float atomics)
+__global__ void ce_sum_rows_k(const float* __restrict__ row_loss, int rows, float* __restrict__ loss_out) {
+    __shared__ float red[256];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < rows; i += 256) s += row_loss[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) loss_out[0] += red[0];
 }
 
 }  // namespace
@@ -172,12 +187,14 @@ extern "C" int mc_l2norm_bwd(const float* dy, const float* y, const float* norm,
     MC_LAUNCH_CHECK();
     return MC_OK;
 }
-extern "C" int mc_ce_fwd_bwd(float* logits, int rows, int n, int label_offset, float w, float smoothing, float* loss_out,
-                             void* stream) {
-    MC_CHECK(logits && loss_out && rows > 0 && n > 0, "ce: bad args");
-    MC_CHECK(label_offset >= 0 && label_offset + rows <= n, "ce: labels out of range");
-    hipLaunchKernelGGL(ce_fwd_bwd_k, dim3(mc_div_up(rows, 4)), dim3(256), 0, (hipStream_t)stream, logits, rows, n,
-                       label_offset, w, smoothing, loss_out);
+extern "C" int mc_ce_fwd_bwd(float* logits, int rows, int n, const long long* labels, int label_offset, float w,
+                             float smoothing, float* loss_out, float* row_ws, void* stream) {
+    MC_CHECK(logits && loss_out && row_ws && rows > 0 && n > 0, "ce: bad args");
+    MC_CHECK(label_offset >= 0 && (labels || label_offset + rows <= n), "ce: labels out of range");
+    hipLaunchKernelGGL(ce_fwd_bwd_k, dim3(mc_div_up(rows, 4)), dim3(256), 0, (hipStream_t)stream, logits, rows, n, labels,
+                       label_offset, w, smoothing, row_ws);
+    MC_LAUNCH_CHECK();
+    hipLaunchKernelGGL(ce_sum_rows_k, dim3(1), dim3(256), 0, (hipStream_t)stream, row_ws, rows, loss_out);
     MC_LAUNCH_CHECK();
     return MC_OK;
 }

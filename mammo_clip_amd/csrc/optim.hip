@@ -4,7 +4,7 @@
 // B5 + BERT model; a parameter that is consumed as a bf16 matrix gets its bf16 image rewritten by the same pass (+2 B)
 // instead of by a cast kernel of its own in the next forward.  Up to PACK tensors go into one launch (pointers travel as kernel arguments, no device
 // table to keep in sync); a workgroup owns one CHUNK of one tensor, found by a scan over the pack's chunk prefix.
-#include "common.cuh"
+#include "common_hip.h"
 #include "../../include/mammoclip_hip.h"
 
 namespace {

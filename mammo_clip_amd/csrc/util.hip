@@ -1,5 +1,5 @@
 // error state, casts, transposes, stem im2col / weight prep, fp32 dropout, bf16 column sums.
-#include "common.cuh"
+#include "common_hip.h"
 #include "../../include/mammoclip_hip.h"
 #include <string.h>
 

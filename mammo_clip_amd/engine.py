@@ -55,7 +55,7 @@ class GradBuckets:
         self.seen = set()
 
     def _hook(self, p):
-        if not self.enabled:
+        if not self.enabled or not self.pending:        # not armed (backward outside Trainer.step): plain autograd
             return
         idx, v = self.bucket_of[p]
         flat = self.buckets[idx][0]
@@ -89,6 +89,7 @@ class GradBuckets:
             h.wait()
             if flat is not None:
                 flat.div_(dist.get_world_size())
+        self.pending = []
 
     def finish(self):
         """Parameters that got no gradient (e.g. the unused BERT pooler) keep grad None, like under the reference's
@@ -96,13 +97,19 @@ class GradBuckets:
         for idx, (flat, plist, views) in enumerate(self.buckets):
             if self.pending[idx] > 0:
                 for p, v in zip(plist, views):
-                    if p not in self.seen:
+                    if p in self.seen:
+                        continue
+                    if p.grad is None:
                         v.zero_()
+                    else:                   # gradient from an earlier backward of this step (micro-batched step: e.g.
+                        v.copy_(p.grad)     # logit_scale, whose gradient comes from the loss backward alone)
+                        p.grad = v
                 self._reduce(flat)
         for h, flat in self.handles:
             h.wait()
             if flat is not None:
                 flat.div_(dist.get_world_size())
+        self.pending = []
 
 
 class Trainer:
@@ -111,6 +118,10 @@ class Trainer:
         self.device = device
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self.buckets = GradBuckets(list(model.parameters()), bucket_mb << 20) if self.world > 1 else None
+        if self.world > 1:
+            # identical replicas: rank 0's parameters and buffers everywhere, like torch DDP does at construction
+            # [ref: trainer_ddp.py:134] -- only gradients are averaged afterwards
+            sync_parameters_and_buffers(model)
 
     def step(self, batch: Dict, micro_batches: int = 1) -> Dict[str, torch.Tensor]:
         if micro_batches > 1:
@@ -162,7 +173,8 @@ def _step_micro(self, batch: Dict, k: int) -> Dict[str, torch.Tensor]:
       1. forward every micro-batch without a graph, keep only the embeddings (and the dropout seed counters);
       2. loss over the concatenated embeddings -> d loss / d embeddings, d loss / d logit_scale;
       3. re-run each micro-batch with the SAME seeds (counter-based masks: bit-identical forward) and with the
-         BatchNorm running-stat update switched off, and back-propagate its slice of the embedding gradients.
+         BatchNorm running-stat update switched off, and back-propagate its slice of the embedding gradients; the
+         gradient buckets are all-reduced from the hooks of the LAST micro-batch's backward (overlapped with it).
     Cost: one extra forward per step; activation memory: one micro-batch."""
     model = self.model
     model.train()
@@ -191,6 +203,10 @@ def _step_micro(self, batch: Dict, k: int) -> Dict[str, torch.Tensor]:
     try:
         for i, mb in enumerate(mbs):
             irng.calls, trng._calls = counters[i]
+            if self.buckets is not None and i == len(mbs) - 1:
+                # gradients become final during the LAST micro-batch's backward: each bucket is all-reduced as soon as
+                # its parameters have accumulated their last contribution, overlapped with the rest of that backward
+                self.buckets.enabled = True
             out = model(mb, self.device)
             ks = list(leaf)
             torch.autograd.backward([out[kk] for kk in ks], [leaf[kk].grad[i * b:(i + 1) * b] for kk in ks])
@@ -201,7 +217,7 @@ def _step_micro(self, batch: Dict, k: int) -> Dict[str, torch.Tensor]:
         if self.buckets is not None:
             self.buckets.enabled = True
     if self.buckets is not None:
-        self.buckets.reduce_all()
+        self.buckets.finish()
     self.optimizer.step()
     if self.scheduler is not None:
         self.scheduler.step()
@@ -226,6 +242,31 @@ def init_distributed():
 
 
 @torch.no_grad()
+def _broadcast_flat(tensors, src: int):
+    """one broadcast per dtype (few large collectives, not one per tensor)"""
+    by_dtype = {}
+    for t in tensors:
+        by_dtype.setdefault(t.dtype, []).append(t)
+    for ts in by_dtype.values():
+        flat = torch.cat([t.reshape(-1) for t in ts])
+        dist.broadcast(flat, src)
+        off = 0
+        for t in ts:
+            t.copy_(flat[off:off + t.numel()].view_as(t))
+            off += t.numel()
+
+
+@torch.no_grad()
+def sync_parameters_and_buffers(model, src: int = 0):
+    """rank ``src``'s parameters AND buffers on every rank (what torch DDP does when it wraps a module)"""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return
+    params = list(model.parameters())
+    _broadcast_flat([p.data for p in params] + list(model.buffers()), src)
+    torch.autograd.graph.increment_version(params)      # cached bf16 weight images key on the version counter
+
+
+@torch.no_grad()
 def sync_buffers(model, src: int = 0):
     """BatchNorm running statistics (and every other buffer) of rank ``src`` on all ranks, like the buffer broadcast
     torch DDP performs at the start of each forward in the reference [ref: trainer_ddp.py:134, DDP default
@@ -233,16 +274,7 @@ def sync_buffers(model, src: int = 0):
     are READ: evaluation (``validate`` calls it) and checkpoints (rank 0 saves).  One collective per dtype."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return
-    by_dtype = {}
-    for b in model.buffers():
-        by_dtype.setdefault(b.dtype, []).append(b)
-    for bufs in by_dtype.values():
-        flat = torch.cat([b.reshape(-1) for b in bufs])
-        dist.broadcast(flat, src)
-        off = 0
-        for b in bufs:
-            b.copy_(flat[off:off + b.numel()].view_as(b))
-            off += b.numel()
+    _broadcast_flat(list(model.buffers()), src)
 
 
 @torch.no_grad()

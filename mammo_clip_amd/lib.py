@@ -137,7 +137,7 @@ _SIGS = {
     "mc_scale_f32": ([P, P, F, P, LL, P], I),
     "mc_l2norm_fwd": ([P, I, I, P, P, P], I),
     "mc_l2norm_bwd": ([P, P, P, I, I, P, P], I),
-    "mc_ce_fwd_bwd": ([P, I, I, I, F, F, P, P], I),
+    "mc_ce_fwd_bwd": ([P, I, I, P, I, F, F, P, P, P], I),
 }
 
 EXPORTS = sorted(list(_SIGS.keys()) + ["mc_last_error"])

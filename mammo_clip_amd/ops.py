@@ -676,6 +676,8 @@ def l2norm_bwd(dy, y, norm):
     return dx
 
 
-def ce_fwd_bwd(logits, label_offset, w, loss_out, smoothing=0.0):
+def ce_fwd_bwd(logits, label_offset, w, loss_out, smoothing=0.0, labels=None):
     rows, n = logits.shape
-    L.call("mc_ce_fwd_bwd", _p(logits), rows, n, int(label_offset), float(w), float(smoothing), _p(loss_out), _st())
+    row_ws = empty((rows,), torch.float32, logits)
+    L.call("mc_ce_fwd_bwd", _p(logits), rows, n, _p(labels), int(label_offset), float(w), float(smoothing), _p(loss_out),
+           _p(row_ws), _st())

@@ -4,7 +4,7 @@ TEST INFRASTRUCTURE ONLY.  This package is a plain torch-fp32 (CPU) restatement 
 reference's algorithm for the one path this repo accelerates (EfficientNet-B2/B5 image encoder,
 BioClinicalBERT text encoder, linear projection heads, all-gather + symmetric InfoNCE).  It is the
 *checker*: only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may
-import it.  Nothing under ``mammo-clip_amd/`` (the product) imports it, and the product has no CPU
+import it.  Nothing under ``mammo_clip_amd/`` (the product) imports it, and the product has no CPU
 fallback: it raises if the HIP library is missing.
 
 Parity pin: every function here is checked against golden vectors produced by importing the

@@ -1,6 +1,6 @@
 // Standalone micro-benchmark / phase profiler for the tiled GEMM (developer tool, not part of the library).
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 [-DGEMM_PROF] scripts/gemmbench.hip -o scripts/gemmbench.bin
-#include "../mammo-clip_amd/csrc/gemm.hip"
+#include "../mammo_clip_amd/csrc/gemm.hip"
 #include <cstdio>
 #include <cstdlib>
 #include <vector>

@@ -182,6 +182,34 @@ def test_global_env_and_scheduler():
     assert all(abs(a - b) < 1e-9 for a, b in zip(lrs, ref))
 
 
+def test_build_scheduler_matches_reference_config_shapes():
+    """[ref: scheduler/__init__.py:8-16 + trainer_ddp.py:146-153]: resolved step configs, epoch configs with an int
+    warm-up (epochs) and with a float warm-up (fraction of the total steps, e.g. cosine_epoch30_warmup3.yaml's 0.1),
+    and the 'constant' schedule = torch's ConstantLR with the config passed through."""
+    from mammo_clip_amd.breastclip.scheduler import build_scheduler
+
+    def opt():
+        return torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=1.0)
+    s1 = build_scheduler(opt(), {"name": "cosine", "config": {"total_steps": 100, "warmup_steps": 10}})
+    assert (s1.tsteps, s1.wsteps) == (100, 10)
+    s2 = build_scheduler(opt(), {"name": "cosine", "config": {"total_epochs": 30, "warmup_epochs": 3}}, steps_per_epoch=500)
+    assert (s2.tsteps, s2.wsteps) == (15000, 1500)
+    s3 = build_scheduler(opt(), {"name": "cosine", "config": {"total_epochs": 30, "warmup_epochs": 0.1}}, steps_per_epoch=500)
+    assert (s3.tsteps, s3.wsteps) == (15000, 1500)            # 0.1 of the total, NOT 0.1 * steps_per_epoch
+    s4 = build_scheduler(opt(), {"name": "cosine", "config": {"total_steps": 7, "warmup_steps": 2}}, total_steps=50)
+    assert (s4.tsteps, s4.wsteps) == (50, 2)
+    o = opt()
+    s5 = build_scheduler(o, {"name": "constant", "config": {"factor": 0.5, "total_iters": 2}})
+    assert isinstance(s5, torch.optim.lr_scheduler.ConstantLR)
+    lrs = []
+    for _ in range(4):
+        lrs.append(o.param_groups[0]["lr"]); o.step(); s5.step()
+    assert lrs == [0.5, 0.5, 1.0, 1.0]
+    assert isinstance(build_scheduler(opt(), {"name": "constant", "config": {}}), torch.optim.lr_scheduler.ConstantLR)
+    with pytest.raises(NotImplementedError):
+        build_scheduler(opt(), {"name": "step", "config": {}})
+
+
 class _ToyModel(torch.nn.Module):
     def forward(self, batch, device=None):
         assert not self.training and not torch.is_grad_enabled()
@@ -267,6 +295,33 @@ def _w2_worker(rank, port, ret):
     gb2.reduce_all()
     ok = ok and all(torch.allclose(p.grad, torch.full((3,), 2 * 1.5 * (i + 1))) for i, p in enumerate(params2[:3]))
     ok = ok and params2[3].grad is None
+    # ... and the overlapped form the micro-batched step uses: hooks off for the first pass, ON for the last one (each
+    # bucket is reduced from the hook that completes it), a parameter whose gradient only exists from the first pass
+    # (like logit_scale, which only the loss backward touches) is picked up by finish()
+    params3 = [torch.nn.Parameter(torch.full((3,), float(i))) for i in range(5)]
+    gb3 = GradBuckets(params3, bucket_bytes=16)
+    gb3.begin()
+    gb3.enabled = False
+    for i, p in enumerate(params3[:4]):
+        (p.sum() * (rank + 1) * (i + 1)).backward()
+    gb3.enabled = True
+    for i, p in enumerate(params3[:3]):
+        (p.sum() * (rank + 1) * (i + 1)).backward()
+    gb3.finish()
+    ok = ok and all(torch.allclose(p.grad, torch.full((3,), 2 * 1.5 * (i + 1))) for i, p in enumerate(params3[:3]))
+    ok = ok and torch.allclose(params3[3].grad, torch.full((3,), 1.5 * 4)) and params3[4].grad is None
+    # a backward outside begin()/finish() (buckets not armed) is plain autograd
+    (params3[0].sum() * 2.0).backward()
+    # Trainer construction puts rank 0's parameters and buffers on every rank (DDP's construction-time broadcast)
+    from mammo_clip_amd.engine import Trainer
+    torch.manual_seed(100 + rank)
+    toy = torch.nn.Sequential(torch.nn.Linear(4, 3), torch.nn.BatchNorm1d(3))
+    toy[1].running_mean.fill_(float(rank))
+    Trainer(toy, None, None)
+    torch.manual_seed(100)
+    ref_toy = torch.nn.Sequential(torch.nn.Linear(4, 3), torch.nn.BatchNorm1d(3))
+    ok = ok and all(torch.equal(a, b) for a, b in zip(toy.parameters(), ref_toy.parameters()))
+    ok = ok and float(toy[1].running_mean[0]) == 0.0
     # buffers of rank 0 everywhere (DDP broadcast_buffers semantics), mixed dtypes
     from mammo_clip_amd.engine import sync_buffers
     bn = torch.nn.BatchNorm2d(3)
