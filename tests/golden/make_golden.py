@@ -15,6 +15,11 @@ Fixtures (checked by tests/test_oracle_golden.py and by the GPU parity tests):
   loss_kats.npz     both loss classes, W in {1,2,4} ranks over gloo (losses + grads)
   e2e_b2_cfg1.npz   BASELINE config #1 (B2 + BERT-base, b=4, 224^2, T=64): embeddings, losses, grads
   e2e_b5_small.npz  B5 + BERT-base, b=2, 160x96, T=32: same (pins the B5 table end to end)
+  e2e_b2_bn8k.npz   B2 + BERT-base, b=8, 456^2, T=64: train-mode fixture in which every BatchNorm sees >= 1800 samples
+                    per channel (the bf16 train-mode tolerance is stated on this one)
+  input_pipeline.npz  the reference's ImageTextDataset.__getitem__ + collate + trainer permute driven on generated PNGs:
+                    raw uint8 pixels in, the normalised float32 batch tensor out (pins row N4)
+  ref_cpu_timing.json  the reference's own config-#1 training step timed on this container's cores
 """
 import json
 import os
@@ -433,9 +438,116 @@ def gen_traj(tag="traj_b5_small", enc_name="tf_efficientnet_b5_ns-detect", arch_
     np.savez_compressed(os.path.join(HERE, f"{tag}.npz"), **store)
 
 
+def gen_input_pipeline():
+    """Row N4: drive the reference's own ``ImageTextDataset.__getitem__`` [ref: data/datasets/imagetext.py:67-212] and
+    ``collate_fn`` (:214-234) on generated PNG files, then the trainer's permute [ref: trainer_ddp.py:288-291]; store
+    the raw uint8 pixels and the float32 batch tensor the model receives.  ``__init__`` opens a hard-coded absolute
+    path of the authors' cluster (:54-57), so the object is allocated without it and given the attributes
+    ``__getitem__`` reads; no transform (``tfms = None``, the 'valid' split of the shipped configs has none)."""
+    import tempfile
+    import pandas as pd
+    from pathlib import Path
+    from PIL import Image
+    from breastclip.data.datasets.imagetext import ImageTextDataset
+    rng = np.random.default_rng(1234)
+    H, W = 76, 48
+    mean, std = 0.3089279, 0.25053555408335154            # configs/pre_train_b5_clip.yaml:23-24
+    cases = {"full_range": (0, 256), "narrow": (17, 201), "dark": (3, 40)}
+    store = {"meta": np.array([H, W]), "mean_std": np.array([mean, std], dtype=np.float64)}
+    with tempfile.TemporaryDirectory() as td:
+        rows = []
+        for pid, (name, (lo, hi)) in enumerate(cases.items()):
+            d = Path(td) / "img" / str(pid)
+            d.mkdir(parents=True)
+            files = []
+            for v in range(2):
+                g = rng.integers(lo, hi, size=(H, W), dtype=np.uint8)
+                Image.fromarray(g, mode="L").save(d / f"v{v}.png")               # 8-bit grey; the dataset opens it as RGB
+                files.append(f"v{v}.png")
+            rows.append({"patient_id": pid, "image": str(files), "text": str(["no mass .", "benign calcification ."])})
+        ds = object.__new__(ImageTextDataset)
+        ds.df = pd.DataFrame(rows)
+        ds.root_dir, ds.img_dir, ds.dataset = Path(td), "img", "upmc"
+        ds.split, ds.tfms, ds.mean, ds.std = "valid", None, mean, std
+        ds.image_encoder_type = "tf_efficientnet_b5_ns-detect"
+        ds.image_aug_other_image = ds.image_view_aug = True
+        ds.has_backtranslated = False
+        ds.text_max_length = 8
+        ds.tokenizer = lambda texts, **kw: {"input_ids": torch.zeros(len(texts), kw["max_length"], dtype=torch.long)}
+        import random
+        random.seed(0); np.random.seed(0)
+        items = [ds[i] for i in range(len(rows))]
+        batch = ds.collate_fn(items)
+        assert batch["images"].shape == (len(rows), 1, H, W, 3) and batch["images"].dtype == torch.float32
+        for key in ("images", "image_views"):
+            x = batch[key].squeeze(1).permute(0, 3, 1, 2)                        # trainer_ddp.py:288-291
+            store["out/" + key] = np_(x.contiguous())
+        raw = np.stack([np.stack([np.array(Image.open(Path(td) / "img" / str(pid) / f"v{v}.png").convert("RGB"))
+                                  for pid in range(len(rows))]) for v in range(2)])   # [2 views, b, H, W, 3] uint8
+        store["raw/images"], store["raw/image_views"] = raw[0], raw[1]
+    np.savez_compressed(os.path.join(HERE, "input_pipeline.npz"), **store)
+    print("input_pipeline.npz", {k: v.shape for k, v in store.items()})
+
+
+def time_reference_cfg1(warmup=3, reps=10):
+    """the REFERENCE's own training step (its model, loss, AdamW, scheduler, call order of
+    trainer_ddp.py:279-308) at config #1 (B2 + BERT-base, b=4, 224^2, T=64, fp32 CPU) on this container's cores:
+    >= 3 warm-up steps, median of >= 10.  Dropout / drop-connect stay ON (it is a timing run)."""
+    import time
+    from breastclip.model import build_model
+    from breastclip.loss import build_loss
+    from breastclip.optimizer import build_optimizer
+    from breastclip.scheduler import build_scheduler
+    from oracle import weights as ow
+    model_cfg = {"name": "clip_custom", "temperature": 0.07,
+                 "image_encoder": {"source": "cnn", "name": "tf_efficientnetv2-detect", "pretrained": True, "model_type": "cnn"},
+                 "text_encoder": {"source": "huggingface", "name": "emilyalsentzer/Bio_ClinicalBERT",
+                                  "pretrained": False, "gradient_checkpointing": False, "pooling": "eos",
+                                  "cache_dir": "/tmp/none", "trust_remote_code": True, "mlm_head": True},
+                 "projection_head": {"name": "linear", "dropout": 0.1, "proj_dim": 512}}
+    loss_cfg = {"breast_clip": dict(label_smoothing=0.0, i2i_weight=1.0, t2t_weight=0.5, loss_ratio=1.0)}
+    torch.manual_seed(10)
+    model = build_model(model_cfg, loss_cfg, types.SimpleNamespace(vocab_size=28996))
+    lf = build_loss(loss_cfg)
+    opt = build_optimizer(model, {"name": "adamw", "config": {"lr": 5e-5, "weight_decay": 1e-4}})
+    sch = build_scheduler(opt, {"name": "cosine", "config": {"total_steps": 10000, "warmup_steps": 100}})
+    b, H, W, T = 4, 224, 224, 64
+    batch = ow.synth_batch(b, H, W, T, seed=10)
+
+    class BE(dict):
+        def to(self, device):
+            return self
+
+    model.train()
+    times = []
+    for it in range(warmup + reps):
+        t0 = time.perf_counter()
+        opt.zero_grad(set_to_none=True)
+        bt = {"images": batch["images"], "image_views": batch["image_views"],
+              "text_tokens": BE(batch["text_tokens"]), "text_tokens2": BE(batch["text_tokens2"])}
+        out = model(bt, torch.device("cpu"))
+        ld = lf(**out, is_train=True)
+        ld["total"].backward()
+        opt.step()
+        sch.step()
+        dt = time.perf_counter() - t0
+        if it >= warmup:
+            times.append(dt)
+    med = float(np.median(times))
+    res = {"what": "reference breastclip training step (fwd + breast_clip loss + bwd + AdamW + scheduler), its own code, CPU fp32",
+           "config": "BASELINE configs[0]: EfficientNet-B2 + BERT-base(BioClinicalBERT shape), batch 4, 224x224, 64 tokens, "
+                     "2 views + 2 texts per pair",
+           "warmup_steps": warmup, "timed_steps": reps, "median_s_per_step": round(med, 4),
+           "min_s_per_step": round(float(min(times)), 4), "max_s_per_step": round(float(max(times)), 4),
+           "pairs_per_s": round(b / med, 4), "threads": torch.get_num_threads(), "host_cores": os.cpu_count(),
+           "torch": torch.__version__, "where": "build container (no GPU); the reference never runs on the GPU box"}
+    json.dump(res, open(os.path.join(HERE, "ref_cpu_timing.json"), "w"), indent=1)
+    print("ref_cpu_timing.json", res)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["arch", "mbconv", "bert", "loss", "e2e_b2", "e2e_b5", "traj"]
+    which = sys.argv[1:] or ["arch", "mbconv", "bert", "loss", "e2e_b2", "e2e_b5", "traj", "e2e_bn8k", "inputs", "timing"]
     import_reference()
     if "arch" in which:
         gen_arch_tables()
@@ -451,3 +563,9 @@ if __name__ == "__main__":
         gen_traj()
     if "e2e_b5" in which:
         gen_e2e("e2e_b5_small", "tf_efficientnet_b5_ns-detect", "efficientnet-b5", 2, 160, 96, 32)
+    if "e2e_bn8k" in which:
+        gen_e2e("e2e_b2_bn8k", "tf_efficientnetv2-detect", "efficientnet-b2", 8, 456, 456, 64)
+    if "inputs" in which:
+        gen_input_pipeline()
+    if "timing" in which:
+        time_reference_cfg1()

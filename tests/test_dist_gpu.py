@@ -88,9 +88,15 @@ WORKER2 = r'''
 import os, sys, types
 sys.path.insert(0, sys.argv[1])
 rank, port, outdir = int(sys.argv[2]), sys.argv[3], sys.argv[4]
+backend = sys.argv[5] if len(sys.argv) > 5 else "gloo"          # "nccl" = RCCL, one GPU per rank
+micro = int(sys.argv[6]) if len(sys.argv) > 6 else 1
 import torch, torch.distributed as dist
-dev = torch.device("cuda:0"); torch.cuda.set_device(dev)
-dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % port, rank=rank, world_size=2)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+dev = torch.device("cuda:%d" % (rank if backend == "nccl" else 0)); torch.cuda.set_device(dev)
+if backend == "nccl":
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%s" % port, rank=rank, world_size=2, device_id=dev)
+else:
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % port, rank=rank, world_size=2)
 import mammo_clip_amd
 from mammo_clip_amd import engine
 from mammo_clip_amd.breastclip import util as U
@@ -107,17 +113,27 @@ U.GlobalEnv.reset()
 assert U.GlobalEnv.get().world_size == 2
 torch.manual_seed(0)
 model = build_model(cfg, loss_cfg, types.SimpleNamespace(vocab_size=28996)).to(dev)
-batch = ow.synth_batch(4, 64, 64, 16, seed=5)
-lo, hi = rank * 2, rank * 2 + 2
+per = 2 * micro                                     # pairs per rank
+batch = ow.synth_batch(2 * per, 64, 64, 16, seed=5)
+lo, hi = rank * per, rank * per + per
 bt = {"images": batch["images"][lo:hi].to(dev), "image_views": batch["image_views"][lo:hi].to(dev),
       "text_tokens": {k: v[lo:hi].to(dev) for k, v in batch["text_tokens"].items()},
       "text_tokens2": {k: v[lo:hi].to(dev) for k, v in batch["text_tokens2"].items()}}
 # the second rank replays the seeds the second MICRO-batch of the single-process run gets (2 encoder calls each)
+# (with micro > 1 the micro-batched step forwards every micro-batch twice: first pass + replay, so the single-process
+# reference below cannot share seeds -- those runs switch dropout / drop-connect off instead)
 model.image_encoder.rng.calls = 2 * rank
 model.text_encoder.text_encoder._calls = 2 * rank
+if micro > 1:
+    enc = model.image_encoder
+    enc._dropout_p = 0.0
+    enc._global_params = enc._global_params._replace(drop_connect_rate=0.0)
+    for lyr in model.text_encoder.text_encoder.encoder.layer:
+        lyr.p_attn = lyr.p_hidden = 0.0
+    model.text_encoder.text_encoder.config.hidden_dropout_prob = 0.0
 tr = engine.Trainer(model, build_loss(loss_cfg), torch.optim.SGD(model.parameters(), lr=0.0), None, dev, bucket_mb=16)
-assert tr.buckets is not None
-out = tr.step(bt)
+assert tr.buckets is not None and len(tr.buckets.buckets) > 3
+out = tr.step(bt, micro_batches=micro)
 torch.save({"loss": float(out["total"]), "grads": {n: p.grad.detach().cpu() for n, p in model.named_parameters() if p.grad is not None}},
            os.path.join(outdir, "r%d.pt" % rank))
 dist.destroy_process_group()
@@ -176,3 +192,88 @@ def test_two_rank_step_equals_micro_batched_single_process(tmp_path):
         e = float((g - r0["grads"][n]).abs().max() / (g.abs().max() + 1e-12))
         worst = max(worst, e)
         assert e < 5e-3, (n, e)
+
+
+def _single_process_reference(n_pairs, k, stochastic_off):
+    import torch
+    import types
+    sys.path.insert(0, ROOT)
+    import mammo_clip_amd  # noqa: F401
+    from mammo_clip_amd import engine
+    from mammo_clip_amd.breastclip import util as U
+    from mammo_clip_amd.breastclip.loss import build_loss
+    from mammo_clip_amd.breastclip.model import build_model
+    from oracle import weights as ow
+    dev = torch.device("cuda:0")
+    cfg = {"name": "clip_custom", "temperature": 0.07,
+           "image_encoder": {"source": "cnn", "name": "tf_efficientnetv2-detect", "pretrained": False, "model_type": "cnn"},
+           "text_encoder": {"source": "huggingface", "name": "emilyalsentzer/Bio_ClinicalBERT", "pretrained": False,
+                            "gradient_checkpointing": False, "pooling": "eos", "cache_dir": "", "trust_remote_code": True},
+           "projection_head": {"name": "linear", "dropout": 0.1, "proj_dim": 512}}
+    loss_cfg = {"breast_clip": dict(label_smoothing=0.0, i2i_weight=1.0, t2t_weight=0.5, loss_ratio=1.0)}
+    U.GlobalEnv.reset()
+    torch.manual_seed(0)
+    model = build_model(cfg, loss_cfg, types.SimpleNamespace(vocab_size=28996)).to(dev)
+    if stochastic_off:
+        enc = model.image_encoder
+        enc._dropout_p = 0.0
+        enc._global_params = enc._global_params._replace(drop_connect_rate=0.0)
+        for lyr in model.text_encoder.text_encoder.encoder.layer:
+            lyr.p_attn = lyr.p_hidden = 0.0
+        model.text_encoder.text_encoder.config.hidden_dropout_prob = 0.0
+    batch = ow.synth_batch(n_pairs, 64, 64, 16, seed=5)
+    bt = {"images": batch["images"].to(dev), "image_views": batch["image_views"].to(dev),
+          "text_tokens": {kk: v.to(dev) for kk, v in batch["text_tokens"].items()},
+          "text_tokens2": {kk: v.to(dev) for kk, v in batch["text_tokens2"].items()}}
+    tr = engine.Trainer(model, build_loss(loss_cfg), torch.optim.SGD(model.parameters(), lr=0.0), None, dev)
+    out = tr.step(bt, micro_batches=k)
+    return float(out["total"]), {n: p.grad.detach().cpu() for n, p in model.named_parameters() if p.grad is not None}
+
+
+def _run_two_ranks(tmp_path, port, backend, micro):
+    script = tmp_path / "w2.py"
+    script.write_text(WORKER2)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(r), str(port), str(tmp_path), backend, str(micro)],
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env) for r in range(2)]
+    outs = [p.communicate(timeout=900) for p in procs]
+    assert all(p.returncode == 0 and "DP-OK" in o[0] for p, o in zip(procs, outs)), [o[1][-3000:] for o in outs]
+    import torch
+    return [torch.load(tmp_path / ("r%d.pt" % r)) for r in range(2)]
+
+
+def _check_against_reference(r0, r1, ref_loss, ref_g):
+    import torch
+    for n in r0["grads"]:
+        assert torch.equal(r0["grads"][n], r1["grads"][n]), n            # all-reduced: identical on both ranks
+    assert abs(ref_loss - 0.5 * (r0["loss"] + r1["loss"])) < 1e-5
+    for n, g in ref_g.items():
+        e = float((g - r0["grads"][n]).abs().max() / (g.abs().max() + 1e-12))
+        assert e < 5e-3, (n, e)
+
+
+@pytest.mark.gpu
+def test_two_rank_micro_batched_step_overlapped_buckets(tmp_path):
+    """The cfg4 mode: every rank runs a MICRO-BATCHED step (k = 2) and the gradient buckets are all-reduced from the
+    hooks of the last micro-batch's backward (engine._step_micro).  2 ranks on the one GPU over gloo == the
+    single-process micro-batched step with k = 4 over the concatenated batch (dropout / drop-connect off)."""
+    r0, r1 = _run_two_ranks(tmp_path, 29881, "gloo", 2)
+    ref_loss, ref_g = _single_process_reference(8, 4, True)
+    _check_against_reference(r0, r1, ref_loss, ref_g)
+
+
+@pytest.mark.gpu
+def test_two_rank_step_over_rccl(tmp_path):
+    """RCCL with MORE than one rank (needs >= 2 GPUs; skipped on a 1-GPU box): fused embedding all-gather /
+    reduce-scatter [ref: util/dist_autograd.py:5-27] and bucketed gradient all-reduce(AVG) [ref: trainer_ddp.py:134] over
+    backend "nccl", one GPU per rank; plain step and micro-batched step, both against the single-process
+    micro-batched step over the concatenated batch."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs (RCCL refuses two ranks on one device)")
+    r0, r1 = _run_two_ranks(tmp_path, 29883, "nccl", 1)
+    ref_loss, ref_g = _single_process_reference(4, 2, False)
+    _check_against_reference(r0, r1, ref_loss, ref_g)
+    r0, r1 = _run_two_ranks(tmp_path, 29885, "nccl", 2)
+    ref_loss, ref_g = _single_process_reference(8, 4, True)
+    _check_against_reference(r0, r1, ref_loss, ref_g)

@@ -648,3 +648,28 @@ def test_raw_u8_input_pipeline_matches_host_normalisation():
         enc(x).square().sum().backward()
         ga.append(enc._conv_stem.weight.grad.clone())
     assert torch.equal(ga[0], ga[1])
+
+
+def test_raw_u8_input_pipeline_vs_reference_fixture():
+    """row N4 pinned by the REFERENCE: tests/golden/input_pipeline.npz holds raw uint8 pixels and the float32 batch
+    tensor the reference's ImageTextDataset.__getitem__ + collate_fn + trainer permute made of them [ref:
+    imagetext.py:67-234, trainer_ddp.py:288-291].  The stem's fused uint8 load must see exactly those values: its patch
+    matrix from the uint8 batch equals, bit for bit, the patch matrix built from the reference's float32 tensor."""
+    import numpy as np
+    import os
+    from mammo_clip_amd.breastclip.model.modules import load_image_encoder
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "input_pipeline.npz"))
+    mean, std = float(z["mean_std"][0]), float(z["mean_std"][1])
+    enc = load_image_encoder({"source": "cnn", "name": "tf_efficientnet_b5_ns-detect", "pretrained": False, "model_type": "cnn"}).to(DEV)
+    enc.eval()
+    l, r, t, bb = enc.stem_pad
+    for key in ("images", "image_views"):
+        ref = torch.from_numpy(z["out/" + key]).to(DEV)                       # [b,3,H,W] float32, the model's input
+        u8 = torch.from_numpy(z["raw/" + key]).to(DEV)                        # [b,H,W,3] uint8
+        b, _, H, W = ref.shape
+        oh, ow = (H + t + bb - 3) // 2 + 1, (W + l + r - 3) // 2 + 1
+        pa = ops.stem_im2col(ref, l, t, oh, ow)
+        pb = ops.stem_im2col(ops.RawImages(u8.unsqueeze(1).squeeze(1).permute(0, 3, 1, 2), mean, std), l, t, oh, ow)
+        assert torch.equal(pa, pb), key
+        with torch.no_grad():
+            assert torch.equal(enc(ref), enc(ops.RawImages(u8.permute(0, 3, 1, 2), mean, std)))

@@ -188,3 +188,20 @@ def test_e2e_train_b2_cfg1(golden_dir):
         if abs(got - ref) > 5e-3 * ref + 3e-6:   # bn2.bias grads are pure round-off (a train-mode BN follows)
             bad.append((str(n), got, float(ref)))
     assert not bad, bad[:5]
+
+
+def test_input_pipeline_vs_reference(golden_dir):
+    """Row N4 pin: raw uint8 pixels -> the float32 batch the reference's ImageTextDataset.__getitem__ + collate_fn +
+    trainer permute produced (make_golden.py gen_input_pipeline): the oracle's three-line restatement must reproduce
+    it bit for bit, in the [b,3,H,W] permuted layout the model receives."""
+    from oracle import inputs as oin
+    z = np.load(os.path.join(golden_dir, "input_pipeline.npz"))
+    mean, std = float(z["mean_std"][0]), float(z["mean_std"][1])
+    for key in ("images", "image_views"):
+        raw, ref = z["raw/" + key], z["out/" + key]
+        assert raw.dtype == np.uint8 and ref.dtype == np.float32 and ref.shape == (raw.shape[0], 3) + raw.shape[1:3]
+        got = np.stack([oin.normalize_u8(raw[i], mean, std) for i in range(raw.shape[0])]).transpose(0, 3, 1, 2)
+        assert np.array_equal(got, ref), float(np.abs(got - ref).max())
+        # each image is min-max scaled on its own: the per-image extremes map to (0 - mean)/std and (1 - mean)/std
+        for i in range(raw.shape[0]):
+            assert np.isclose(ref[i].min(), (0.0 - mean) / std) and np.isclose(ref[i].max(), (1.0 - mean) / std)
