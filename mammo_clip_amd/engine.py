@@ -113,9 +113,11 @@ class GradBuckets:
 
 
 class Trainer:
-    def __init__(self, model, loss_func, optimizer, scheduler=None, device=None, bucket_mb: int = 256):
+    def __init__(self, model, loss_func, optimizer, scheduler=None, device=None, bucket_mb: int = 256,
+                 overlap_micro: bool = True):
         self.model, self.loss_func, self.optimizer, self.scheduler = model, loss_func, optimizer, scheduler
         self.device = device
+        self.overlap_micro = overlap_micro      # micro-batched step: reduce buckets from the last backward's hooks
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self.buckets = GradBuckets(list(model.parameters()), bucket_mb << 20) if self.world > 1 else None
         if self.world > 1:
@@ -203,7 +205,7 @@ def _step_micro(self, batch: Dict, k: int) -> Dict[str, torch.Tensor]:
     try:
         for i, mb in enumerate(mbs):
             irng.calls, trng._calls = counters[i]
-            if self.buckets is not None and i == len(mbs) - 1:
+            if self.buckets is not None and self.overlap_micro and i == len(mbs) - 1:
                 # gradients become final during the LAST micro-batch's backward: each bucket is all-reduced as soon as
                 # its parameters have accumulated their last contribution, overlapped with the rest of that backward
                 self.buckets.enabled = True
@@ -217,7 +219,10 @@ def _step_micro(self, batch: Dict, k: int) -> Dict[str, torch.Tensor]:
         if self.buckets is not None:
             self.buckets.enabled = True
     if self.buckets is not None:
-        self.buckets.finish()
+        if self.overlap_micro:
+            self.buckets.finish()
+        else:
+            self.buckets.reduce_all()
     self.optimizer.step()
     if self.scheduler is not None:
         self.scheduler.step()
