@@ -816,8 +816,14 @@ static int pick_grid_m(const mc_gemm_args& p) {
     if (gm >= 16 && mtiles >= 2 * gm) gm &= ~7LL;
     return (int)gm;
 }
+extern "C" int mc_gemm256_eligible(const mc_gemm_args* a);      // gemm256.hip: 256 x 256 tiles for plain NT problems
+extern "C" int mc_gemm256_stat_rows(const mc_gemm_args* a);
+extern "C" int mc_gemm256_launch(const mc_gemm_args* a, void* stream);
+
 extern "C" int mc_gemm_stat_rows(const mc_gemm_args* a) {
-    // number of partial rows the launch will write ( = row-block workgroups x batch )
+    // number of partial rows the launch will write ( = row-block workgroups x batch ); `a` must be the arguments of the
+    // launch itself (the tile configuration depends on the whole problem)
+    if (a->K > 0 && mc_gemm256_eligible(a)) return mc_gemm256_stat_rows(a);
     mc_gemm_args q = *a;
     static float dummy;
     q.stat_partials = &dummy;                      // the row count of a launch WITH statistics
@@ -854,6 +860,7 @@ extern "C" int mc_gemm_bf16(const mc_gemm_args* a, void* stream) {
              "gemm: the per-batch weight gate is provided for NT, bf16 output, gate only");
     MC_CHECK(!p.R || (!p.c_f32 && p.ldr % 8 == 0), "gemm: residual needs bf16 output and ldr % 8 == 0");
     if (p.alpha == 0.f) p.alpha = 1.f;
+    if (mc_gemm256_eligible(&p)) return mc_gemm256_launch(&p, stream);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int grid_m = pick_grid_m(p);
     const int lay = p.a_kmajor ? 2 : (p.b_kmajor ? 1 : 0);

@@ -1,0 +1,439 @@
+// 256 x 256 x 64 bf16 MFMA GEMM for gfx950, plain NT operands, bf16 output:
+//     C[z][M,N] = alpha * A[z][M,K] . B[z][N,K]^T (+ bias[n]) (+ R[m,n]),   optional per-column sum / sum-of-squares partials
+// -- the late-stage 1x1 convolutions of EfficientNet (efficientnet_custom.py:104,122,283: forward and data gradient) and
+// the BERT linears (text_encoder.py:47-49 -> BertModel), i.e. every launch that used to land on the 128 x 128 tile kernel
+// of gemm.hip with plain k-contiguous operands.
+//
+// Structure (one workgroup of 8 waves per CU, all 160 KB of LDS):
+//   * waves 2 (M) x 4 (N), wave tile 128 x 64 = 8 x 4 fragments of v_mfma_f32_16x16x32_bf16 (128 accumulator registers)
+//   * a K tile (64 deep) of A and of B is staged as FOUR 16 KB half-tiles [A0 | A1 | B0 | B1]; half h of A holds, for
+//     BOTH wave rows, the 64 rows of C-quadrant row h (tile rows wm*128 + h*64 ..), half h of B the 32 columns of quadrant
+//     column h of all four wave columns: a whole half-tile is finished being read after one phase (see below)
+//   * direct-to-LDS DMA (global_load_lds_dwordx4, inline asm so the compiler keeps no book on it); the DMA writes
+//     lane-linearly, so the bank-conflict swizzle sits on the SOURCE address: slot s of LDS row r holds 16-byte chunk
+//     s ^ ((r >> 1) & 7) of that row's 128 bytes (conflict-free for ds_read_b128's 16-lane groups)
+//   * 4 phases per K tile, one C quadrant (16 MFMAs per wave) and ONE half-tile DMA issue per phase, two LDS stage
+//     buffers; the DMA stream runs 3 half-tiles ahead with a counted s_waitcnt vmcnt(6) once per K tile -- it never
+//     drains in the main loop -- and crosses output-tile boundaries (the K tiles of all output tiles of a workgroup form
+//     one flat stream):
+//         phase 1: read B0 (4) + A0 (8) fragments, stage A1(t+1);  quadrant (0,0)
+//         phase 2: read B1 (4),                    stage B0(t+2);  quadrant (0,1)
+//         phase 3: read A1 (8),                    stage A0(t+2);  quadrant (1,1)
+//         phase 4: (B0 still in registers)         stage B1(t+2);  vmcnt(6): all of tile t+1 has landed;  quadrant (1,0)
+//     Hazards: a half-tile is re-staged >= 2 phases after its last ds_read, or 1 phase after (B0) with the reads retired
+//     by an explicit lgkmcnt before the reading phase's first barrier; a staged buffer is read one phase after the wait
+//     that retires it.  The two wave rows run half a phase apart (one extra barrier for wave row 1 up front): while one
+//     wave of a SIMD issues MFMAs its partner reads LDS / issues DMA; s_setprio favours the MFMA wave.
+//   * epilogue through the 32 KB of LDS the stages leave free, in four 64-row slabs (16-byte coalesced stores, optional
+//     bias / residual / BatchNorm column statistics), while the DMAs of the next output tile are already in flight
+//   * persistent workgroups, XCD-aware work order: all column tiles of a row block run on ONE XCD at about the same
+//     time (workgroup id mod 8 = XCD), so the activation rows are fetched from HBM once and shared through that L2.
+#include "common_hip.h"
+#include "../../include/mammoclip_hip.h"
+
+namespace g256 {
+
+constexpr int BM = 256, BN = 256, BK = 64, NTHR = 512;
+constexpr int HALF_BYTES = 128 * 128;            // 128 LDS rows of 128 bytes (64 bf16)
+constexpr int OFF_A0 = 0, OFF_A1 = HALF_BYTES, OFF_B0 = 2 * HALF_BYTES, OFF_B1 = 3 * HALF_BYTES;
+constexpr int STAGE_BYTES = 4 * HALF_BYTES;      // 64 KB
+constexpr int EPI_OFF = 2 * STAGE_BYTES;         // 128 KB
+constexpr int EPI_BYTES = 64 * BN * 2;           // one slab: 64 rows x 256 columns bf16 = 32 KB
+constexpr int LDS_BYTES = EPI_OFF + EPI_BYTES;   // 160 KB
+
+__device__ __attribute__((aligned(16))) unsigned int g_zero16[4];
+
+__device__ __forceinline__ void glds16(const void* src, unsigned lds_dst_wave_base) {
+    const unsigned lds = __builtin_amdgcn_readfirstlane(lds_dst_wave_base);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(src), "s"(lds) : "memory");
+}
+
+// same with a wave-uniform 64-bit base in SGPRs and a 32-bit per-lane byte offset (no per-lane 64-bit address arithmetic)
+__device__ __forceinline__ void glds16_s(unsigned voff_bytes, const void* sbase, unsigned lds_dst_wave_base) {
+    const unsigned lds = __builtin_amdgcn_readfirstlane(lds_dst_wave_base);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff_bytes), "s"(lds), "s"(sbase) : "memory");
+}
+
+#define G256_BAR()                                   \
+    do {                                             \
+        asm volatile("" ::: "memory");               \
+        __builtin_amdgcn_s_barrier();                \
+        asm volatile("" ::: "memory");               \
+        __builtin_amdgcn_sched_barrier(0);           \
+    } while (0)
+
+// position of one K tile in the flat stream of a workgroup (all wave-uniform)
+struct TilePos {
+    const bf16_t* a;        // A + z*sA + m0*lda + k0
+    const bf16_t* b;        // B + z*sB + n0*ldb + k0
+    int mrem, nrem, krem;   // rows / columns / k left from (m0, n0, k0)
+    bool valid;
+};
+
+struct Work {               // per-workgroup work list (wave-uniform)
+    int xcd, slot, S, NTl, MT, ktn;
+    long long n_items;      // items of this workgroup
+};
+
+__device__ __forceinline__ void item_coords(const Work& w, long long it, int& z, int& mt, int& nt) {
+    const long long u = w.slot + it * w.S;
+    const long long ru = u / w.NTl;
+    nt = (int)(u - ru * w.NTl);
+    const long long unit = w.xcd + 8 * ru;
+    z = (int)(unit / w.MT);
+    mt = (int)(unit - (long long)z * w.MT);
+}
+
+template <bool STATS>
+__global__ __launch_bounds__(NTHR, 2) void gemm256_kernel(const mc_gemm_args p, const int MT, const int NTl, const int ktn) {
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[LDS_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+
+    Work wk;
+    wk.xcd = blockIdx.x & 7; wk.slot = blockIdx.x >> 3; wk.S = gridDim.x >> 3; wk.NTl = NTl; wk.MT = MT; wk.ktn = ktn;
+    {
+        const long long RB = (long long)p.batch * MT;                         // (batch, row block) units
+        const long long ux = RB > wk.xcd ? (RB - wk.xcd + 7) >> 3 : 0;        // units of this XCD
+        const long long nloc = ux * NTl;
+        wk.n_items = nloc > wk.slot ? (nloc - wk.slot + wk.S - 1) / wk.S : 0;
+    }
+    if (wk.n_items == 0) return;
+    const long long total = wk.n_items * ktn;                                 // K tiles in this workgroup's stream
+
+    auto make_pos = [&](long long it, int kt) __attribute__((always_inline)) {
+        TilePos q;
+        q.valid = it < wk.n_items;
+        int z = 0, mt = 0, nt = 0;
+        if (q.valid) item_coords(wk, it, z, mt, nt);
+        const long long m0 = (long long)mt * BM, n0 = (long long)nt * BN, k0 = (long long)kt * BK;
+        q.a = p.A + (long long)z * p.sA1 + m0 * p.lda + k0;
+        q.b = p.B + (long long)z * p.sB1 + n0 * p.ldb + k0;
+        const long long mr = p.M - m0, nr = p.N - n0, kr = p.K - k0;
+        q.mrem = mr > BM ? BM : (int)mr; q.nrem = nr > BN ? BN : (int)nr; q.krem = kr > BK ? BK : (int)kr;
+        return q;
+    };
+
+    // ---- DMA source geometry of this thread: 2 wave-instructions per half-tile, each fills 8 LDS rows (1 KiB)
+    //   instruction q of wave w fills LDS rows lr = (q*8 + w)*8 + (lane >> 3); lane & 7 = slot s, chunk c = s ^ ((lr >> 1) & 7)
+    //   A half h: LDS row lr <-> tile row (lr >> 6)*128 + h*64 + (lr & 63);  B half h: tile col (lr >> 5)*64 + h*32 + (lr & 31)
+    //   => instruction q / half h move the tile row by q*128 + h*64 (A) resp. the tile column by q*128 + h*32 (B): a
+    //   wave-uniform term that goes into the scalar base; the lane keeps ONE byte offset per operand
+    auto geo = [&](int q, int h, int& ra, int& rb, int& ck) __attribute__((always_inline)) {
+        const int g = q * 8 + wave;
+        const int lr = g * 8 + (lane >> 3);
+        ck = (lane & 7) ^ ((lr >> 1) & 7);
+        ra = (lr >> 6) * 128 + h * 64 + (lr & 63);
+        rb = (lr >> 5) * 64 + h * 32 + (lr & 31);
+    };
+    unsigned voffA, voffB;
+    {
+        int ra, rb, ck;
+        geo(0, 0, ra, rb, ck);
+        voffA = (unsigned)((ra * p.lda + ck * 8) * 2);
+        voffB = (unsigned)((rb * p.ldb + ck * 8) * 2);
+    }
+    const bf16_t* const zero = reinterpret_cast<const bf16_t*>(g_zero16);
+    typedef __attribute__((address_space(3))) unsigned int lds_u32_t;
+    const unsigned smem_lds = (unsigned)(uintptr_t)(lds_u32_t*)smem;
+
+    // stage half-tile `which` (0 = A0, 1 = A1, 2 = B0, 3 = B1) of the tile at `q` into stage buffer `buf`
+    auto stage = [&](const TilePos& q, int buf, auto which_c) __attribute__((always_inline)) {
+        constexpr int which = decltype(which_c)::value;
+        constexpr bool isA = which < 2;
+        constexpr int h = which & 1;
+        if (!q.valid) return;
+        const unsigned dst = smem_lds + buf * STAGE_BYTES + which * HALF_BYTES;
+        const bool full = q.mrem == BM && q.nrem == BN && q.krem == BK;
+        if (full) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const bf16_t* sb = isA ? q.a + (long long)(i * 128 + h * 64) * p.lda : q.b + (long long)(i * 128 + h * 32) * p.ldb;
+                glds16_s(isA ? voffA : voffB, sb, dst + (unsigned)((i * 8 + wave) * 1024));
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                int ra, rb, ck;
+                geo(i, h, ra, rb, ck);
+                const bool ok = isA ? (ra < q.mrem && ck * 8 < q.krem) : (rb < q.nrem && ck * 8 < q.krem);
+                const bf16_t* src = isA ? q.a + ((long long)ra * p.lda + ck * 8) : q.b + ((long long)rb * p.ldb + ck * 8);
+                glds16(ok ? src : zero, dst + (unsigned)((i * 8 + wave) * 1024));
+            }
+        }
+    };
+    using C0 = std::integral_constant<int, 0>; using C1 = std::integral_constant<int, 1>;
+    using C2 = std::integral_constant<int, 2>; using C3 = std::integral_constant<int, 3>;
+
+    // ---- fragment read addresses: LDS row r = base + (lane & 15), chunk (kk*4 + (lane >> 4)) ^ ((r >> 1) & 7); the row
+    // bases are multiples of 16, so the swizzle term depends on the lane only; kk = 1 flips chunk bit 2 (byte 64)
+    const int frow = lane & 15;
+    const unsigned fsw0 = (unsigned)((((lane >> 4) ^ ((frow >> 1) & 7)) << 4));
+    const unsigned fA0 = (unsigned)((wm * 64 + frow) * 128) + fsw0;     // + i*2048 (16 rows); kk = 1: byte bit 6 flipped
+    const unsigned fB0 = (unsigned)((wn * 32 + frow) * 128) + fsw0;     // + j*2048
+    const unsigned fA1 = fA0 ^ 64u, fB1 = fB0 ^ 64u;                    // (i*2048 / j*2048 never touch bit 6: plain immediates)
+
+    f32x4_t acc[8][4];
+    bf16x8_t a0[4][2], a1[4][2], b0[2][2], b1[2][2];
+
+    auto read_a = [&](bf16x8_t (&af)[4][2], int buf, int h) __attribute__((always_inline)) {
+        const unsigned char* base = smem + buf * STAGE_BYTES + (h ? OFF_A1 : OFF_A0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            af[i][0] = *reinterpret_cast<const bf16x8_t*>(base + fA0 + i * 2048);
+            af[i][1] = *reinterpret_cast<const bf16x8_t*>(base + fA1 + i * 2048);
+        }
+    };
+    auto read_b = [&](bf16x8_t (&bf)[2][2], int buf, int h) __attribute__((always_inline)) {
+        const unsigned char* base = smem + buf * STAGE_BYTES + (h ? OFF_B1 : OFF_B0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            bf[j][0] = *reinterpret_cast<const bf16x8_t*>(base + fB0 + j * 2048);
+            bf[j][1] = *reinterpret_cast<const bf16x8_t*>(base + fB1 + j * 2048);
+        }
+    };
+    // operands swapped (D = Bfrag . Afrag^T): a lane holds 4 consecutive output COLUMNS of one output row
+    //   acc[i8][j4][r]: row = wm*128 + i8*16 + (lane & 15), column = wn*64 + j4*16 + (lane >> 4)*4 + r
+    auto mma_quad = [&](const bf16x8_t (&af)[4][2], const bf16x8_t (&bf)[2][2], auto ih_c, auto jh_c) __attribute__((always_inline)) {
+        constexpr int ih = decltype(ih_c)::value, jh = decltype(jh_c)::value;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[ih * 4 + i][jh * 2 + j] =
+                        __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j][kk], af[i][kk], acc[ih * 4 + i][jh * 2 + j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+    const float alpha = p.alpha;
+
+    // current (consumed) item
+    long long cit = 0;
+    int ckt = 0;
+    int cz, cmt, cnt;
+    item_coords(wk, 0, cz, cmt, cnt);
+
+    // producer positions: p1 = tile t+1, p2 = tile t+2
+    long long pit = 0; int pkt = 0;
+    auto next_pos = [&]() __attribute__((always_inline)) {
+        ++pkt;
+        if (pkt == ktn) { pkt = 0; ++pit; }
+        return make_pos(pit, pkt);
+    };
+    TilePos p0 = make_pos(0, 0);
+    TilePos p1 = next_pos();
+    TilePos p2 = next_pos();
+
+    // ---- pipeline prologue: tile 0 completely, tile 1 without its last half (stream order per tile: B0, A0, B1, A1)
+    stage(p0, 0, C2{}); stage(p0, 0, C0{}); stage(p0, 0, C3{}); stage(p0, 0, C1{});
+    stage(p1, 1, C2{}); stage(p1, 1, C0{}); stage(p1, 1, C3{});
+    if (p1.valid) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    G256_BAR();
+    if (wm == 1) G256_BAR();                    // wave row 1 runs half a phase behind wave row 0 from here on
+
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    bool drain = false;                         // stores of an epilogue are in the queue: the next tile wait drains it
+    int buf = 0;
+    for (long long t = 0; t < total; ++t) {
+        // ------------------------------------------------ phase 1: quadrant (0,0)
+        read_b(b0, buf, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        read_a(a0, buf, 0);
+        stage(p1, buf ^ 1, C1{});                                // A1 of tile t+1
+        asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");       // the 4 B0 reads have retired (B0 is re-staged next phase)
+        G256_BAR();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        mma_quad(a0, b0, C0{}, C0{});
+        G256_BAR();
+        // ------------------------------------------------ phase 2: quadrant (0,1)
+        read_b(b1, buf, 1);
+        stage(p2, buf, C2{});                                    // B0 of tile t+2
+        G256_BAR();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        mma_quad(a0, b1, C0{}, C1{});
+        G256_BAR();
+        // ------------------------------------------------ phase 3: quadrant (1,1)
+        read_a(a1, buf, 1);
+        stage(p2, buf, C0{});                                    // A0 of tile t+2
+        G256_BAR();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        mma_quad(a1, b1, C1{}, C1{});
+        G256_BAR();
+        // ------------------------------------------------ phase 4: quadrant (1,0)
+        if (drain) {
+            // first tile after an epilogue: its global stores share the counter with the DMAs and may complete out of
+            // order with them, so nothing can be counted -- wait for everything issued so far (up to A0(t+2), issued a
+            // phase ago), THEN issue B1(t+2): the next tile's vmcnt(6) is exact again
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            stage(p2, buf, C3{});
+            drain = false;
+        } else {
+            stage(p2, buf, C3{});                                // B1 of tile t+2
+            if (p2.valid) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");           // everything up to A1(t+1) has landed
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        G256_BAR();
+        mma_quad(a1, b0, C1{}, C0{});
+        G256_BAR();
+
+        p1 = p2;
+        p2 = next_pos();
+        buf ^= 1;
+        ++ckt;
+        if (ckt == ktn) {
+            // ============================================ epilogue of item (cz, cmt, cnt)
+            if (wm == 0) G256_BAR();            // un-stagger: wave row 0 waits for wave row 1 to finish its last quadrant
+            unsigned char* const etile = smem + EPI_OFF;
+            const long long m0 = (long long)cmt * BM;
+            const int n0 = cnt * BN;
+            bf16_t* const Cb = reinterpret_cast<bf16_t*>(p.C) + (long long)cz * p.sC1;
+            const bf16_t* const Rb = p.R ? p.R + (long long)cz * p.sC1 : nullptr;
+            const float* bias = p.bias ? p.bias + (long long)cz * p.bias_stride1 : nullptr;
+            const int cc = tid & 31, r0 = tid >> 5;              // copy-out role: 16-byte chunk cc of rows r0 + 16*pass
+            const int ncol = n0 + cc * 8;
+            float csum[8], csq[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { csum[q] = 0.f; csq[q] = 0.f; }
+            float bv[4][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int n = n0 + wn * 64 + j * 16 + (lane >> 4) * 4 + r;
+                    bv[j][r] = (bias && n < p.N) ? bias[n] : 0.f;
+                }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {                        // slab s = tile rows s*64 .. s*64+63 (wave row s >> 1, quadrant row s & 1)
+                if (wm == (s >> 1)) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const f32x4_t v = acc[(s & 1) * 4 + i][j];
+                            const uint2 pk = make_uint2(pack_bf2(v[0] * alpha + bv[j][0], v[1] * alpha + bv[j][1]),
+                                                        pack_bf2(v[2] * alpha + bv[j][2], v[3] * alpha + bv[j][3]));
+                            const int row = i * 16 + (lane & 15);
+                            const int col = wn * 64 + j * 16 + (lane >> 4) * 4;          // multiple of 4
+                            const int ch = col >> 3;
+                            *reinterpret_cast<uint2*>(etile + row * (BN * 2) + ((ch ^ (row & 31)) << 4) + (col & 7) * 2) = pk;
+                        }
+                }
+                G256_BAR();
+                if (ncol < p.N) {
+#pragma unroll
+                    for (int ps = 0; ps < 4; ++ps) {
+                        const int row = r0 + ps * 16;
+                        const long long m = m0 + s * 64 + row;
+                        if (m < p.M) {
+                            uint4 v = *reinterpret_cast<const uint4*>(etile + row * (BN * 2) + ((cc ^ (row & 31)) << 4));
+                            if (Rb) {
+                                float f[8], g[8];
+                                unpack8(v, f);
+                                const uint4 rv = *reinterpret_cast<const uint4*>(Rb + m * p.ldr + ncol);
+                                unpack8(rv, g);
+#pragma unroll
+                                for (int q = 0; q < 8; ++q) f[q] += g[q];
+                                v = pack8(f);
+                            }
+                            if (STATS) {
+                                float f[8];
+                                unpack8(v, f);
+#pragma unroll
+                                for (int q = 0; q < 8; ++q) { csum[q] += f[q]; csq[q] += f[q] * f[q]; }
+                            }
+                            *reinterpret_cast<uint4*>(Cb + m * p.ldc + ncol) = v;
+                        }
+                    }
+                }
+                G256_BAR();
+            }
+            if (STATS) {
+                // column statistics of this output tile: 16 row groups -> one value per column, fixed order
+                float* red = reinterpret_cast<float*>(etile);            // [16][256][2] floats = 32 KB
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    red[(r0 * BN + cc * 8 + q) * 2 + 0] = csum[q];
+                    red[(r0 * BN + cc * 8 + q) * 2 + 1] = csq[q];
+                }
+                G256_BAR();
+                if (tid < BN) {
+                    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { s1 += red[(r * BN + tid) * 2]; s2 += red[(r * BN + tid) * 2 + 1]; }
+                    const int n = n0 + tid;
+                    if (n < p.N) {
+                        float* dst = p.stat_partials + ((long long)cz * MT + cmt) * 2 * p.N;
+                        dst[n] = s1;
+                        dst[p.N + n] = s2;
+                    }
+                }
+                G256_BAR();
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+            drain = true;
+            ckt = 0;
+            ++cit;
+            if (cit < wk.n_items) item_coords(wk, cit, cz, cmt, cnt);
+            if (wm == 1) G256_BAR();            // restore the half-phase stagger
+        }
+    }
+    if (wm == 0) G256_BAR();                    // balance the extra barrier of wave row 1
+}
+
+}  // namespace g256
+
+// ---- host side ------------------------------------------------------------------------------------------------------
+// eligibility + launch, called from mc_gemm_bf16 (gemm.hip) for plain NT bf16-output problems
+#include <cstdlib>
+// MC_GEMM_256: 0 = never, 1 = by the size rule below (default), 2 = whenever the layout allows (tests / A-B runs)
+static int g256_mode() { const char* e = getenv("MC_GEMM_256"); return e ? atoi(e) : 1; }
+extern "C" int mc_gemm256_eligible(const mc_gemm_args* a) {
+    const mc_gemm_args& p = *a;
+    const int mode = g256_mode();
+    if (mode == 0) return 0;
+    if (p.a_kmajor || p.b_kmajor || p.c_f32 || p.pro_operand != 0 || p.splits > 1 || p.nb2 > 1) return 0;
+    if (p.lda * 128 + 64 >= (1LL << 30) || p.ldb * 128 + 64 >= (1LL << 30)) return 0;      // 32-bit lane byte offsets
+    if (mode == 2) return 1;
+    if (p.N < 96 || p.K < 64 || p.M < 256) return 0;
+    const long long MT = (p.M + 255) / 256, NTl = (p.N + 255) / 256;
+    const long long items = (long long)(p.batch > 0 ? p.batch : 1) * MT * NTl;
+    // one 256 x 256 tile per CU and round: enough tiles to keep the 256 CUs busy, and a last round that is not mostly idle
+    if (items < 200) return 0;
+    const long long rounds = (items + 255) / 256;
+    if (items * 10 < rounds * 256 * 7) return 0;                  // < 70 % of the CU-rounds filled
+    return 1;
+}
+extern "C" int mc_gemm256_stat_rows(const mc_gemm_args* a) {
+    return (int)((a->batch > 0 ? a->batch : 1) * ((a->M + 255) / 256));
+}
+extern "C" int mc_gemm256_launch(const mc_gemm_args* a, void* stream) {
+    mc_gemm_args p = *a;
+    if (p.batch <= 0) p.batch = 1;
+    if (p.alpha == 0.f) p.alpha = 1.f;
+    const int MT = (int)((p.M + 255) / 256), NTl = (int)((p.N + 255) / 256), ktn = (int)((p.K + 63) / 64);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const dim3 grid(256), block(g256::NTHR);
+    if (p.stat_partials) hipLaunchKernelGGL((g256::gemm256_kernel<true>), grid, block, 0, st, p, MT, NTl, ktn);
+    else hipLaunchKernelGGL((g256::gemm256_kernel<false>), grid, block, 0, st, p, MT, NTl, ktn);
+    MC_LAUNCH_CHECK();
+    return MC_OK;
+}

@@ -42,8 +42,10 @@ def empty(shape, dtype, like):
 # ------------------------------------------------------------------------------------------- GEMM
 def gemm(A, B, C_out, M, N, K, lda, ldb, ldc, a_kmajor=0, b_kmajor=0, c_f32=0, c_atomic=0, splits=1,
          batch=1, nb2=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), bias=None, bias_stride1=0, act=0, R=None, ldr=0,
-         alpha=1.0, pro=None, stat_partials=None, max_grid_m=0, splitk_ws=None, split_groups=None, kind=None):
-    """pro = (operand, scale, shift, gate or None, rows_per_img, nch); split_groups = (rows per group, sub-splits, scale)"""
+         alpha=1.0, pro=None, stat_partials=None, max_grid_m=0, splitk_ws=None, split_groups=None, kind=None, stats=False):
+    """pro = (operand, scale, shift, gate or None, rows_per_img, nch); split_groups = (rows per group, sub-splits, scale)
+    stats=True: allocates and returns the [rows, 2, N] column sum / sum-of-squares partials of C (the row count depends on
+    the tile configuration the library picks for this problem: mc_gemm_stat_rows on the complete argument block)"""
     a = L.GemmArgs()
     a.A, a.B, a.C = _p(A), _p(B), _p(C_out)
     a.M, a.K, a.N = M, K, N
@@ -62,11 +64,15 @@ def gemm(A, B, C_out, M, N, K, lda, ldb, ldc, a_kmajor=0, b_kmajor=0, c_f32=0, c
     a.splitk_ws = _p(splitk_ws)
     if split_groups is not None:
         a.split_group_rows, a.split_sub, a.split_scale = split_groups[0], split_groups[1], _p(split_groups[2])
+    if stats:
+        stat_partials = empty((L.load().mc_gemm_stat_rows(C.byref(a)), 2, N), torch.float32, C_out)
+        a.stat_partials = _p(stat_partials)
     _note(batch * (2 * M * K + 2 * N * K + (4 if c_f32 else 2) * M * N + (2 * M * N if R is not None else 0)),
           2 * batch * M * N * K)
     if L.TIMER is not None and not a_kmajor and not b_kmajor and pro is None and N > 64 and K > 48 and not c_f32:
         kind = (kind or "") + "|glnt"       # lands on gemm_kernel<128,128,64,2,2,0,0,false,true> (direct-to-LDS NT tiles)
     L.call("mc_gemm_bf16", C.byref(a), _st(), kind=kind)
+    return stat_partials
 
 
 def gemm_stat_rows(M, N=128, batch=1):
@@ -176,25 +182,21 @@ def linear_fwd(x, w, bias=None, act=0, residual=None, stats=False, pro=None, out
         # x is already activated and only carries the per-image gate: one GEMM per image (batched) whose weight tile
         # is scaled by that image's gate while it is staged -- no per-row prologue on the big operand
         hw, n_img = pro[3], M // pro[3]
-        part = empty((gemm_stat_rows(hw, N, n_img), 2, N), torch.float32, x) if stats else None
         if N > 64 and K > 48 and w.is_contiguous():
             # gated copies of the weight (n_img x N x K, a few MB) -> plain batched GEMM, direct-to-LDS staging
             wg = empty((n_img, N, K), BF16, x)
             L.call("mc_gate_weights_bf16", _p(w), _p(pro[2]), n_img, N, K, _p(wg), _st())
-            gemm(x, wg, y, hw, N, K, x.stride(0), K, y.stride(0), batch=n_img, sA=(hw * x.stride(0), 0), sB=(N * K, 0),
-                 sC=(hw * y.stride(0), 0), stat_partials=part, kind="fwd")
+            part = gemm(x, wg, y, hw, N, K, x.stride(0), K, y.stride(0), batch=n_img, sA=(hw * x.stride(0), 0), sB=(N * K, 0),
+                        sC=(hw * y.stride(0), 0), stats=stats, kind="fwd")
         else:
-            gemm(x, w, y, hw, N, K, x.stride(0), w.stride(0), y.stride(0), batch=n_img, sA=(hw * x.stride(0), 0),
-                 sC=(hw * y.stride(0), 0), pro=(3, None, None, pro[2], hw, K), stat_partials=part, kind="fwd")
+            part = gemm(x, w, y, hw, N, K, x.stride(0), w.stride(0), y.stride(0), batch=n_img, sA=(hw * x.stride(0), 0),
+                        sC=(hw * y.stride(0), 0), pro=(3, None, None, pro[2], hw, K), stats=stats, kind="fwd")
         return (y, part) if stats else y
-    part = None
-    if stats:
-        part = empty((gemm_stat_rows(M, N), 2, N), torch.float32, x)
     p = None
     if pro is not None:
         p = (1, pro[0], pro[1], pro[2], pro[3], K)
-    gemm(x, w, y, M, N, K, x.stride(0), w.stride(0), y.stride(0), bias=bias, act=act, R=residual,
-         ldr=(residual.stride(0) if residual is not None else 0), pro=p, stat_partials=part, kind="fwd")
+    part = gemm(x, w, y, M, N, K, x.stride(0), w.stride(0), y.stride(0), bias=bias, act=act, R=residual,
+                ldr=(residual.stride(0) if residual is not None else 0), pro=p, stats=stats, kind="fwd")
     return (y, part) if stats else y
 
 

@@ -109,6 +109,80 @@ def test_gemm_prologue_a_and_b():
     check(y2, F.silu(d.float() * scale + shift).to(BF).float() @ w.float().T, 1e-2, "prologue A no gate")
 
 
+class _force_gemm256:
+    """route every layout-eligible launch to the 256 x 256 tile kernel (MC_GEMM_256=2), whatever its size"""
+
+    def __enter__(self):
+        import os
+        self.old = os.environ.get("MC_GEMM_256")
+        os.environ["MC_GEMM_256"] = "2"
+
+    def __exit__(self, *a):
+        import os
+        if self.old is None:
+            os.environ.pop("MC_GEMM_256", None)
+        else:
+            os.environ["MC_GEMM_256"] = self.old
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (512, 256, 128), (300, 144, 24), (257, 40, 240), (4096, 304, 1824),
+                                   (5000, 1824, 304), (1392 * 3, 512, 3072), (8192, 2304, 768), (777, 776, 1000),
+                                   (66000, 176, 1056), (130, 64, 48), (20000, 3072, 512)])
+def test_gemm256_nt(M, N, K):
+    """256 x 256 x 64 tile kernel (gemm256.hip): ragged M / N / K tails, one to many K tiles per output tile, more
+    output tiles than workgroups (persistent stream across tiles), every path of the staged pipeline; 3 repeats on
+    fresh outputs (a race between the DMA stream and the fragment reads would come and go)."""
+    x, w = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5)
+    ref = x.float() @ w.float().T
+    with _force_gemm256():
+        for rep in range(3):
+            y = ops.linear_fwd(x, w)
+            check(y, ref, 1e-2, f"gemm256 nt rep {rep}")
+    # asymmetric identity: catches transposed / permuted fragments exactly
+    n = 512
+    a = torch.eye(n, device=DEV).to(BF)
+    b = (torch.arange(n * n, device=DEV).reshape(n, n) % 61).float().to(BF)
+    with _force_gemm256():
+        y = ops.linear_fwd(a, b)
+    check(y, b.float().T, 1e-6, "gemm256 identity")
+
+
+def test_gemm256_bias_residual_stats_batched_alpha():
+    M, N, K = 3000, 1000, 712
+    x, w = rnd(M, K, seed=3), rnd(N, K, seed=4, scale=K ** -0.5)
+    bias = rnd(N, seed=5, dtype=torch.float32)
+    res = rnd(M, N, seed=6)
+    with _force_gemm256():
+        y = ops.linear_fwd(x, w, bias=bias, residual=res)
+        y3, part = ops.linear_fwd(x, w, stats=True)
+    check(y, (x.float() @ w.float().T + bias).to(BF).float() + res.float(), 1e-2, "gemm256 bias+residual")
+    assert part.shape == ((M + 255) // 256, 2, N)
+    s = part.double().sum(0)
+    yf = y3.float().double()
+    check(s[0].float(), yf.sum(0).float(), 1e-4, "gemm256 colsum")
+    check(s[1].float(), (yf * yf).sum(0).float(), 1e-4, "gemm256 colsumsq")
+    # batched (one weight matrix per batch element, like the per-image gated projection weights) + alpha + stats
+    nb, hw, N2, K2 = 5, 700, 304, 1824
+    xb, wb = rnd(nb * hw, K2, seed=7), rnd(nb, N2, K2, seed=8, scale=K2 ** -0.5)
+    yb = torch.empty(nb * hw, N2, device=DEV, dtype=BF)
+    with _force_gemm256():
+        pb = ops.gemm(xb, wb, yb, hw, N2, K2, K2, K2, N2, batch=nb, sA=(hw * K2, 0), sB=(N2 * K2, 0), sC=(hw * N2, 0),
+                      alpha=0.5, stats=True)
+    refb = 0.5 * torch.einsum("bmk,bnk->bmn", xb.float().view(nb, hw, K2), wb.float()).reshape(nb * hw, N2)
+    check(yb, refb, 1e-2, "gemm256 batched")
+    assert pb.shape == (nb * ((hw + 255) // 256), 2, N2)
+    check(pb.double().sum(0)[0].float(), yb.float().double().sum(0).float(), 1e-4, "gemm256 batched colsum")
+    # strided output / operands (columns of a wider buffer, like the fused QKV projection)
+    H = 768
+    xs = rnd(2048, 3 * H, seed=9)
+    ws = rnd(H, H, seed=10, scale=H ** -0.5)
+    out = torch.zeros(2048, 3 * H, device=DEV, dtype=BF)
+    with _force_gemm256():
+        ops.gemm(xs[:, H:], ws, out[:, 2 * H:], 2048, H, H, 3 * H, H, 3 * H)
+    check(out[:, 2 * H:], xs[:, H:2 * H].float() @ ws.float().T, 1e-2, "gemm256 strided")
+    assert float(out[:, :2 * H].abs().max()) == 0.0
+
+
 def test_gemm_batched_attention_shapes():
     b, nh, T, hd = 2, 3, 64, 64
     H = nh * hd
