@@ -41,16 +41,8 @@ constexpr int EPI_OFF = 2 * STAGE_BYTES;         // 128 KB
 constexpr int EPI_BYTES = 64 * BN * 2;           // one slab: 64 rows x 256 columns bf16 = 32 KB
 constexpr int LDS_BYTES = EPI_OFF + EPI_BYTES;   // 160 KB
 
-__device__ __attribute__((aligned(16))) unsigned int g_zero16[4];
-
-__device__ __forceinline__ void glds16(const void* src, unsigned lds_dst_wave_base) {
-    const unsigned lds = __builtin_amdgcn_readfirstlane(lds_dst_wave_base);
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(src), "s"(lds) : "memory");
-}
-
-// same with a wave-uniform 64-bit base in SGPRs and a 32-bit per-lane byte offset (no per-lane 64-bit address arithmetic)
+// direct-to-LDS DMA of 16 bytes per lane: wave-uniform 64-bit base in SGPRs + 32-bit per-lane byte offset; lane l's bytes
+// land at lds_dst_wave_base + 16 l.  Inline assembly: the compiler keeps no book on it (the kernel counts vmcnt itself).
 __device__ __forceinline__ void glds16_s(unsigned voff_bytes, const void* sbase, unsigned lds_dst_wave_base) {
     const unsigned lds = __builtin_amdgcn_readfirstlane(lds_dst_wave_base);
     unsigned keep;
@@ -138,7 +130,6 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256_kernel(const mc_gemm_args p, 
         voffA = (unsigned)((ra * p.lda + ck * 8) * 2);
         voffB = (unsigned)((rb * p.ldb + ck * 8) * 2);
     }
-    const bf16_t* const zero = reinterpret_cast<const bf16_t*>(g_zero16);
     typedef __attribute__((address_space(3))) unsigned int lds_u32_t;
     const unsigned smem_lds = (unsigned)(uintptr_t)(lds_u32_t*)smem;
 
@@ -157,13 +148,20 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256_kernel(const mc_gemm_args p, 
                 glds16_s(isA ? voffA : voffB, sb, dst + (unsigned)((i * 8 + wave) * 1024));
             }
         } else {
+            // partial tile.  Rows / columns beyond the matrix are CLAMPED to the last valid one (row m of C depends only on
+            // row m of A, column n only on row n of B, and those outputs are never stored); chunks beyond K must be ZERO
+            // in LDS: their lanes are masked off the DMA (EXEC) and store zeros to their slot instead.  Every 8-lane group
+            // covers all 8 chunks of a row and K % 8 == 0, so every wave-instruction keeps active lanes: the number of DMA
+            // instructions per wave -- what the counted vmcnt relies on -- is the same as on the full-tile path.
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 int ra, rb, ck;
                 geo(i, h, ra, rb, ck);
-                const bool ok = isA ? (ra < q.mrem && ck * 8 < q.krem) : (rb < q.nrem && ck * 8 < q.krem);
-                const bf16_t* src = isA ? q.a + ((long long)ra * p.lda + ck * 8) : q.b + ((long long)rb * p.ldb + ck * 8);
-                glds16(ok ? src : zero, dst + (unsigned)((i * 8 + wave) * 1024));
+                const int rr = isA ? (ra < q.mrem ? ra : q.mrem - 1) : (rb < q.nrem ? rb : q.nrem - 1);
+                const unsigned voff = (unsigned)((rr * (isA ? p.lda : p.ldb) + ck * 8) * 2);
+                const unsigned d = dst + (unsigned)((i * 8 + wave) * 1024);
+                if (ck * 8 < q.krem) glds16_s(voff, isA ? q.a : q.b, d);
+                else *reinterpret_cast<uint4*>(smem + (d - smem_lds) + lane * 16) = make_uint4(0u, 0u, 0u, 0u);
             }
         }
     };
@@ -310,14 +308,33 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256_kernel(const mc_gemm_args p, 
             float csum[8], csq[8];
 #pragma unroll
             for (int q = 0; q < 8; ++q) { csum[q] = 0.f; csq[q] = 0.f; }
+            // bias of the lane's 4 x 4 columns.  (Loaded by inline assembly with its own wait: ANY vector-memory load the
+            // compiler tracks inside this loop makes it drain vmcnt at the loop head -- and with it the DMA stream -- on
+            // every K tile.)  Column groups start at multiples of 4 and N % 8 == 0: a group is inside or outside as a whole.
             float bv[4][4];
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int n = n0 + wn * 64 + j * 16 + (lane >> 4) * 4 + r;
-                    bv[j][r] = (bias && n < p.N) ? bias[n] : 0.f;
+                for (int r = 0; r < 4; ++r) bv[j][r] = 0.f;
+            if (bias) {
+                f32x4_t t[4];
+                const float* bp[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int n = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
+                    bp[j] = bias + (n < p.N ? n : 0);
                 }
+                asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %5, off\n\t"
+                             "global_load_dwordx4 %2, %6, off\n\tglobal_load_dwordx4 %3, %7, off\n\ts_waitcnt vmcnt(0)"
+                             : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3])
+                             : "v"(bp[0]), "v"(bp[1]), "v"(bp[2]), "v"(bp[3]) : "memory");
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int n = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) bv[j][r] = n < p.N ? t[j][r] : 0.f;
+                }
+            }
 #pragma unroll
             for (int s = 0; s < 4; ++s) {                        // slab s = tile rows s*64 .. s*64+63 (wave row s >> 1, quadrant row s & 1)
                 if (wm == (s >> 1)) {
@@ -343,9 +360,13 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256_kernel(const mc_gemm_args p, 
                         if (m < p.M) {
                             uint4 v = *reinterpret_cast<const uint4*>(etile + row * (BN * 2) + ((cc ^ (row & 31)) << 4));
                             if (Rb) {
+                                // (inline assembly with its own wait: a load the compiler tracks inside this loop would
+                                // make it drain vmcnt at the loop head -- and with it the DMA stream -- on every K tile)
                                 float f[8], g[8];
                                 unpack8(v, f);
-                                const uint4 rv = *reinterpret_cast<const uint4*>(Rb + m * p.ldr + ncol);
+                                uint4 rv;
+                                asm volatile("global_load_dwordx4 %0, %1, off\n\ts_waitcnt vmcnt(0)"
+                                             : "=&v"(rv) : "v"(Rb + m * p.ldr + ncol) : "memory");
                                 unpack8(rv, g);
 #pragma unroll
                                 for (int q = 0; q < 8; ++q) f[q] += g[q];
