@@ -50,6 +50,28 @@ __device__ __forceinline__ void glds16_s(unsigned voff_bytes, const void* sbase,
                  : "=&s"(keep) : "v"(voff_bytes), "s"(lds), "s"(sbase) : "memory");
 }
 
+// Two main-loop schedules share everything else in this file:
+//   G256_PHASED   the 4-phase / counted-vmcnt schedule described above
+//   (default)     ONE barrier per K tile: wait for tile t, barrier, issue the whole of tile t+1 (8 DMA instructions per
+//                 wave, 64 KB in flight per CU), then the four quadrants of tile t back to back; the two waves of a SIMD
+//                 drift apart on their own and cover each other's LDS reads and DMA issue.
+// Measured on MI355X (scripts/g256bench.hip, uniform random operands): the one-barrier schedule is 10-25 % faster on every
+// shape of the model (8192^3: 853 vs 772 TFLOP/s; 44544x3072x512: 728 vs 657; 173280x176x1056: 471 vs 405): with 8 barriers
+// per K tile the phased schedule's load phases (2 DMA issues of ~150 cycles each + up to 12 ds_read_b128) are longer than
+// the 16-MFMA phases they are meant to hide under (phase profile, -DG256_PROF), so the barriers expose them.
+#ifndef G256_PHASED
+#define G256_SIMPLE
+#endif
+#ifdef G256_SIMPLE
+#define G256_NOSTAGGER
+#endif
+#ifdef G256_PROF
+__device__ unsigned long long g_g256_prof[2][12];   // developer phase profile (scripts/g256bench.hip): [wave row][segment]
+#define GP(i) do { unsigned long long t_ = __builtin_amdgcn_s_memtime(); pacc[i] += t_ - tprof; tprof = t_; } while (0)
+#else
+#define GP(i)
+#endif
+
 #define G256_BAR()                                   \
     do {                                             \
         asm volatile("" ::: "memory");               \
@@ -139,6 +161,9 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256_kernel(const mc_gemm_args p, 
         constexpr bool isA = which < 2;
         constexpr int h = which & 1;
         if (!q.valid) return;
+#ifdef G256_NODMA
+        if (q.valid) return;                    // diagnostic build: fragments + MFMA speed with no fill traffic (wrong results)
+#endif
         const unsigned dst = smem_lds + buf * STAGE_BYTES + which * HALF_BYTES;
         const bool full = q.mrem == BM && q.nrem == BN && q.krem == BK;
         if (full) {
@@ -179,7 +204,11 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256_kernel(const mc_gemm_args p, 
     f32x4_t acc[8][4];
     bf16x8_t a0[4][2], a1[4][2], b0[2][2], b1[2][2];
 
+    long long t_cur = 0;
     auto read_a = [&](bf16x8_t (&af)[4][2], int buf, int h) __attribute__((always_inline)) {
+#ifdef G256_NOREAD
+        if (t_cur > 0) { asm volatile("" : "+v"(af[0][0]), "+v"(af[1][0]), "+v"(af[2][0]), "+v"(af[3][0])); return; }
+#endif
         const unsigned char* base = smem + buf * STAGE_BYTES + (h ? OFF_A1 : OFF_A0);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -188,6 +217,9 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256_kernel(const mc_gemm_args p, 
         }
     };
     auto read_b = [&](bf16x8_t (&bf)[2][2], int buf, int h) __attribute__((always_inline)) {
+#ifdef G256_NOREAD
+        if (t_cur > 0) { asm volatile("" : "+v"(bf[0][0]), "+v"(bf[1][0])); return; }
+#endif
         const unsigned char* base = smem + buf * STAGE_BYTES + (h ? OFF_B1 : OFF_B0);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -199,7 +231,9 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256_kernel(const mc_gemm_args p, 
     //   acc[i8][j4][r]: row = wm*128 + i8*16 + (lane & 15), column = wn*64 + j4*16 + (lane >> 4)*4 + r
     auto mma_quad = [&](const bf16x8_t (&af)[4][2], const bf16x8_t (&bf)[2][2], auto ih_c, auto jh_c) __attribute__((always_inline)) {
         constexpr int ih = decltype(ih_c)::value, jh = decltype(jh_c)::value;
+#ifndef G256_NOPRIO
         __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
@@ -208,7 +242,9 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256_kernel(const mc_gemm_args p, 
                 for (int j = 0; j < 2; ++j)
                     acc[ih * 4 + i][jh * 2 + j] =
                         __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j][kk], af[i][kk], acc[ih * 4 + i][jh * 2 + j], 0, 0, 0);
+#ifndef G256_NOPRIO
         __builtin_amdgcn_s_setprio(0);
+#endif
     };
 
     const float alpha = p.alpha;
@@ -232,11 +268,15 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256_kernel(const mc_gemm_args p, 
 
     // ---- pipeline prologue: tile 0 completely, tile 1 without its last half (stream order per tile: B0, A0, B1, A1)
     stage(p0, 0, C2{}); stage(p0, 0, C0{}); stage(p0, 0, C3{}); stage(p0, 0, C1{});
+#ifndef G256_SIMPLE
     stage(p1, 1, C2{}); stage(p1, 1, C0{}); stage(p1, 1, C3{});
     if (p1.valid) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     G256_BAR();
+#endif
+#ifndef G256_NOSTAGGER
     if (wm == 1) G256_BAR();                    // wave row 1 runs half a phase behind wave row 0 from here on
+#endif
 
 #pragma unroll
     for (int i = 0; i < 8; ++i)
@@ -245,34 +285,72 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256_kernel(const mc_gemm_args p, 
 
     bool drain = false;                         // stores of an epilogue are in the queue: the next tile wait drains it
     int buf = 0;
+#ifdef G256_PROF
+    unsigned long long pacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tprof = __builtin_amdgcn_s_memtime();
+#endif
     for (long long t = 0; t < total; ++t) {
+        t_cur = t;
+#ifdef G256_SIMPLE
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        G256_BAR();
+        stage(p1, buf ^ 1, C2{}); stage(p1, buf ^ 1, C0{}); stage(p1, buf ^ 1, C3{}); stage(p1, buf ^ 1, C1{});
+        read_b(b0, buf, 0);
+        read_a(a0, buf, 0);
+        mma_quad(a0, b0, C0{}, C0{});
+        read_b(b1, buf, 1);
+        mma_quad(a0, b1, C0{}, C1{});
+        read_a(a1, buf, 1);
+        mma_quad(a1, b1, C1{}, C1{});
+        mma_quad(a1, b0, C1{}, C0{});
+        drain = false;
+#else
         // ------------------------------------------------ phase 1: quadrant (0,0)
         read_b(b0, buf, 0);
         __builtin_amdgcn_sched_barrier(0);
         read_a(a0, buf, 0);
+        GP(8);
         stage(p1, buf ^ 1, C1{});                                // A1 of tile t+1
+        GP(9);
         asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");       // the 4 B0 reads have retired (B0 is re-staged next phase)
+        GP(0);
         G256_BAR();
+        GP(1);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
+        GP(2);
         mma_quad(a0, b0, C0{}, C0{});
+        GP(3);
         G256_BAR();
+        GP(4);
         // ------------------------------------------------ phase 2: quadrant (0,1)
         read_b(b1, buf, 1);
+        GP(8);
         stage(p2, buf, C2{});                                    // B0 of tile t+2
+        GP(9);
         G256_BAR();
+        GP(1);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
+        GP(2);
         mma_quad(a0, b1, C0{}, C1{});
+        GP(3);
         G256_BAR();
+        GP(4);
         // ------------------------------------------------ phase 3: quadrant (1,1)
         read_a(a1, buf, 1);
+        GP(8);
         stage(p2, buf, C0{});                                    // A0 of tile t+2
+        GP(9);
         G256_BAR();
+        GP(1);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
+        GP(2);
         mma_quad(a1, b1, C1{}, C1{});
+        GP(3);
         G256_BAR();
+        GP(4);
         // ------------------------------------------------ phase 4: quadrant (1,0)
         if (drain) {
             // first tile after an epilogue: its global stores share the counter with the DMAs and may complete out of
@@ -286,9 +364,17 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256_kernel(const mc_gemm_args p, 
             if (p2.valid) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");           // everything up to A1(t+1) has landed
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
+        GP(5);
         G256_BAR();
+        GP(1);
         mma_quad(a1, b0, C1{}, C0{});
+        GP(3);
         G256_BAR();
+        GP(4);
+#ifdef G256_PROF
+        pacc[7] += 1;
+#endif
+#endif  // G256_SIMPLE
 
         p1 = p2;
         p2 = next_pos();
@@ -296,7 +382,9 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256_kernel(const mc_gemm_args p, 
         ++ckt;
         if (ckt == ktn) {
             // ============================================ epilogue of item (cz, cmt, cnt)
+#ifndef G256_NOSTAGGER
             if (wm == 0) G256_BAR();            // un-stagger: wave row 0 waits for wave row 1 to finish its last quadrant
+#endif
             unsigned char* const etile = smem + EPI_OFF;
             const long long m0 = (long long)cmt * BM;
             const int n0 = cnt * BN;
@@ -414,10 +502,19 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256_kernel(const mc_gemm_args p, 
             ckt = 0;
             ++cit;
             if (cit < wk.n_items) item_coords(wk, cit, cz, cmt, cnt);
+#ifndef G256_NOSTAGGER
             if (wm == 1) G256_BAR();            // restore the half-phase stagger
+#endif
+            GP(6);
         }
     }
+#ifdef G256_PROF
+    if (lane == 0 && wn == 0)
+        for (int q = 0; q < 12; ++q) atomicAdd(&g_g256_prof[wm][q], pacc[q]);
+#endif
+#ifndef G256_NOSTAGGER
     if (wm == 0) G256_BAR();                    // balance the extra barrier of wave row 1
+#endif
 }
 
 }  // namespace g256
@@ -437,11 +534,18 @@ extern "C" int mc_gemm256_eligible(const mc_gemm_args* a) {
     if (p.N < 96 || p.K < 64 || p.M < 256) return 0;
     const long long MT = (p.M + 255) / 256, NTl = (p.N + 255) / 256;
     const long long items = (long long)(p.batch > 0 ? p.batch : 1) * MT * NTl;
-    // one 256 x 256 tile per CU and round: enough tiles to keep the 256 CUs busy, and a last round that is not mostly idle
     if (items < 200) return 0;
+    // One 256 x 256 tile per CU and round.  Against the 128 x 128 kernel of gemm.hip (two workgroups per CU, four times
+    // finer work granularity) the big tile wins where its rounds are well filled and little of the tile is padding
+    // (A/B on MI355X, scripts/gemm256_bench.py): e.g. 44544 x 3072 x 512  742 vs 638 TFLOP/s, 16384 x 3072 x 768  869 vs
+    // 740, 8192^3  1059 vs 873; it loses where the last round is mostly idle or N is a poor fit (44544 x 304 x 1824:
+    // 348 tiles on 256 CUs, 41 % padding: 347 vs 489).  One column tile wide (N <= 256) with a long reduction is the
+    // HBM-bound case -- the activation operand streams exactly once: 173280 x 176 x 1056  488 vs 442.
     const long long rounds = (items + 255) / 256;
-    if (items * 10 < rounds * 256 * 7) return 0;                  // < 70 % of the CU-rounds filled
-    return 1;
+    const double occ = (double)items / (double)(rounds * 256), useful = (double)p.N / (double)(NTl * 256);
+    if (occ * useful >= 0.88) return 1;
+    if (NTl == 1 && p.N >= 160 && p.K >= 768 && occ >= 0.85) return 1;
+    return 0;
 }
 extern "C" int mc_gemm256_stat_rows(const mc_gemm_args* a) {
     return (int)((a->batch > 0 ? a->batch : 1) * ((a->M + 255) / 256));
