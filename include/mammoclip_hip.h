@@ -79,7 +79,11 @@ typedef struct mc_gemm_args {
     const float* split_scale;
 } mc_gemm_args;
 int mc_gemm_bf16(const mc_gemm_args* args, void* stream);
+/* rows of the stat_partials buffer the launch described by `args` (the COMPLETE argument block) will write */
 int mc_gemm_stat_rows(const mc_gemm_args* args);
+/* which tile kernel serves `args`: 256 = the 256 x 256 x 64 direct-to-LDS kernel (gemm256.hip: plain NT operands, bf16
+ * output, enough well-filled tiles for the 256 CUs), 128 = the 128-row tile family (gemm.hip) */
+int mc_gemm_tile_config(const mc_gemm_args* args);
 
 /* Row-streaming variant for the HBM-bound 1x1 convolutions (small weight matrix, millions of pixels):
  *   C[M,N] = pro(X)[M,K] . W[N,K]^T (+ R);  N <= 256, K <= 384 (mc_gemm_rows_supported), bf16 in/out.

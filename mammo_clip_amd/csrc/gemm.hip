@@ -820,6 +820,11 @@ extern "C" int mc_gemm256_eligible(const mc_gemm_args* a);      // gemm256.hip: 
 extern "C" int mc_gemm256_stat_rows(const mc_gemm_args* a);
 extern "C" int mc_gemm256_launch(const mc_gemm_args* a, void* stream);
 
+extern "C" int mc_gemm_tile_config(const mc_gemm_args* a) {
+    // 256: the 256 x 256 x 64 kernel of gemm256.hip will run this problem; 128: the tile family of this file
+    return (a->K > 0 && mc_gemm256_eligible(a)) ? 256 : 128;
+}
+
 extern "C" int mc_gemm_stat_rows(const mc_gemm_args* a) {
     // number of partial rows the launch will write ( = row-block workgroups x batch ); `a` must be the arguments of the
     // launch itself (the tile configuration depends on the whole problem)

@@ -85,6 +85,7 @@ _SIGS = {
     "mc_adamw_step": ([C.POINTER(AdamwTensor), I, D, D, D, D, D, LL, P], I),
     "mc_gemm_bf16": ([C.POINTER(GemmArgs), P], I),
     "mc_gemm_stat_rows": ([C.POINTER(GemmArgs)], I),
+    "mc_gemm_tile_config": ([C.POINTER(GemmArgs)], I),
     "mc_gemm_rows_supported": ([I, I], I),
     "mc_gemm_rows_blocks": ([LL], I),
     "mc_gemm_rows_bf16": ([C.POINTER(GemmRowsArgs), P], I),

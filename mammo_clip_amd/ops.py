@@ -70,7 +70,8 @@ def gemm(A, B, C_out, M, N, K, lda, ldb, ldc, a_kmajor=0, b_kmajor=0, c_f32=0, c
     _note(batch * (2 * M * K + 2 * N * K + (4 if c_f32 else 2) * M * N + (2 * M * N if R is not None else 0)),
           2 * batch * M * N * K)
     if L.TIMER is not None and not a_kmajor and not b_kmajor and pro is None and N > 64 and K > 48 and not c_f32:
-        kind = (kind or "") + "|glnt"       # lands on gemm_kernel<128,128,64,2,2,0,0,false,true> (direct-to-LDS NT tiles)
+        # plain NT direct-to-LDS MFMA tiles: gemm256_kernel (256 x 256) or gemm_kernel<128,128,64,2,2,0,0,false,true>
+        kind = (kind or "") + ("|glnt256" if L.load().mc_gemm_tile_config(C.byref(a)) == 256 else "|glnt")
     L.call("mc_gemm_bf16", C.byref(a), _st(), kind=kind)
     return stat_partials
 
