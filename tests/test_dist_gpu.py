@@ -310,3 +310,70 @@ def test_two_rank_step_over_rccl(tmp_path):
     r0, r1 = _run_two_ranks(tmp_path, 29885, "nccl", 2)
     ref_loss, ref_g = _single_process_reference(8, 4, True)
     _check_against_reference(r0, r1, ref_loss, ref_g, tol=None)
+
+
+WORKER_DDP = r'''
+import os, sys, types
+sys.path.insert(0, sys.argv[1])
+import torch, torch.distributed as dist
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+dev = torch.device("cuda:0"); torch.cuda.set_device(dev)
+dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%s" % sys.argv[2], rank=0, world_size=1, device_id=dev)
+import mammo_clip_amd
+from mammo_clip_amd.breastclip import util as U
+from mammo_clip_amd.breastclip.loss import build_loss
+from mammo_clip_amd.breastclip.model import build_model
+from mammo_clip_amd.breastclip.optimizer import build_optimizer
+from oracle import weights as ow
+cfg = {"name": "clip_custom", "temperature": 0.07,
+       "image_encoder": {"source": "cnn", "name": "tf_efficientnetv2-detect", "pretrained": False, "model_type": "cnn"},
+       "text_encoder": {"source": "huggingface", "name": "emilyalsentzer/Bio_ClinicalBERT", "pretrained": False,
+                        "gradient_checkpointing": False, "pooling": "eos", "cache_dir": "", "trust_remote_code": True},
+       "projection_head": {"name": "linear", "dropout": 0.1, "proj_dim": 512}}
+loss_cfg = {"breast_clip": dict(label_smoothing=0.0, i2i_weight=1.0, t2t_weight=0.5, loss_ratio=1.0)}
+batch = ow.synth_batch(2, 64, 64, 16, seed=3)
+bt = {"images": batch["images"].to(dev), "image_views": batch["image_views"].to(dev),
+      "text_tokens": {k: v.to(dev) for k, v in batch["text_tokens"].items()},
+      "text_tokens2": {k: v.to(dev) for k, v in batch["text_tokens2"].items()}}
+res = []
+for wrap in (False, True):
+    torch.manual_seed(0)
+    U.GlobalEnv.reset()
+    model = build_model(cfg, loss_cfg, types.SimpleNamespace(vocab_size=28996)).to(dev)
+    # exactly how the reference wraps it [ref: trainer_ddp.py:134]
+    net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[0], find_unused_parameters=True) if wrap else model
+    loss_func = build_loss(loss_cfg)
+    opt = build_optimizer(net, {"name": "adamw", "config": {"lr": 1e-4, "weight_decay": 1e-4}})
+    losses = []
+    for step in range(2):                      # the reference's hot loop [ref: trainer_ddp.py:279-308]
+        opt.zero_grad(set_to_none=True)
+        net.train()
+        out = net(bt, dev)
+        ld = loss_func(**out, is_train=True)
+        ld["total"].backward()
+        opt.step()
+        losses.append(float(ld["total"]))
+    sd = {k.replace("module.", ""): v.detach().clone() for k, v in net.state_dict().items()}
+    pooler = dict(model.named_parameters())["text_encoder.text_encoder.pooler.dense.weight"].grad
+    assert pooler is None or float(pooler.abs().max()) == 0.0          # unused parameter: tolerated by find_unused_parameters
+    res.append((losses, sd))
+(l0, s0), (l1, s1) = res
+assert l0[0] == l1[0], (l0, l1)
+assert abs(l0[1] - l1[1]) < 5e-3, (l0, l1)
+worst = max(float((s0[k].float() - s1[k].float()).abs().max()) for k in s0)
+assert worst < 5e-3, worst
+dist.destroy_process_group()
+print("DDP-OK", l0, l1, worst)
+'''
+
+
+@pytest.mark.gpu
+def test_model_under_torch_ddp_find_unused_parameters(tmp_path):
+    """INTEGRATION.md claim: the model drops into the reference's trainer unchanged -- wrapped in torch's
+    DistributedDataParallel(find_unused_parameters=True) [ref: trainer_ddp.py:134] over RCCL (world size 1 here), two
+    steps of the reference's loop order with the HIP AdamW give the same losses and parameters as the unwrapped model."""
+    script = tmp_path / "ddp.py"
+    script.write_text(WORKER_DDP)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, str(script), ROOT, "29889"], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0 and "DDP-OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])

@@ -210,6 +210,24 @@ def test_build_scheduler_matches_reference_config_shapes():
         build_scheduler(opt(), {"name": "step", "config": {}})
 
 
+def test_custom_ops_registered_with_torch_library():
+    """the kernels are dispatcher-visible operators (``torch.ops.mammoclip.*``) with schemas and fake (meta)
+    implementations; the real implementation exists for device type cuda only (CPU tensors raise: no fallback)."""
+    import mammo_clip_amd.custom_ops as co
+    for name in co.OPS:
+        assert hasattr(torch.ops.mammoclip, name), name
+    x = torch.empty(10, 16, dtype=torch.bfloat16, device="meta")
+    w = torch.empty(24, 16, dtype=torch.bfloat16, device="meta")
+    assert torch.ops.mammoclip.linear(x, w).shape == (10, 24)
+    assert torch.ops.mammoclip.linear_wgrad(torch.empty(10, 24, dtype=torch.bfloat16, device="meta"), x).dtype == torch.float32
+    d = torch.ops.mammoclip.dwconv(torch.empty(2 * 6 * 6, 8, dtype=torch.bfloat16, device="meta"),
+                                   torch.empty(9, 8, device="meta"), 2, 6, 6, 3, 2, 0, 0, 3, 3)
+    assert d.shape == (2 * 3 * 3, 8)
+    assert "Tensor? bias=None" in str(torch.ops.mammoclip.linear.default._schema)
+    with pytest.raises(NotImplementedError):
+        torch.ops.mammoclip.linear(torch.zeros(4, 8, dtype=torch.bfloat16), torch.zeros(8, 8, dtype=torch.bfloat16))
+
+
 class _ToyModel(torch.nn.Module):
     def forward(self, batch, device=None):
         assert not self.training and not torch.is_grad_enabled()

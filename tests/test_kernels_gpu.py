@@ -747,3 +747,29 @@ def test_raw_u8_input_pipeline_vs_reference_fixture():
         assert torch.equal(pa, pb), key
         with torch.no_grad():
             assert torch.equal(enc(ref), enc(ops.RawImages(u8.permute(0, 3, 1, 2), mean, std)))
+
+
+def test_torch_library_custom_ops():
+    """the ``mammoclip::`` operators (custom_ops.py) run the same kernels as the ops.py wrappers, are differentiable where
+    an explicit backward op is registered, and pass torch.library.opcheck (schema, fake tensor, autograd registration)."""
+    import mammo_clip_amd.custom_ops  # noqa: F401
+    x = rnd(300, 64, seed=1).requires_grad_(True)
+    w = rnd(48, 64, seed=2, scale=0.125).requires_grad_(True)
+    b = rnd(48, seed=3, dtype=torch.float32)
+    y = torch.ops.mammoclip.linear(x, w, b)
+    assert torch.equal(y, ops.linear_fwd(x.detach(), w.detach(), bias=b))
+    g = rnd(300, 48, seed=4)
+    y.backward(g)
+    check(x.grad, g.float() @ w.detach().float(), 1e-2, "custom op dx")
+    check(w.grad, g.float().T @ x.detach().float(), 1e-2, "custom op dw")
+    n, h, wd, c, k = 2, 9, 7, 16, 3
+    xi = rnd(n * h * wd, c, seed=5).requires_grad_(True)
+    wk = rnd(k * k, c, seed=6, dtype=torch.float32)
+    yo = torch.ops.mammoclip.dwconv(xi, wk, n, h, wd, k, 1, 1, 1, h, wd)
+    ref = F.conv2d(xi.detach().float().view(n, h, wd, c).permute(0, 3, 1, 2), wk.T.reshape(c, 1, k, k), padding=1, groups=c)
+    check(yo, ref.permute(0, 2, 3, 1).reshape(n * h * wd, c), 1e-2, "custom op dwconv")
+    yo.backward(rnd(n * h * wd, c, seed=7))
+    assert xi.grad is not None and torch.isfinite(xi.grad.float()).all()
+    check(torch.ops.mammoclip.gelu(xi.detach()), F.gelu(xi.detach().float()), 1e-2, "custom op gelu")
+    torch.library.opcheck(torch.ops.mammoclip.linear.default, (x.detach(), w.detach(), b), test_utils=("test_schema", "test_faketensor"))
+    torch.library.opcheck(torch.ops.mammoclip.gelu.default, (xi.detach(),), test_utils=("test_schema", "test_faketensor"))
