@@ -47,6 +47,8 @@ WORKLOADS = {
     "cfg3": ("tf_efficientnet_b5_ns-detect", "efficientnet-b5", 32, 1520, 912, 256),
     # BASELINE config #4: GLOBAL batch 1024 (strong scaling: 1024 / N pairs per GPU, in micro-batches of 32)
     "cfg4": ("tf_efficientnet_b5_ns-detect", "efficientnet-b5", 1024, 1520, 912, 256),
+    # BASELINE config #5: cfg4's model with fp8 (OCP e4m3) operands for the late-stage 1x1 convolutions, GLOBAL batch 2048
+    "cfg5": ("tf_efficientnet_b5_ns-detect", "efficientnet-b5", 2048, 1520, 912, 256),
 }
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 MFMA_PEAK_TFS = 2500.0         # dense bf16 MFMA peak
@@ -64,9 +66,9 @@ ROOFLINE_KERNEL = "bnact_bwd_k<true> (BatchNorm+SiLU backward apply pass)"
 STREAM_OPS = (ROOFLINE_OP, "mc_gemm_bf16")
 
 
-def model_cfg(enc_name):
+def model_cfg(enc_name, fp8=False):
     return {"name": "clip_custom", "temperature": 0.07,
-            "image_encoder": {"source": "cnn", "name": enc_name, "pretrained": True, "model_type": "cnn"},
+            "image_encoder": {"source": "cnn", "name": enc_name, "pretrained": True, "model_type": "cnn", "fp8": fp8},
             "text_encoder": {"source": "huggingface", "name": "emilyalsentzer/Bio_ClinicalBERT", "pretrained": False,
                              "gradient_checkpointing": False, "pooling": "eos", "cache_dir": "", "trust_remote_code": True},
             "projection_head": {"name": "linear", "dropout": 0.1, "proj_dim": 512}}
@@ -122,6 +124,7 @@ def main():
     ap.add_argument("--micro-batches", type=int, default=1,
                     help="cut the per-GPU batch into k micro-batches (one extra forward per step; for batches beyond one pass)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fp8", action="store_true", help="fp8 (e4m3) operands for the late-stage 1x1 convolutions (config #5 arithmetic on any workload)")
     ap.add_argument("--op-profile", action="store_true", help="print a per-entry-point HIP-event breakdown (rank 0)")
     args = ap.parse_args()
 
@@ -154,14 +157,15 @@ def main():
     enc_name, arch_name, b, H, W, T = WORKLOADS[args.workload]
     if args.batch:
         b = args.batch
-    strong = args.workload == "cfg4" and not args.batch
+    strong = args.workload in ("cfg4", "cfg5") and not args.batch
     if strong:
-        assert 1024 % world == 0
-        b = 1024 // world
+        assert b % world == 0
+        b = b // world
         args.micro_batches = max(1, b // 32)
+    fp8 = args.workload == "cfg5" or args.fp8
     util.GlobalEnv.reset()
     torch.manual_seed(10)
-    model = build_model(model_cfg(enc_name), LOSS_CFG, types.SimpleNamespace(vocab_size=28996)).to(device)
+    model = build_model(model_cfg(enc_name, fp8), LOSS_CFG, types.SimpleNamespace(vocab_size=28996)).to(device)
     loss_func = build_loss(LOSS_CFG)
     opt = build_optimizer(model, {"name": "adamw", "config": {"lr": 5e-5, "weight_decay": 1e-4}})
     sched = LinearWarmupCosineAnnealingLR(opt, total_steps=10000, warmup_steps=100)
@@ -225,7 +229,7 @@ def main():
             "metric": "image-text pairs/s (whole node), EN-B5+BioClinicalBERT contrastive pre-training step",
             "value": round(pairs, 3), "unit": "image-text pairs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "strong" if strong else "weak",
-            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "vs_baseline": None, "dtype": "bf16" + (" + fp8 e4m3 pointwise-conv operands" if fp8 else ""), "data": "synthetic",
             "config": {"workload": f"{args.workload}: {arch_name} + BioClinicalBERT(BERT-base), {b} pairs/GPU "
                                    f"(2 views + 2 reports each), {H}x{W} images, {T}-token reports, breast_clip loss, "
                                    f"AdamW; fwd+loss+bwd+optimizer; dropout/drop-connect on",

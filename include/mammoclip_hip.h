@@ -77,6 +77,13 @@ typedef struct mc_gemm_args {
     long long split_group_rows;
     int split_sub;
     const float* split_scale;
+    /* fp8 operands (BASELINE config #5: fp8 weights / activations for the pointwise convolutions,
+     * efficientnet_custom.py:104,122,283): A and B hold OCP e4m3 bytes (gfx950's fp8, NOT the fnuz form), lda / ldb /
+     * strides in elements (= bytes), K, lda, ldb multiples of 16; plain NT layout, bf16 output, fp32 accumulation
+     * (v_mfma_f32_16x16x32_fp8_fp8).  The product of the two per-tensor dequantisation scales is passed in alpha and/or
+     * alpha_dev (device scalar, multiplied onto alpha; produced by mc_quant_fp8_bf16 without a host round trip). */
+    int ab_fp8;
+    const float* alpha_dev;
 } mc_gemm_args;
 int mc_gemm_bf16(const mc_gemm_args* args, void* stream);
 /* rows of the stat_partials buffer the launch described by `args` (the COMPLETE argument block) will write */
@@ -84,6 +91,15 @@ int mc_gemm_stat_rows(const mc_gemm_args* args);
 /* which tile kernel serves `args`: 256 = the 256 x 256 x 64 direct-to-LDS kernel (gemm256.hip: plain NT operands, bf16
  * output, enough well-filled tiles for the 256 CUs), 128 = the 128-row tile family (gemm.hip) */
 int mc_gemm_tile_config(const mc_gemm_args* args);
+
+/* fp8 operand preparation (BASELINE config #5; OCP e4m3 as implemented by gfx950).
+ * mc_amax_bf16:       amax[0] = max(amax[0], max |x|)   (caller zero-fills amax; integer atomic, deterministic)
+ * mc_quant_fp8_bf16:  y = e4m3(clamp(x * 448 / amax_in[0], +-448));  scale_out[0] = amax_in[0] / 448 (the dequantisation
+ *                     scale, optional);  amax_next[0] = max(amax_next[0], max |x|) (optional: delayed scaling measures the
+ *                     tensor it converts);  n % 8 == 0, contiguous. */
+int mc_amax_bf16(const mc_bf16* x, long long n, float* amax, void* stream);
+int mc_quant_fp8_bf16(const mc_bf16* x, long long n, const float* amax_in, unsigned char* y, float* scale_out,
+                      float* amax_next, void* stream);
 
 /* Row-streaming variant for the HBM-bound 1x1 convolutions (small weight matrix, millions of pixels):
  *   C[M,N] = pro(X)[M,K] . W[N,K]^T (+ R);  N <= 256, K <= 384 (mc_gemm_rows_supported), bf16 in/out.

@@ -155,7 +155,12 @@ class _MBConvFn(torch.autograd.Function):
         saved = {}
         if a.expand != 1:
             we = ops.cast_bf16(blk._expand_conv.weight.view(a.cexp, a.cin))
-            e, part0 = ops.linear_fwd(x, we, stats=True)
+            if blk.fp8 and a.cin % 16 == 0 and not ops._rows_ok(n * hw, a.cexp, a.cin, None, 0):
+                # config #5: fp8 (e4m3, per-tensor scale) activations and weights on the fp8 MFMA; BatchNorm statistics
+                # and everything downstream stay on the bf16 / fp32 path; backward uses the bf16 tensors (straight-through)
+                e, part0 = ops.linear_fwd_fp8(x, we, stats=True)
+            else:
+                e, part0 = ops.linear_fwd(x, we, stats=True)
             st0 = _bn_stats(part0, n * hw, blk._bn0, training)
             dw_in, pro0 = e, (st0.scale, st0.shift)
             saved.update(we=we, e=e, st0=st0)
@@ -174,7 +179,10 @@ class _MBConvFn(torch.autograd.Function):
         gate = ops.se_fwd(pooled, blk._se_reduce.weight.view(a.cse, a.cexp), blk._se_reduce.bias,
                           blk._se_expand.weight.view(a.cexp, a.cse), blk._se_expand.bias)
         wp = ops.cast_bf16(blk._project_conv.weight.view(a.cout, a.cexp))
-        if keep:
+        if keep and blk.fp8 and a.cexp % 16 == 0 and a.cout > 64:
+            wg = ops.gate_weights(wp, gate)                       # [n, cout, cexp] bf16: the SE gate folded into the weights
+            p, part2 = ops.linear_fwd_fp8(act1, wg, stats=True, batch_w=(n, ohw))
+        elif keep:
             p, part2 = ops.linear_fwd(act1, wp, stats=True, pro=(None, None, gate, ohw))
         else:
             p, part2 = ops.linear_fwd(d, wp, stats=True, pro=(st1.scale, st1.shift, gate, ohw))
@@ -258,7 +266,10 @@ class _HeadFn(torch.autograd.Function):
     def forward(ctx, x, w, gamma, beta, mod, n, h, wd):
         cin, cout = w.shape[1], w.shape[0]
         wb = ops.cast_bf16(w.view(cout, cin))
-        e, part = ops.linear_fwd(x, wb, stats=True)
+        if mod.fp8 and cin % 16 == 0:
+            e, part = ops.linear_fwd_fp8(x, wb, stats=True)
+        else:
+            e, part = ops.linear_fwd(x, wb, stats=True)
         st = _bn_stats(part, n * h * wd, mod._bn1, mod.training)
         pooled = ops.bnact_pool(e, n, h * wd, cout, st.scale, st.shift, 1)
         ctx.mod, ctx.st, ctx.geo = mod, st, (n, h, wd, cin, cout)
@@ -344,6 +355,7 @@ class MBConvBlock(nn.Module):
                          _static_pad(image_size, a.kernel_size, s),
                          bool(a.id_skip and s == 1 and cin == a.output_filters))
         self._param_names = [n for n, _ in self.named_parameters()]
+        self.fp8 = False
         self.register_buffer("_ones", torch.ones(cin), persistent=False)
         self.register_buffer("_zeros", torch.zeros(cin), persistent=False)
 
@@ -383,6 +395,7 @@ class EfficientNet(nn.Module):
         self._bn1 = _BN(head_out)
         self._dropout_p = gp.dropout_rate if gp.include_top else 0.0
         self.out_dim = head_out
+        self.fp8 = False
         self.rng = _Seeds()
         self.register_buffer("_ones_b", torch.ones(1), persistent=False)
 
@@ -424,6 +437,15 @@ class EfficientNet(nn.Module):
     def _check_model_name_is_valid(cls, model_name):
         if model_name not in VALID_MODELS:
             raise ValueError("model_name should be one of: " + ", ".join(VALID_MODELS))
+
+    def set_fp8(self, on: bool = True):
+        """BASELINE config #5: forward of the late-stage 1x1 convolutions (expand / project / head on the tiled MFMA path)
+        with per-tensor-scaled OCP e4m3 activations and weights on gfx950's fp8 MFMA [ref: efficientnet_custom.py:104,
+        122,283 are the convolutions concerned]; statistics, depthwise stages and the whole backward stay bf16 / fp32."""
+        self.fp8 = bool(on)
+        for blk in self._blocks:
+            blk.fp8 = bool(on)
+        return self
 
     def set_swish(self, memory_efficient=True):
         """No-op: the swish is always the fused, recompute-in-backward form."""

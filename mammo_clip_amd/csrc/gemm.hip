@@ -866,6 +866,7 @@ extern "C" int mc_gemm_bf16(const mc_gemm_args* a, void* stream) {
     MC_CHECK(!p.R || (!p.c_f32 && p.ldr % 8 == 0), "gemm: residual needs bf16 output and ldr % 8 == 0");
     if (p.alpha == 0.f) p.alpha = 1.f;
     if (mc_gemm256_eligible(&p)) return mc_gemm256_launch(&p, stream);
+    MC_CHECK(!p.ab_fp8 && !p.alpha_dev, "gemm: fp8 operands / alpha_dev need the plain NT bf16-output form (gemm256)");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int grid_m = pick_grid_m(p);
     const int lay = p.a_kmajor ? 2 : (p.b_kmajor ? 1 : 0);

@@ -82,8 +82,8 @@ __device__ unsigned long long g_g256_prof[2][12];   // developer phase profile (
 
 // position of one K tile in the flat stream of a workgroup (all wave-uniform)
 struct TilePos {
-    const bf16_t* a;        // A + z*sA + m0*lda + k0
-    const bf16_t* b;        // B + z*sB + n0*ldb + k0
+    const unsigned char* a; // A + (z*sA + m0*lda + k0) elements
+    const unsigned char* b; // B + (z*sB + n0*ldb + k0) elements
     int mrem, nrem, krem;   // rows / columns / k left from (m0, n0, k0)
     bool valid;
 };
@@ -102,8 +102,16 @@ __device__ __forceinline__ void item_coords(const Work& w, long long it, int& z,
     mt = (int)(unit - (long long)z * w.MT);
 }
 
-template <bool STATS>
+// FP8: the operands are OCP e4m3 bytes (per-tensor scaled; the product of the two dequantisation scales arrives through
+// alpha / alpha_dev).  A K tile is still 128 BYTES per row -- 128 fp8 values -- so staging, LDS image and fragment reads are
+// byte for byte those of the bf16 kernel; a 16-byte fragment read holds 16 consecutive k values of the lane's row and
+// feeds TWO v_mfma_f32_16x16x32_fp8_fp8 (bytes 0-7 and 8-15: the k order inside the 128-deep tile is a permutation that
+// A and B share, which a dot product does not see).  Twice the flops per staged byte of the bf16 kernel.
+template <bool STATS, bool FP8>
 __global__ __launch_bounds__(NTHR, 2) void gemm256_kernel(const mc_gemm_args p, const int MT, const int NTl, const int ktn) {
+    constexpr int ES = FP8 ? 1 : 2;             // bytes per operand element
+    constexpr int KT = 128 / ES;                // K tile in elements (128 bytes per LDS row)
+    constexpr int CH = 16 / ES;                 // elements per 16-byte chunk
     __shared__ __attribute__((aligned(1024))) unsigned char smem[LDS_BYTES];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -125,11 +133,11 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256_kernel(const mc_gemm_args p, 
         q.valid = it < wk.n_items;
         int z = 0, mt = 0, nt = 0;
         if (q.valid) item_coords(wk, it, z, mt, nt);
-        const long long m0 = (long long)mt * BM, n0 = (long long)nt * BN, k0 = (long long)kt * BK;
-        q.a = p.A + (long long)z * p.sA1 + m0 * p.lda + k0;
-        q.b = p.B + (long long)z * p.sB1 + n0 * p.ldb + k0;
+        const long long m0 = (long long)mt * BM, n0 = (long long)nt * BN, k0 = (long long)kt * KT;
+        q.a = reinterpret_cast<const unsigned char*>(p.A) + ((long long)z * p.sA1 + m0 * p.lda + k0) * ES;
+        q.b = reinterpret_cast<const unsigned char*>(p.B) + ((long long)z * p.sB1 + n0 * p.ldb + k0) * ES;
         const long long mr = p.M - m0, nr = p.N - n0, kr = p.K - k0;
-        q.mrem = mr > BM ? BM : (int)mr; q.nrem = nr > BN ? BN : (int)nr; q.krem = kr > BK ? BK : (int)kr;
+        q.mrem = mr > BM ? BM : (int)mr; q.nrem = nr > BN ? BN : (int)nr; q.krem = kr > KT ? KT : (int)kr;
         return q;
     };
 
@@ -149,8 +157,8 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256_kernel(const mc_gemm_args p, 
     {
         int ra, rb, ck;
         geo(0, 0, ra, rb, ck);
-        voffA = (unsigned)((ra * p.lda + ck * 8) * 2);
-        voffB = (unsigned)((rb * p.ldb + ck * 8) * 2);
+        voffA = (unsigned)((ra * p.lda + ck * CH) * ES);
+        voffB = (unsigned)((rb * p.ldb + ck * CH) * ES);
     }
     typedef __attribute__((address_space(3))) unsigned int lds_u32_t;
     const unsigned smem_lds = (unsigned)(uintptr_t)(lds_u32_t*)smem;
@@ -165,11 +173,11 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256_kernel(const mc_gemm_args p, 
         if (q.valid) return;                    // diagnostic build: fragments + MFMA speed with no fill traffic (wrong results)
 #endif
         const unsigned dst = smem_lds + buf * STAGE_BYTES + which * HALF_BYTES;
-        const bool full = q.mrem == BM && q.nrem == BN && q.krem == BK;
+        const bool full = q.mrem == BM && q.nrem == BN && q.krem == KT;
         if (full) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                const bf16_t* sb = isA ? q.a + (long long)(i * 128 + h * 64) * p.lda : q.b + (long long)(i * 128 + h * 32) * p.ldb;
+                const unsigned char* sb = isA ? q.a + (long long)(i * 128 + h * 64) * p.lda * ES : q.b + (long long)(i * 128 + h * 32) * p.ldb * ES;
                 glds16_s(isA ? voffA : voffB, sb, dst + (unsigned)((i * 8 + wave) * 1024));
             }
         } else {
@@ -183,9 +191,9 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256_kernel(const mc_gemm_args p, 
                 int ra, rb, ck;
                 geo(i, h, ra, rb, ck);
                 const int rr = isA ? (ra < q.mrem ? ra : q.mrem - 1) : (rb < q.nrem ? rb : q.nrem - 1);
-                const unsigned voff = (unsigned)((rr * (isA ? p.lda : p.ldb) + ck * 8) * 2);
+                const unsigned voff = (unsigned)((rr * (isA ? p.lda : p.ldb) + ck * CH) * ES);
                 const unsigned d = dst + (unsigned)((i * 8 + wave) * 1024);
-                if (ck * 8 < q.krem) glds16_s(voff, isA ? q.a : q.b, d);
+                if (ck * CH < q.krem) glds16_s(voff, isA ? q.a : q.b, d);
                 else *reinterpret_cast<uint4*>(smem + (d - smem_lds) + lane * 16) = make_uint4(0u, 0u, 0u, 0u);
             }
         }
@@ -239,15 +247,32 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256_kernel(const mc_gemm_args p, 
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[ih * 4 + i][jh * 2 + j] =
-                        __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j][kk], af[i][kk], acc[ih * 4 + i][jh * 2 + j], 0, 0, 0);
+                for (int j = 0; j < 2; ++j) {
+                    if constexpr (FP8) {
+                        typedef __attribute__((ext_vector_type(2))) long l2_t;
+                        const l2_t a2 = __builtin_bit_cast(l2_t, af[i][kk]), b2 = __builtin_bit_cast(l2_t, bf[j][kk]);
+                        f32x4_t c = acc[ih * 4 + i][jh * 2 + j];
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(b2[0], a2[0], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(b2[1], a2[1], c, 0, 0, 0);
+                        acc[ih * 4 + i][jh * 2 + j] = c;
+                    } else {
+                        acc[ih * 4 + i][jh * 2 + j] =
+                            __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j][kk], af[i][kk], acc[ih * 4 + i][jh * 2 + j], 0, 0, 0);
+                    }
+                }
 #ifndef G256_NOPRIO
         __builtin_amdgcn_s_setprio(0);
 #endif
     };
 
-    const float alpha = p.alpha;
+    // alpha_dev: a device-resident factor (the product of the fp8 dequantisation scales); read through the scalar cache
+    // and pinned before the loop (a vector load pending at the loop head would drain the DMA stream, see the epilogue)
+    float alpha = p.alpha;
+    if (p.alpha_dev) {
+        alpha *= __builtin_nontemporal_load(p.alpha_dev);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        asm volatile("" : "+v"(alpha));
+    }
 
     // current (consumed) item
     long long cit = 0;
@@ -527,9 +552,10 @@ static int g256_mode() { const char* e = getenv("MC_GEMM_256"); return e ? atoi(
 extern "C" int mc_gemm256_eligible(const mc_gemm_args* a) {
     const mc_gemm_args& p = *a;
     const int mode = g256_mode();
-    if (mode == 0) return 0;
+    if (mode == 0 && !p.ab_fp8) return 0;
     if (p.a_kmajor || p.b_kmajor || p.c_f32 || p.pro_operand != 0 || p.splits > 1 || p.nb2 > 1) return 0;
     if (p.lda * 128 + 64 >= (1LL << 30) || p.ldb * 128 + 64 >= (1LL << 30)) return 0;      // 32-bit lane byte offsets
+    if (p.ab_fp8) return 1;                     // the fp8 operand path exists only here
     if (mode == 2) return 1;
     if (p.N < 96 || p.K < 64 || p.M < 256) return 0;
     const long long MT = (p.M + 255) / 256, NTl = (p.N + 255) / 256;
@@ -554,11 +580,16 @@ extern "C" int mc_gemm256_launch(const mc_gemm_args* a, void* stream) {
     mc_gemm_args p = *a;
     if (p.batch <= 0) p.batch = 1;
     if (p.alpha == 0.f) p.alpha = 1.f;
-    const int MT = (int)((p.M + 255) / 256), NTl = (int)((p.N + 255) / 256), ktn = (int)((p.K + 63) / 64);
+    const int kt_el = p.ab_fp8 ? 128 : 64;
+    const int MT = (int)((p.M + 255) / 256), NTl = (int)((p.N + 255) / 256), ktn = (int)((p.K + kt_el - 1) / kt_el);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const dim3 grid(256), block(g256::NTHR);
-    if (p.stat_partials) hipLaunchKernelGGL((g256::gemm256_kernel<true>), grid, block, 0, st, p, MT, NTl, ktn);
-    else hipLaunchKernelGGL((g256::gemm256_kernel<false>), grid, block, 0, st, p, MT, NTl, ktn);
+    if (p.ab_fp8) {
+        MC_CHECK(p.K % 16 == 0 && p.lda % 16 == 0 && p.ldb % 16 == 0, "gemm (fp8 operands): K, lda, ldb must be multiples of 16");
+        if (p.stat_partials) hipLaunchKernelGGL((g256::gemm256_kernel<true, true>), grid, block, 0, st, p, MT, NTl, ktn);
+        else hipLaunchKernelGGL((g256::gemm256_kernel<false, true>), grid, block, 0, st, p, MT, NTl, ktn);
+    } else if (p.stat_partials) hipLaunchKernelGGL((g256::gemm256_kernel<true, false>), grid, block, 0, st, p, MT, NTl, ktn);
+    else hipLaunchKernelGGL((g256::gemm256_kernel<false, false>), grid, block, 0, st, p, MT, NTl, ktn);
     MC_LAUNCH_CHECK();
     return MC_OK;
 }

@@ -33,6 +33,7 @@ class GemmArgs(C.Structure):
         ("max_grid_m", I),
         ("splitk_ws", P),
         ("split_group_rows", LL), ("split_sub", I), ("split_scale", P),
+        ("ab_fp8", I), ("alpha_dev", P),
     ]
 
 
@@ -86,6 +87,8 @@ _SIGS = {
     "mc_gemm_bf16": ([C.POINTER(GemmArgs), P], I),
     "mc_gemm_stat_rows": ([C.POINTER(GemmArgs)], I),
     "mc_gemm_tile_config": ([C.POINTER(GemmArgs)], I),
+    "mc_amax_bf16": ([P, LL, P, P], I),
+    "mc_quant_fp8_bf16": ([P, LL, P, P, P, P, P], I),
     "mc_gemm_rows_supported": ([I, I], I),
     "mc_gemm_rows_blocks": ([LL], I),
     "mc_gemm_rows_bf16": ([C.POINTER(GemmRowsArgs), P], I),

@@ -42,7 +42,8 @@ def empty(shape, dtype, like):
 # ------------------------------------------------------------------------------------------- GEMM
 def gemm(A, B, C_out, M, N, K, lda, ldb, ldc, a_kmajor=0, b_kmajor=0, c_f32=0, c_atomic=0, splits=1,
          batch=1, nb2=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), bias=None, bias_stride1=0, act=0, R=None, ldr=0,
-         alpha=1.0, pro=None, stat_partials=None, max_grid_m=0, splitk_ws=None, split_groups=None, kind=None, stats=False):
+         alpha=1.0, pro=None, stat_partials=None, max_grid_m=0, splitk_ws=None, split_groups=None, kind=None, stats=False,
+         ab_fp8=0, alpha_dev=None):
     """pro = (operand, scale, shift, gate or None, rows_per_img, nch); split_groups = (rows per group, sub-splits, scale)
     stats=True: allocates and returns the [rows, 2, N] column sum / sum-of-squares partials of C (the row count depends on
     the tile configuration the library picks for this problem: mc_gemm_stat_rows on the complete argument block)"""
@@ -55,6 +56,7 @@ def gemm(A, B, C_out, M, N, K, lda, ldb, ldc, a_kmajor=0, b_kmajor=0, c_f32=0, c
     a.sA1, a.sA2, a.sB1, a.sB2, a.sC1, a.sC2 = sA[0], sA[1], sB[0], sB[1], sC[0], sC[1]
     a.bias, a.bias_stride1, a.act = _p(bias), bias_stride1, act
     a.R, a.ldr, a.alpha = _p(R), ldr, alpha
+    a.ab_fp8, a.alpha_dev = ab_fp8, _p(alpha_dev)
     if pro is not None:
         a.pro_operand = pro[0]
         a.pro_scale, a.pro_shift, a.pro_gate = _p(pro[1]), _p(pro[2]), _p(pro[3])
@@ -67,7 +69,8 @@ def gemm(A, B, C_out, M, N, K, lda, ldb, ldc, a_kmajor=0, b_kmajor=0, c_f32=0, c
     if stats:
         stat_partials = empty((L.load().mc_gemm_stat_rows(C.byref(a)), 2, N), torch.float32, C_out)
         a.stat_partials = _p(stat_partials)
-    _note(batch * (2 * M * K + 2 * N * K + (4 if c_f32 else 2) * M * N + (2 * M * N if R is not None else 0)),
+    es = 1 if ab_fp8 else 2
+    _note(batch * (es * M * K + es * N * K + (4 if c_f32 else 2) * M * N + (2 * M * N if R is not None else 0)),
           2 * batch * M * N * K)
     if L.TIMER is not None and not a_kmajor and not b_kmajor and pro is None and N > 64 and K > 48 and not c_f32:
         # plain NT direct-to-LDS MFMA tiles: gemm256_kernel (256 x 256) or gemm_kernel<128,128,64,2,2,0,0,false,true>
@@ -80,6 +83,47 @@ def gemm_stat_rows(M, N=128, batch=1):
     a = L.GemmArgs()
     a.M, a.N, a.batch = M, N, batch
     return L.load().mc_gemm_stat_rows(C.byref(a))
+
+
+# ------------------------------------------------------------------------------------------- fp8 (config #5)
+def amax_bf16(x, out=None):
+    """max |x| of a contiguous bf16 tensor -> float32 [1] on the device"""
+    x = x.contiguous()
+    if out is None:
+        out = torch.zeros(1, dtype=torch.float32, device=x.device)
+    L.call("mc_amax_bf16", _p(x), x.numel(), _p(out), _st())
+    return out
+
+
+def quant_fp8(x, amax, amax_next=None):
+    """bf16 -> OCP e4m3 bytes with the per-tensor scale 448 / amax.  Returns (q uint8 like x, dequantisation scale [1])."""
+    x = x.contiguous()
+    q = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+    scale = torch.empty(1, dtype=torch.float32, device=x.device)
+    L.call("mc_quant_fp8_bf16", _p(x), x.numel(), _p(amax), _p(q), _p(scale), _p(amax_next), _st())
+    return q, scale
+
+
+def linear_fwd_fp8(x, w, amax_x=None, amax_w=None, stats=False, batch_w=None):
+    """y[M,N] (bf16) = dequant( e4m3(x)[M,K] . e4m3(w)[N,K]^T ) -- fp8 operands on v_mfma_f32_16x16x32_fp8_fp8, fp32
+    accumulation.  amax_*: device scalars (None: measured on the tensor now).  batch_w = (n_img, rows per image): ``w`` is
+    [n_img, N, K] with one matrix per image (the gated projection weights).  Returns y (, column statistics partials)."""
+    M, K = x.shape
+    N = w.shape[-2]
+    assert K % 16 == 0, "fp8 operands: K must be a multiple of 16"
+    ax = amax_x if amax_x is not None else amax_bf16(x)
+    aw = amax_w if amax_w is not None else amax_bf16(w)
+    xq, sx = quant_fp8(x, ax)
+    wq, sw = quant_fp8(w, aw)
+    y = empty((M, N), BF16, x)
+    a = dict(ab_fp8=1, alpha_dev=sx * sw)
+    if batch_w is not None:
+        n_img, hw = batch_w
+        part = gemm(xq, wq, y, hw, N, K, K, K, N, batch=n_img, sA=(hw * K, 0), sB=(N * K, 0), sC=(hw * N, 0), stats=stats,
+                    kind="fwd_fp8", **a)
+    else:
+        part = gemm(xq, wq, y, M, N, K, K, K, N, stats=stats, kind="fwd_fp8", **a)
+    return (y, part) if stats else y
 
 
 ROWS_MIN_M = 8192       # below this the tiled kernel is as good
@@ -199,6 +243,15 @@ def linear_fwd(x, w, bias=None, act=0, residual=None, stats=False, pro=None, out
     part = gemm(x, w, y, M, N, K, x.stride(0), w.stride(0), y.stride(0), bias=bias, act=act, R=residual,
                 ldr=(residual.stride(0) if residual is not None else 0), pro=p, stats=stats, kind="fwd")
     return (y, part) if stats else y
+
+
+def gate_weights(w, gate):
+    """per-image gated copies of a weight matrix: out[i, n, k] = w[n, k] * gate[i, k]  (bf16)"""
+    N, K = w.shape
+    n_img = gate.shape[0]
+    wg = empty((n_img, N, K), BF16, w)
+    L.call("mc_gate_weights_bf16", _p(w), _p(gate), n_img, N, K, _p(wg), _st())
+    return wg
 
 
 def linear_dgrad(dy, w, residual=None, w_t=None):

@@ -773,3 +773,44 @@ def test_torch_library_custom_ops():
     check(torch.ops.mammoclip.gelu(xi.detach()), F.gelu(xi.detach().float()), 1e-2, "custom op gelu")
     torch.library.opcheck(torch.ops.mammoclip.linear.default, (x.detach(), w.detach(), b), test_utils=("test_schema", "test_faketensor"))
     torch.library.opcheck(torch.ops.mammoclip.gelu.default, (xi.detach(),), test_utils=("test_schema", "test_faketensor"))
+
+
+def _e4m3(x, amax):
+    """torch reference of the per-tensor e4m3 quantisation: dequantised values and the scale"""
+    scale = 448.0 / amax
+    q = (x.float() * scale).clamp(-448.0, 448.0).to(torch.float8_e4m3fn)
+    return q.float() / scale
+
+
+@pytest.mark.parametrize("M,N,K", [(3000, 1824, 304), (4096, 512, 3072), (700, 304, 1824), (256, 2048, 512), (5000, 96, 48)])
+def test_fp8_quant_and_gemm(M, N, K):
+    """config #5 building blocks: (1) the quantisation kernel reproduces torch's float8_e4m3fn conversion (OCP e4m3, the
+    format gfx950's fp8 MFMA reads) byte for byte; (2) the fp8 GEMM equals the fp32 product of the DEQUANTISED operands
+    up to the bf16 rounding of its output (<= 1e-2 of max|ref|): every fp8 x fp8 product is exact in fp32."""
+    x, w = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5)
+    ax, aw = ops.amax_bf16(x), ops.amax_bf16(w)
+    assert float(ax) == float(x.float().abs().max()) and float(aw) == float(w.float().abs().max())
+    xq, sx = ops.quant_fp8(x, ax)
+    refq = (x.float() * (448.0 / float(ax))).clamp(-448.0, 448.0).to(torch.float8_e4m3fn)
+    assert torch.equal(xq.view(torch.uint8), refq.view(torch.uint8))
+    assert abs(float(sx) - float(ax) / 448.0) <= 1e-9 * float(ax)
+    y, part = ops.linear_fwd_fp8(x, w, stats=True)
+    ref = _e4m3(x, float(ax)) @ _e4m3(w, float(aw)).T
+    check(y, ref, 1e-2, "fp8 gemm vs dequantised fp32 product")
+    s = part.double().sum(0)
+    check(s[0].float(), y.float().double().sum(0).float(), 1e-4, "fp8 gemm colsum")
+    # and it stays close to the unquantised product (e4m3: 3 mantissa bits -> ~6 % per element, averaging out over K)
+    full = x.float() @ w.float().T
+    assert relerr(y, full) <= 0.08 * (1 + 64.0 / K) ** 0.5 + 0.02, relerr(y, full)
+
+
+def test_fp8_batched_gated_weights():
+    nb, hw, N, K = 5, 700, 304, 1824
+    x, w = rnd(nb * hw, K, seed=7), rnd(N, K, seed=8, scale=K ** -0.5)
+    gate = torch.sigmoid(rnd(nb, K, seed=9, dtype=torch.float32))
+    wg = ops.gate_weights(w, gate)
+    check(wg, (w.float()[None] * gate[:, None, :]), 1e-2, "gated weights")
+    y = ops.linear_fwd_fp8(x, wg, batch_w=(nb, hw))
+    ax, aw = float(x.float().abs().max()), float(wg.float().abs().max())
+    ref = torch.einsum("bmk,bnk->bmn", _e4m3(x, ax).view(nb, hw, K), _e4m3(wg, aw)).reshape(nb * hw, N)
+    check(y, ref, 1e-2, "fp8 batched gemm")

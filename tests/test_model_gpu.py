@@ -411,3 +411,51 @@ def test_micro_batched_step_matches_full_graph():
     assert int(dict(model2.named_buffers())["image_encoder._bn0.num_batches_tracked"]) == 2 * k
     # the seed counters continue where the first pass left them
     assert model2.image_encoder.rng.calls == model.image_encoder.rng.calls
+
+
+def test_fp8_pointwise_convs_config5():
+    """BASELINE config #5 arithmetic: the late-stage 1x1 convolutions (expand / project / head on the tiled MFMA path) with
+    per-tensor-scaled OCP e4m3 activations and weights.  Same weights and batch as the B5 golden case: the fp8 model must
+    stay close to the REFERENCE's fp32 outputs (eval: per-row cosine >= 0.998, |loss - reference| <= 2e-2; e4m3 carries 3
+    mantissa bits, ~6 % per element, averaged over K >= 64 products per output) and close to the bf16 HIP model; a train
+    step must run with finite gradients everywhere (backward uses the bf16 operands: straight-through).  The GEMM itself
+    is held to the dequantised-operand product in test_kernels_gpu.py::test_fp8_quant_and_gemm."""
+    z = np.load(os.path.join(GOLDEN, "e2e_b5_small.npz"))
+    b, H, W, T = [int(v) for v in z["meta"]]
+    model, lossf, sd = _build("tf_efficientnet_b5_ns-detect", "efficientnet-b5")
+    batch = ow.synth_batch(b, H, W, T, seed=10)
+    embs = ("image_embeddings", "image_view_embeddings")
+    with torch.no_grad():
+        out16, ld16 = _run(model, lossf, batch, False)
+        e16 = {k: out16[k].clone() for k in embs}
+    model.image_encoder.set_fp8(True)
+    assert all(blk.fp8 for blk in model.image_encoder._blocks)
+    from mammo_clip_amd import lib as L
+    calls = []
+    orig = L.call
+
+    def spy(name, *a, kind=None):
+        calls.append((name, kind))
+        return orig(name, *a, kind=kind)
+    L.call = spy
+    try:
+        with torch.no_grad():
+            out8, ld8 = _run(model, lossf, batch, False)
+    finally:
+        L.call = orig
+    n8 = sum(1 for nme, kd in calls if nme == "mc_gemm_bf16" and kd and "fwd_fp8" in kd)
+    assert n8 >= 2 * 30, n8                      # expand + project of the 16-aligned blocks and the head, both views
+    rep = {"loss(fp8, bf16, ref)": (float(ld8["total"]), float(ld16["total"]), float(z["eval/total"]))}
+    for k in embs:
+        rep[k] = (_cos(out8[k], z["eval/" + k]), _cos(out8[k], e16[k]))
+        assert rep[k][0] >= 0.998 and rep[k][1] >= 0.998, rep
+    assert abs(float(ld8["total"]) - float(z["eval/total"])) <= 2e-2, rep
+    assert not torch.equal(out8["image_embeddings"], e16["image_embeddings"])      # the fp8 path really ran
+    model.train()
+    model.zero_grad(set_to_none=True)
+    out, ld = _run(model, lossf, batch, True)
+    ld["total"].backward()
+    assert torch.isfinite(ld["total"])
+    for n, p in model.named_parameters():
+        assert p.grad is None or torch.isfinite(p.grad).all(), n
+    print("fp8", rep, float(ld["total"]))
