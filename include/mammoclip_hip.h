@@ -198,6 +198,15 @@ typedef struct mc_dwconv_args {
     const float* pro_scale;
     const float* pro_shift;
     float* stat_partials;
+    /* mc_dwconv_fwd only, stride 1: BatchNorm(+SiLU)-backward epilogue for the launch that computes the DATA GRADIENT of
+     * a stride-1 depthwise conv as a forward conv on flipped taps.  epi_x = the conv output e [n,oh,ow,c] that fed
+     * silu(bn(e)); the kernel then writes dZ = y * silu'(e*epi_scale + epi_shift) instead of y and stat_partials receives
+     * [rows][2][c] = (sum dZ, sum dZ * (e - epi_mean) * epi_invstd), the input of mc_bn_bwd_finalize.  NULL = plain conv. */
+    const mc_bf16* epi_x;
+    const float* epi_scale;
+    const float* epi_shift;
+    const float* epi_mean;
+    const float* epi_invstd;
 } mc_dwconv_args;
 int mc_dwconv_stat_rows(const mc_dwconv_args* args);
 int mc_dwconv_fwd(const mc_dwconv_args* args, void* stream);

@@ -234,12 +234,23 @@ class _MBConvFn(torch.autograd.Function):
             dw_in, pro0 = x, None
         dwdw = ops.dwconv_bwd_weight(dw_in, dd, n, h, w, a.cexp, k, s, l, t, oh, ow, pro=pro0)
         wflip = sv["wkkc"].flip(0).contiguous() if s == 1 else None     # tap order reversed = 180 degree rotation
-        da0 = ops.dwconv_bwd_data(dd, sv["wkkc"], n, h, w, a.cexp, k, s, l, t, oh, ow, w_kkc_flipped=wflip)
-        del dd
         grads = {}
+        if a.expand != 1 and s == 1:
+            # stride 1: the data-gradient kernel finishes the bn0 + swish backward in its epilogue -- it reads e at the
+            # output position, writes dZ0 = dA0 * silu'(bn0(e)) and leaves the BatchNorm-backward reductions behind, so
+            # the separate reduce pass over (e, dA0) is gone and the apply pass is a plain linear combination
+            dz0, part0 = ops.dwconv_bwd_data(dd, sv["wkkc"], n, h, w, a.cexp, k, s, l, t, oh, ow, w_kkc_flipped=wflip,
+                                             epi=(sv["e"], st0))
+            del dd
+            de, dg0, db0 = ops.bnact_bwd(sv["e"], n, hw, a.cexp, st0, blk._bn0.weight, 0, g=dz0, partials=part0)
+            del dz0
+        else:
+            da0 = ops.dwconv_bwd_data(dd, sv["wkkc"], n, h, w, a.cexp, k, s, l, t, oh, ow, w_kkc_flipped=wflip)
+            del dd
+            if a.expand != 1:
+                de, dg0, db0 = ops.bnact_bwd(sv["e"], n, hw, a.cexp, st0, blk._bn0.weight, 1, g=da0)
+                del da0
         if a.expand != 1:
-            de, dg0, db0 = ops.bnact_bwd(sv["e"], n, hw, a.cexp, st0, blk._bn0.weight, 1, g=da0)
-            del da0
             we_t = ops.cast_transpose_bf16(blk._expand_conv.weight.view(a.cexp, a.cin))     # [cin, cexp]
             dx = ops.linear_dgrad(de, sv["we"], residual=dy if a.skip else None, w_t=we_t)
             dwe = ops.linear_wgrad(de, x)

@@ -100,9 +100,15 @@ __device__ unsigned long long g_march_prof[8];     // developer phase profile (s
 #define MPROF(i)
 #endif
 
-template <int K, int S, int CPL, int LP, int NCOL>
-__global__ __launch_bounds__(256, (K == 3 && S == 1 ? 3 : 2)) void dwconv_march_fwd_kernel(const mc_dwconv_args p, int strips, int segs,
+// EPI (stride 1 only): the launch is the DATA GRADIENT of a depthwise conv whose input was silu(bn0(e)) -- the output of
+// this "forward on flipped taps" is dA0, and the kernel finishes the step that follows it in the MBConv backward
+// [ref: efficientnet_custom.py:104-107 backwards]: it reads e at the output position, writes dZ0 = dA0 * silu'(e*scale+shift)
+// instead of dA0 and leaves the BatchNorm-backward reduction (sum dZ0, sum dZ0 * xhat0) in stat_partials -- the separate
+// reduce pass over (e, dA0) disappears and the BN0 apply pass becomes a plain linear combination.
+template <int K, int S, int CPL, int LP, int NCOL, bool EPI = false>
+__global__ __launch_bounds__(256, (K == 3 && S == 1 && !EPI ? 3 : 2)) void dwconv_march_fwd_kernel(const mc_dwconv_args p, int strips, int segs,
                                                                                 int seg_rows, int ctiles, int gy) {
+    static_assert(!EPI || S == 1, "the BatchNorm-backward epilogue is provided for stride 1");
     using C = MarchCfg<K, S, CPL, LP, NCOL>;
     typedef typename std::conditional<CPL == 4, uint2, uint32_t>::type ldsv_t;
     __shared__ __attribute__((aligned(16))) unsigned char smem[C::BUF_BYTES > 8192 ? C::BUF_BYTES : 8192];
@@ -134,6 +140,21 @@ __global__ __launch_bounds__(256, (K == 3 && S == 1 ? 3 : 2)) void dwconv_march_
             if (ch_ok) w[t][h] = *reinterpret_cast<const f32x2_t*>(p.w_kkc + (long long)t * p.c + cl + 2 * h);
         }
 
+    // EPI: BatchNorm parameters of the lane's channels (z = e*scale + shift, xhat = (e - mean) * invstd)
+    f32x2_t e_sc[C::H2], e_sh[C::H2], e_mu[C::H2], e_is[C::H2];
+    if constexpr (EPI) {
+#pragma unroll
+        for (int h = 0; h < C::H2; ++h) {
+            e_sc[h] = e_sh[h] = e_mu[h] = e_is[h] = f32x2_t{0.f, 0.f};
+            if (ch_ok) {
+                e_sc[h] = *reinterpret_cast<const f32x2_t*>(p.epi_scale + cl + 2 * h);
+                e_sh[h] = *reinterpret_cast<const f32x2_t*>(p.epi_shift + cl + 2 * h);
+                e_mu[h] = *reinterpret_cast<const f32x2_t*>(p.epi_mean + cl + 2 * h);
+                e_is[h] = *reinterpret_cast<const f32x2_t*>(p.epi_invstd + cl + 2 * h);
+            }
+        }
+    }
+
     // ---- per-thread staging geometry, constant for the whole kernel
     const int vv = tid % C::VPP;
     const int cs = c0 + vv * 8;
@@ -159,6 +180,7 @@ __global__ __launch_bounds__(256, (K == 3 && S == 1 ? 3 : 2)) void dwconv_march_
     for (int h = 0; h < C::H2; ++h) { ssum[h] = f32x2_t{0.f, 0.f}; ssq[h] = f32x2_t{0.f, 0.f}; }
     f32x2_t acc[C::NCOL][C::A][C::H2];
     bf16_t* optr = nullptr;                                // lane's pixel in the next output row to complete
+    const bf16_t* eptr = nullptr;                          // EPI: the same pixel of e
     int o_next = 0;
     unsigned col_ok = 0;                                   // bit i: the lane's i-th output column exists (and its channels do)
     const long long row_pitch = (long long)p.ow * p.c;
@@ -264,6 +286,7 @@ __global__ __launch_bounds__(256, (K == 3 && S == 1 ? 3 : 2)) void dwconv_march_
                     for (int h = 0; h < C::H2; ++h) acc[i][a][h] = f32x2_t{0.f, 0.f};
             o_next = fdiv_c(-(K - 1), S);
             optr = reinterpret_cast<bf16_t*>(p.out) + (((long long)img * p.oh + oy0 + o_next) * p.ow + ox0 + xl0) * p.c + cl;
+            if constexpr (EPI) eptr = p.epi_x + (((long long)img * p.oh + oy0 + o_next) * p.ow + ox0 + xl0) * p.c + cl;
             col_ok = 0;
 #pragma unroll
             for (int i = 0; i < C::NCOL; ++i) col_ok |= (ch_ok && ox0 + xl0 + i < p.ow ? 1u : 0u) << i;
@@ -274,6 +297,17 @@ __global__ __launch_bounds__(256, (K == 3 && S == 1 ? 3 : 2)) void dwconv_march_
             const unsigned char* lp_m = smem + lb_m + sb * (C::P * C::IWP * C::PSB);
 #pragma unroll
             for (int j = 0; j < C::P; ++j) {
+                // EPI: the e values of the output row this step completes, requested before the step's LDS reads and
+                // FMAs so that their latency hides under them
+                ldsv_t ev[C::NCOL];
+                if constexpr (EPI) {
+                    const bool row_ok = o_next >= 0 && o_next < nrows;
+#pragma unroll
+                    for (int i = 0; i < C::NCOL; ++i) {
+                        const bool ok = row_ok && ((col_ok >> i) & 1u);
+                        ev[i] = *reinterpret_cast<const ldsv_t*>(ok ? eptr + i * pix_pitch : p.epi_x);
+                    }
+                }
                 f32x2_t in[C::NIN][C::H2];
 #pragma unroll
                 for (int i = 0; i < C::NIN; ++i) {
@@ -308,10 +342,22 @@ __global__ __launch_bounds__(256, (K == 3 && S == 1 ? 3 : 2)) void dwconv_march_
                                 uint32_t o2[C::H2];
 #pragma unroll
                                 for (int h = 0; h < C::H2; ++h) {
-                                    o2[h] = pack_bf2(acc[i][sl][h].x, acc[i][sl][h].y);
-                                    const f32x2_t r = {bf_lo(o2[h]), bf_hi(o2[h])};   // statistics of the stored (rounded) tensor
-                                    ssum[h] += r;
-                                    ssq[h] = __builtin_elementwise_fma(r, r, ssq[h]);
+                                    if constexpr (EPI) {
+                                        uint32_t ew;
+                                        if constexpr (CPL == 4) ew = h == 0 ? ev[i].x : ev[i].y; else ew = ev[i];
+                                        const f32x2_t e2 = {bf_lo(ew), bf_hi(ew)};
+                                        const f32x2_t z = __builtin_elementwise_fma(e2, e_sc[h], e_sh[h]);
+                                        const f32x2_t dz = {acc[i][sl][h].x * silu_grad_f(z.x), acc[i][sl][h].y * silu_grad_f(z.y)};
+                                        o2[h] = pack_bf2(dz.x, dz.y);
+                                        const f32x2_t r = {bf_lo(o2[h]), bf_hi(o2[h])};  // reductions of the stored (rounded) dZ0
+                                        ssum[h] += r;
+                                        ssq[h] = __builtin_elementwise_fma(r, (e2 - e_mu[h]) * e_is[h], ssq[h]);
+                                    } else {
+                                        o2[h] = pack_bf2(acc[i][sl][h].x, acc[i][sl][h].y);
+                                        const f32x2_t r = {bf_lo(o2[h]), bf_hi(o2[h])};   // statistics of the stored (rounded) tensor
+                                        ssum[h] += r;
+                                        ssq[h] = __builtin_elementwise_fma(r, r, ssq[h]);
+                                    }
                                 }
                                 if constexpr (CPL == 4) *reinterpret_cast<uint2*>(optr + i * pix_pitch) = make_uint2(o2[0], o2[1]);
                                 else *reinterpret_cast<uint32_t*>(optr + i * pix_pitch) = o2[0];
@@ -320,6 +366,7 @@ __global__ __launch_bounds__(256, (K == 3 && S == 1 ? 3 : 2)) void dwconv_march_
                     }
                     ++o_next;
                     optr += row_pitch;
+                    if constexpr (EPI) eptr += row_pitch;
 #pragma unroll
                     for (int i = 0; i < C::NCOL; ++i)
 #pragma unroll
@@ -878,7 +925,7 @@ template <typename C> MarchPlan march_plan(const mc_dwconv_args& p) {
     m.segs = mc_div_up(p.oh, m.seg_rows);
     // persistent workgroups: as many as are resident at once, every one with the same item count
     long long nitems = (long long)p.n * m.strips * m.segs;
-    long long cap = 256 * C::OCC / m.ctiles;
+    long long cap = 256 * (p.epi_x ? 2 : C::OCC) / m.ctiles;      // (the epilogue variant is built for 2 workgroups per CU)
     if (cap < 8) cap = 8;
     long long per = (nitems + cap - 1) / cap;
     m.gy = (int)((nitems + per - 1) / per);
@@ -900,6 +947,14 @@ template <int K, int S, typename F> auto march_dispatch(const mc_dwconv_args& p,
 template <int K, int S, typename C> int launch_march(const mc_dwconv_args& p, hipStream_t st) {
     MarchPlan m = march_plan<C>(p);
     int gy8 = (m.gy + 7) / 8 * 8;
+    if constexpr (S == 1) {
+        if (p.epi_x) {
+            hipLaunchKernelGGL((dwconv_march_fwd_kernel<K, S, C::H2 * 2, C::TCH / (C::H2 * 2), C::NCOL, true>), dim3(gy8 * m.ctiles), dim3(256),
+                               0, st, p, m.strips, m.segs, m.seg_rows, m.ctiles, m.gy);
+            MC_LAUNCH_CHECK();
+            return MC_OK;
+        }
+    }
     hipLaunchKernelGGL((dwconv_march_fwd_kernel<K, S, C::H2 * 2, C::TCH / (C::H2 * 2), C::NCOL>), dim3(gy8 * m.ctiles), dim3(256), 0, st, p,
                        m.strips, m.segs, m.seg_rows, m.ctiles, m.gy);
     MC_LAUNCH_CHECK();
@@ -949,6 +1004,8 @@ extern "C" int mc_dwconv_fwd(const mc_dwconv_args* a, void* stream) {
     const mc_dwconv_args& p = *a;
     if (int e = check_common(p)) return e;
     MC_CHECK(p.x && p.w_kkc, "dwconv_fwd: null x / w");
+    MC_CHECK(!p.epi_x || (p.stride == 1 && p.epi_scale && p.epi_shift && p.epi_mean && p.epi_invstd && p.stat_partials),
+             "dwconv_fwd: the BatchNorm-backward epilogue needs stride 1, scale/shift/mean/invstd and stat_partials");
     hipStream_t st = (hipStream_t)stream;
     if (p.k == 3 && p.stride == 1) return launch_march_cp<3, 1>(p, st);
     if (p.k == 3 && p.stride == 2) return launch_march_cp<3, 2>(p, st);

@@ -63,6 +63,7 @@ class DwconvArgs(C.Structure):
         ("n", I), ("h", I), ("w", I), ("c", I),
         ("k", I), ("stride", I), ("pad_l", I), ("pad_t", I), ("oh", I), ("ow", I),
         ("pro_scale", P), ("pro_shift", P), ("stat_partials", P),
+        ("epi_x", P), ("epi_scale", P), ("epi_shift", P), ("epi_mean", P), ("epi_invstd", P),
     ]
 
 

@@ -422,26 +422,35 @@ def _dw_args(n, h, w, c, k, stride, pad_l, pad_t, oh, ow):
     return a
 
 
-def dwconv_fwd(x, w_kkc, n, h, w, c, k, stride, pad_l, pad_t, oh, ow, pro=None, stats=False):
+def dwconv_fwd(x, w_kkc, n, h, w, c, k, stride, pad_l, pad_t, oh, ow, pro=None, stats=False, epi=None):
+    """epi = (e, BNStats): BatchNorm(+SiLU)-backward epilogue (stride 1; see mc_dwconv_args.epi_x): returns
+    (dZ, [rows,2,c] partials for bn_bwd_finalize) instead of (y, BatchNorm statistics partials)."""
     a = _dw_args(n, h, w, c, k, stride, pad_l, pad_t, oh, ow)
     y = empty((n * oh * ow, c), BF16, x)
     a.x, a.out, a.w_kkc = _p(x), _p(y), _p(w_kkc)
     if pro is not None:
         a.pro_scale, a.pro_shift = _p(pro[0]), _p(pro[1])
+    if epi is not None:
+        e, st = epi
+        assert stride == 1 and e.shape == y.shape
+        a.epi_x, a.epi_scale, a.epi_shift, a.epi_mean, a.epi_invstd = _p(e), _p(st.scale), _p(st.shift), _p(st.mean), _p(st.invstd)
+        stats = True
     part = None
     if stats:
         rows = L.load().mc_dwconv_stat_rows(C.byref(a))
         part = empty((rows, 2, c), torch.float32, x)
         a.stat_partials = _p(part)
-    _note(2 * n * c * (h * w + oh * ow), 2 * n * c * oh * ow * k * k)
-    L.call("mc_dwconv_fwd", C.byref(a), _st())
+    _note(2 * n * c * (h * w + oh * ow * (2 if epi is not None else 1)), 2 * n * c * oh * ow * k * k)
+    L.call("mc_dwconv_fwd", C.byref(a), _st(), kind=("dgrad_bn" if epi is not None else None))
     return (y, part) if stats else y
 
 
-def dwconv_bwd_data(dy, w_kkc, n, h, w, c, k, stride, pad_l, pad_t, oh, ow, w_kkc_flipped=None):
-    """dx [n*h*w, c].  stride 1 runs the LDS-tiled forward kernel on the flipped filter; stride 2 the gather kernel."""
+def dwconv_bwd_data(dy, w_kkc, n, h, w, c, k, stride, pad_l, pad_t, oh, ow, w_kkc_flipped=None, epi=None):
+    """dx [n*h*w, c].  stride 1 runs the LDS-tiled forward kernel on the flipped filter; stride 2 the marching
+    super-pixel kernel.  epi (stride 1 only) = (e, BNStats): returns (dZ, BatchNorm-backward partials), see dwconv_fwd."""
     if stride == 1 and w_kkc_flipped is not None:
-        return dwconv_fwd(dy, w_kkc_flipped, n, oh, ow, c, k, 1, k - 1 - pad_l, k - 1 - pad_t, h, w)
+        return dwconv_fwd(dy, w_kkc_flipped, n, oh, ow, c, k, 1, k - 1 - pad_l, k - 1 - pad_t, h, w, epi=epi)
+    assert epi is None
     a = _dw_args(n, h, w, c, k, stride, pad_l, pad_t, oh, ow)
     dx = empty((n * h * w, c), BF16, dy)
     a.dy, a.out, a.w_kkc = _p(dy), _p(dx), _p(w_kkc)

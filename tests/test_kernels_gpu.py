@@ -814,3 +814,33 @@ def test_fp8_batched_gated_weights():
     ax, aw = float(x.float().abs().max()), float(wg.float().abs().max())
     ref = torch.einsum("bmk,bnk->bmn", _e4m3(x, ax).view(nb, hw, K), _e4m3(wg, aw)).reshape(nb * hw, N)
     check(y, ref, 1e-2, "fp8 batched gemm")
+
+
+@pytest.mark.parametrize("k,n,h,w,c", [(3, 2, 40, 33, 240), (5, 2, 29, 23, 384), (3, 3, 17, 50, 144), (5, 1, 60, 64, 64), (3, 2, 20, 20, 24)])
+def test_dwconv_dgrad_with_bn_backward_epilogue(k, n, h, w, c):
+    """stride-1 depthwise data gradient with the fused BatchNorm(+SiLU)-backward epilogue (mc_dwconv_args.epi_x) ==
+    plain data gradient followed by the two-pass BatchNorm backward: dE, dgamma, dbeta (bf16 round-off: the fused path
+    rounds dZ once more, <= 1.5e-2 of max|ref|)."""
+    pad = (k - 1) // 2
+    e = rnd(n * h * w, c, seed=1)
+    dd = rnd(n * h * w, c, seed=2)
+    wk = rnd(k * k, c, seed=3, dtype=torch.float32)
+    gamma, beta = rnd(c, seed=4, dtype=torch.float32) * 0.2 + 1.0, rnd(c, seed=5, dtype=torch.float32) * 0.1
+    ef = e.float()
+    mean, var = ef.mean(0), ef.var(0, unbiased=False)
+    st = ops.BNStats()
+    st.mean, st.invstd = mean.contiguous(), (var + 1e-3).rsqrt().contiguous()
+    st.scale = (gamma * st.invstd).contiguous()
+    st.shift = (beta - mean * st.scale).contiguous()
+    st.count = float(n * h * w)
+    wflip = wk.flip(0).contiguous()
+    da0 = ops.dwconv_bwd_data(dd, wk, n, h, w, c, k, 1, pad, pad, h, w, w_kkc_flipped=wflip)
+    de_ref, dg_ref, db_ref = ops.bnact_bwd(e, n, h * w, c, st, gamma, 1, g=da0)
+    dz, part = ops.dwconv_bwd_data(dd, wk, n, h, w, c, k, 1, pad, pad, h, w, w_kkc_flipped=wflip, epi=(e, st))
+    de, dg, db = ops.bnact_bwd(e, n, h * w, c, st, gamma, 0, g=dz, partials=part)
+    z = ef * st.scale + st.shift
+    sg = torch.sigmoid(z)
+    check(dz, da0.float() * (sg * (1 + z * (1 - sg))), 1.5e-2, "dZ0")
+    check(de, de_ref, 1.5e-2, "dE through the fused epilogue")
+    check(dg, dg_ref, 1e-2, "dgamma")
+    check(db, db_ref, 1e-2, "dbeta")
