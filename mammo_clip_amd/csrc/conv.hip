@@ -111,8 +111,15 @@ __global__ __launch_bounds__(256, (K == 3 && S == 1 && !EPI ? 3 : 2)) void dwcon
     static_assert(!EPI || S == 1, "the BatchNorm-backward epilogue is provided for stride 1");
     using C = MarchCfg<K, S, CPL, LP, NCOL>;
     typedef typename std::conditional<CPL == 4, uint2, uint32_t>::type ldsv_t;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[C::BUF_BYTES > 8192 ? C::BUF_BYTES : 8192];
+    // EPI: the e rows of the output rows a staged block completes travel through LDS beside the input block (same
+    // prefetch, position-major like the dy tile of the weight-gradient kernel: a wave's reads are contiguous)
+    constexpr int XQ = C::TOW / NCOL;                      // lane column groups per strip
+    constexpr int E_BYTES = EPI ? C::RB * C::TOW * C::PXB : 0;
+    constexpr int NVE = EPI ? (C::RB * C::TOW * C::VPP + C::TS - 1) / C::TS : 1;
+    constexpr int MAIN_BYTES = C::BUF_BYTES > 8192 ? C::BUF_BYTES : 8192;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[MAIN_BYTES + E_BYTES];
     __shared__ __attribute__((aligned(16))) float pro_lds[2][C::TCH];      // prologue scale / shift of the tile's channels
+    unsigned char* const esm = smem + MAIN_BYTES;
     // XCD-aware decomposition: the channel tiles of one (image, strip, segment) share 128-byte lines, so they are
     // given consecutive slots on the SAME XCD (workgroup id % 8) and meet in that XCD's L2.
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
@@ -141,16 +148,15 @@ __global__ __launch_bounds__(256, (K == 3 && S == 1 && !EPI ? 3 : 2)) void dwcon
         }
 
     // EPI: BatchNorm parameters of the lane's channels (z = e*scale + shift, xhat = (e - mean) * invstd)
-    f32x2_t e_sc[C::H2], e_sh[C::H2], e_mu[C::H2], e_is[C::H2];
+    // (the loop accumulates sum dZ and sum dZ * e; xhat = (e - mean) * invstd enters when the partials are written)
+    f32x2_t e_sc[C::H2], e_sh[C::H2];
     if constexpr (EPI) {
 #pragma unroll
         for (int h = 0; h < C::H2; ++h) {
-            e_sc[h] = e_sh[h] = e_mu[h] = e_is[h] = f32x2_t{0.f, 0.f};
+            e_sc[h] = e_sh[h] = f32x2_t{0.f, 0.f};
             if (ch_ok) {
                 e_sc[h] = *reinterpret_cast<const f32x2_t*>(p.epi_scale + cl + 2 * h);
                 e_sh[h] = *reinterpret_cast<const f32x2_t*>(p.epi_shift + cl + 2 * h);
-                e_mu[h] = *reinterpret_cast<const f32x2_t*>(p.epi_mean + cl + 2 * h);
-                e_is[h] = *reinterpret_cast<const f32x2_t*>(p.epi_invstd + cl + 2 * h);
             }
         }
     }
@@ -169,6 +175,18 @@ __global__ __launch_bounds__(256, (K == 3 && S == 1 && !EPI ? 3 : 2)) void dwcon
         meta[i] = (unsigned)row | ((unsigned)col << 8) | ((unsigned)(((row * C::IWP + pos) * C::PSB + vv * 16) >> 4) << 16);
         if (v >= C::RB * C::IW_T * C::VPP) meta[i] = 0xffu;    // row 255: never valid
     }
+    unsigned metae[NVE];                                   // EPI: the same for the e block (RB rows x TOW columns)
+    if constexpr (EPI) {
+#pragma unroll
+        for (int i = 0; i < NVE; ++i) {
+            const int v = tid + i * C::TS;
+            const int row = v / (C::TOW * C::VPP), col = (v / C::VPP) % C::TOW;
+            metae[i] = (unsigned)row | ((unsigned)col << 8) |
+                       ((unsigned)((((row * NCOL + col % NCOL) * XQ + col / NCOL) * C::PXB + vv * 16) >> 4) << 16);
+            if (v >= C::RB * C::TOW * C::VPP) metae[i] = 0xffu;
+        }
+    }
+    const int ebase = (wave * C::PXW + (lane_ok ? px : 0)) * C::PXB + lq * (CPL * 2);
     if (has_pro && tid < 2 * C::TCH) {
         const int ch = tid % C::TCH;
         const float* src = tid < C::TCH ? p.pro_scale : p.pro_shift;
@@ -180,7 +198,6 @@ __global__ __launch_bounds__(256, (K == 3 && S == 1 && !EPI ? 3 : 2)) void dwcon
     for (int h = 0; h < C::H2; ++h) { ssum[h] = f32x2_t{0.f, 0.f}; ssq[h] = f32x2_t{0.f, 0.f}; }
     f32x2_t acc[C::NCOL][C::A][C::H2];
     bf16_t* optr = nullptr;                                // lane's pixel in the next output row to complete
-    const bf16_t* eptr = nullptr;                          // EPI: the same pixel of e
     int o_next = 0;
     unsigned col_ok = 0;                                   // bit i: the lane's i-th output column exists (and its channels do)
     const long long row_pitch = (long long)p.ow * p.c;
@@ -198,6 +215,9 @@ __global__ __launch_bounds__(256, (K == 3 && S == 1 && !EPI ? 3 : 2)) void dwcon
     };
 
     uint4 vals[C::NV];
+    uint4 evals[NVE];
+    unsigned einb = 0;
+    int nrows_l = 0;                                       // rows of the item being LOADED (for the e block's row mask)
     unsigned inb = 0;                                      // vectors of the staged block that hold real pixels
     unsigned colmask = 0;                                  // per item: vectors whose column lies inside the image
     // global -> registers for block b of item (img, ox0, oy0)
@@ -224,6 +244,20 @@ __global__ __launch_bounds__(256, (K == 3 && S == 1 && !EPI ? 3 : 2)) void dwcon
             vals[i] = *reinterpret_cast<const uint4*>(a);
             inb |= (ok ? 1u : 0u) << i;
         }
+        if constexpr (EPI) {
+            // e rows of the output rows block b completes: o = b*RB - (K-1) + row  (only rows / columns that exist)
+            const int o0 = b * C::RB - (K - 1);
+            const bf16_t* eorg = p.epi_x + ((long long)img * p.oh + oy0 + o0) * ((long long)p.ow * p.c) + (long long)ox0 * p.c + c0;
+            einb = 0;
+#pragma unroll
+            for (int i = 0; i < NVE; ++i) {
+                const int o = o0 + (int)(metae[i] & 0xffu);
+                const bool ok = st_ok && (metae[i] & 0xffu) != 0xffu && o >= 0 && o < nrows_l && ox0 + (int)((metae[i] >> 8) & 0xffu) < p.ow;
+                const long long goff = (long long)(metae[i] & 0xffu) * ((long long)p.ow * p.c) + (long long)((metae[i] >> 8) & 0xffu) * p.c + vv * 8;
+                evals[i] = *reinterpret_cast<const uint4*>(ok ? eorg + goff : p.epi_x);
+                einb |= (ok ? 1u : 0u) << i;
+            }
+        }
     };
     // registers -> LDS, with the fused BN+SiLU prologue on real pixels (zero padding stays zero)
     auto stage_store = [&]() {
@@ -248,12 +282,19 @@ __global__ __launch_bounds__(256, (K == 3 && S == 1 && !EPI ? 3 : 2)) void dwcon
                 *reinterpret_cast<uint4*>(smem + ((meta[i] >> 16) << 4)) = val;
             }
         }
+        if constexpr (EPI) {
+#pragma unroll
+            for (int i = 0; i < NVE; ++i)
+                if (tid < C::TS && (metae[i] & 0xffu) != 0xffu)
+                    *reinterpret_cast<uint4*>(esm + ((metae[i] >> 16) << 4)) = ((einb >> i) & 1u) ? evals[i] : make_uint4(0u, 0u, 0u, 0u);
+        }
     };
 
     int it = y, img = 0;
     int ox0 = 0, oy0 = 0, nrows = 0, nblk = 0, b = 0;
     if (it >= nitems) return;                 // (never: gy <= nitems)
     item_geom(it, img, ox0, oy0, nrows, nblk);
+    nrows_l = nrows;
     stage_load(img, ox0, oy0, 0, true);
 #ifdef MARCH_PROF
     unsigned long long pacc[6] = {0, 0, 0, 0, 0, 0};
@@ -274,6 +315,7 @@ __global__ __launch_bounds__(256, (K == 3 && S == 1 && !EPI ? 3 : 2)) void dwcon
             if (it2 < nitems) item_geom(it2, img2, ox2, oy2, nrows2, nblk2);
         }
         const bool more = it2 < nitems;
+        nrows_l = nrows2;
         if (more) stage_load(img2, ox2, oy2, b2, b2 == 0);
         MPROF(3);
 
@@ -286,7 +328,7 @@ __global__ __launch_bounds__(256, (K == 3 && S == 1 && !EPI ? 3 : 2)) void dwcon
                     for (int h = 0; h < C::H2; ++h) acc[i][a][h] = f32x2_t{0.f, 0.f};
             o_next = fdiv_c(-(K - 1), S);
             optr = reinterpret_cast<bf16_t*>(p.out) + (((long long)img * p.oh + oy0 + o_next) * p.ow + ox0 + xl0) * p.c + cl;
-            if constexpr (EPI) eptr = p.epi_x + (((long long)img * p.oh + oy0 + o_next) * p.ow + ox0 + xl0) * p.c + cl;
+
             col_ok = 0;
 #pragma unroll
             for (int i = 0; i < C::NCOL; ++i) col_ok |= (ch_ok && ox0 + xl0 + i < p.ow ? 1u : 0u) << i;
@@ -297,16 +339,12 @@ __global__ __launch_bounds__(256, (K == 3 && S == 1 && !EPI ? 3 : 2)) void dwcon
             const unsigned char* lp_m = smem + lb_m + sb * (C::P * C::IWP * C::PSB);
 #pragma unroll
             for (int j = 0; j < C::P; ++j) {
-                // EPI: the e values of the output row this step completes, requested before the step's LDS reads and
-                // FMAs so that their latency hides under them
+                // EPI: the e values of the output row this step completes (row sb*P + j of the staged e block)
                 ldsv_t ev[C::NCOL];
                 if constexpr (EPI) {
-                    const bool row_ok = o_next >= 0 && o_next < nrows;
 #pragma unroll
-                    for (int i = 0; i < C::NCOL; ++i) {
-                        const bool ok = row_ok && ((col_ok >> i) & 1u);
-                        ev[i] = *reinterpret_cast<const ldsv_t*>(ok ? eptr + i * pix_pitch : p.epi_x);
-                    }
+                    for (int i = 0; i < C::NCOL; ++i)
+                        ev[i] = *reinterpret_cast<const ldsv_t*>(esm + ebase + ((sb * C::P + j) * NCOL + i) * XQ * C::PXB);
                 }
                 f32x2_t in[C::NIN][C::H2];
 #pragma unroll
@@ -351,7 +389,7 @@ __global__ __launch_bounds__(256, (K == 3 && S == 1 && !EPI ? 3 : 2)) void dwcon
                                         o2[h] = pack_bf2(dz.x, dz.y);
                                         const f32x2_t r = {bf_lo(o2[h]), bf_hi(o2[h])};  // reductions of the stored (rounded) dZ0
                                         ssum[h] += r;
-                                        ssq[h] = __builtin_elementwise_fma(r, (e2 - e_mu[h]) * e_is[h], ssq[h]);
+                                        ssq[h] = __builtin_elementwise_fma(r, e2, ssq[h]);
                                     } else {
                                         o2[h] = pack_bf2(acc[i][sl][h].x, acc[i][sl][h].y);
                                         const f32x2_t r = {bf_lo(o2[h]), bf_hi(o2[h])};   // statistics of the stored (rounded) tensor
@@ -366,7 +404,6 @@ __global__ __launch_bounds__(256, (K == 3 && S == 1 && !EPI ? 3 : 2)) void dwcon
                     }
                     ++o_next;
                     optr += row_pitch;
-                    if constexpr (EPI) eptr += row_pitch;
 #pragma unroll
                     for (int i = 0; i < C::NCOL; ++i)
 #pragma unroll
@@ -400,6 +437,15 @@ __global__ __launch_bounds__(256, (K == 3 && S == 1 && !EPI ? 3 : 2)) void dwcon
             float s = 0.f;
             for (int wv = 0; wv < 4; ++wv)
                 for (int q = 0; q < C::PXW; ++q) s += red[(wv * 64 + q * LP + ch / CPL) * 2 * CPL + which * CPL + ch % CPL];
+            if constexpr (EPI) {
+                // which == 1 holds sum dZ * e: turn it into sum dZ * xhat = invstd * (sum dZ * e - mean * sum dZ)
+                float s0 = 0.f;
+                if (which == 1) {
+                    for (int wv = 0; wv < 4; ++wv)
+                        for (int q = 0; q < C::PXW; ++q) s0 += red[(wv * 64 + q * LP + ch / CPL) * 2 * CPL + ch % CPL];
+                    if (c0 + ch < p.c) s = p.epi_invstd[c0 + ch] * (s - p.epi_mean[c0 + ch] * s0);
+                }
+            }
             if (c0 + ch < p.c) p.stat_partials[((long long)y * 2 + which) * p.c + c0 + ch] = s;
         }
     }
