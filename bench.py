@@ -57,10 +57,12 @@ MFMA_PEAK_TFS = 2500.0         # dense bf16 MFMA peak
 # 10.8 % and 10.7 % of GPU time; in the single-pass cfg3 workload the first is clearly ahead, 13.5 % vs 9 %):
 #  * bnact_bwd_k<true>, the BatchNorm(+SiLU) backward "apply" pass  dx = A*dz + B*x + C  (reads the saved conv output x
 #    and the upstream gradient g, writes dx): HBM-bound, 3 x rows x channels x 2 B algorithmic bytes per launch;
-#  * gemm_kernel<128,128,64,2,2,0,0,false,true>, the direct-to-LDS NT MFMA tile kernel (forward / data-gradient 1x1
-#    convolutions of the late stages and the BERT linears): MFMA-bound, 2 M N K flop per launch.
+#  * the plain NT direct-to-LDS MFMA tile kernels (forward / data-gradient 1x1 convolutions of the late stages and the BERT
+#    linears): gemm_kernel<128,128,64,2,2,0,0,false,true> and, where its 256 x 256 tiles fill the 256 CUs well,
+#    g256::gemm256_kernel (mc_gemm_tile_config): MFMA-bound, 2 M N K flop per launch.
 # Both are timed live; the one with more GPU time in the run is "roofline", the other "roofline_runner_up".
-GEMM_KERNEL = "gemm_kernel<128,128,64,2,2,0,0,false,true> (direct-to-LDS NT MFMA tiles: late-stage 1x1 convs fwd/dgrad, BERT linears)"
+GEMM_KERNEL = ("plain NT direct-to-LDS MFMA tile kernels: gemm_kernel<128,128,64,2,2,0,0,false,true> and g256::gemm256_kernel "
+               "(256x256x64), chosen per problem by tile fill (late-stage 1x1 convs fwd/dgrad, BERT linears)")
 ROOFLINE_OP = "mc_bnact_bwd_apply"
 ROOFLINE_KERNEL = "bnact_bwd_k<true> (BatchNorm+SiLU backward apply pass)"
 STREAM_OPS = (ROOFLINE_OP, "mc_gemm_bf16")
@@ -202,7 +204,9 @@ def main():
         sc, st, sb, _ = summ.get(ROOFLINE_OP, (0, 0.0, 0, 0))
         ach = sb / (st * 1e-3) / 1e9 if st > 0 else 0.0
         traffic = gtraffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_roofline_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r02_roofline_traffic.json")
+        if not os.path.exists(tpath):
+            tpath = os.path.join(ROOT, "profiles", "r01_roofline_traffic.json")
         if os.path.exists(tpath) and args.workload in ("cfg3", "cfg4") and not args.batch:   # same 32-pair kernel launches
             tj = json.load(open(tpath))                                     # PMC passes (rocprofv3 --pmc), same workload
             traffic, gtraffic = tj.get("hbm_bytes_per_launch"), tj.get("gemm_nt_hbm_bytes_per_launch")
