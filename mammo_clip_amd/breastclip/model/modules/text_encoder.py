@@ -59,12 +59,18 @@ class _LayerFn(torch.autograd.Function):
         pa, ph = (lyr.p_attn, lyr.p_hidden) if lyr.training else (0.0, 0.0)
         sid = 16 * lyr.index
         sq, sk, sv = att.self.query, att.self.key, att.self.value
-        wqkv = torch.empty((3 * H, H), dtype=torch.bfloat16, device=x.device)
-        ops.cast_bf16(sq.weight, out=wqkv[:H])
-        ops.cast_bf16(sk.weight, out=wqkv[H:2 * H])
-        ops.cast_bf16(sv.weight, out=wqkv[2 * H:])
-        bqkv = torch.empty((3 * H,), dtype=torch.float32, device=x.device)
-        bqkv[:H].copy_(sq.bias); bqkv[H:2 * H].copy_(sk.bias); bqkv[2 * H:].copy_(sv.bias)   # D2D copies
+        # fused QKV operand: [3H, H] bf16 weight image + [3H] fp32 bias, rebuilt only when one of the six parameters
+        # changed (version counters: bumped by the optimizer step / load_state_dict), not on every layer call
+        ver = tuple(p_._version for p_ in (sq.weight, sk.weight, sv.weight, sq.bias, sk.bias, sv.bias)) + (sq.weight.data_ptr(),)
+        cache = getattr(lyr, "_qkv_cache", None)
+        if cache is None or cache[0] != ver or cache[1].device != x.device:
+            wqkv = torch.empty((3 * H, H), dtype=torch.bfloat16, device=x.device)
+            ops.cast_bf16(sq.weight, out=wqkv[:H])
+            ops.cast_bf16(sk.weight, out=wqkv[H:2 * H])
+            ops.cast_bf16(sv.weight, out=wqkv[2 * H:])
+            bqkv = torch.cat([sq.bias.detach(), sk.bias.detach(), sv.bias.detach()]).float().contiguous()
+            lyr._qkv_cache = cache = (ver, wqkv, bqkv)
+        _, wqkv, bqkv = cache
         qkv = ops.linear_fwd(x, wqkv, bias=bqkv)
         scores = torch.empty((b, nh, t, t), dtype=torch.float32, device=x.device)
         ops.gemm(qkv, qkv[:, H:], scores, t, t, hd, 3 * H, 3 * H, t, c_f32=1, batch=b * nh, nb2=nh,
