@@ -125,6 +125,8 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="pairs per GPU (0 = workload default)")
     ap.add_argument("--micro-batches", type=int, default=1,
                     help="cut the per-GPU batch into k micro-batches (one extra forward per step; for batches beyond one pass)")
+    ap.add_argument("--keep-graphs", type=int, default=1,
+                    help="micro-batched step: micro-batches forwarded once with their graph kept (activation memory x this)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fp8", action="store_true", help="fp8 (e4m3) operands for the late-stage 1x1 convolutions (config #5 arithmetic on any workload)")
     ap.add_argument("--op-profile", action="store_true", help="print a per-entry-point HIP-event breakdown (rank 0)")
@@ -171,7 +173,7 @@ def main():
     loss_func = build_loss(LOSS_CFG)
     opt = build_optimizer(model, {"name": "adamw", "config": {"lr": 5e-5, "weight_decay": 1e-4}})
     sched = LinearWarmupCosineAnnealingLR(opt, total_steps=10000, warmup_steps=100)
-    trainer = engine.Trainer(model, loss_func, opt, sched, device)
+    trainer = engine.Trainer(model, loss_func, opt, sched, device, keep_graphs=args.keep_graphs)
     batch = synth_batch_gpu(b, H, W, T, device, seed=10 + rank)
 
     def sync():
@@ -197,6 +199,7 @@ def main():
     dt = float(tmax)
     loss_val = float(ld["total"])
     summ = timer.summary()
+    peak_gb = torch.cuda.max_memory_allocated() / 1e9
 
     if rank == 0:
         ms = dt / args.steps * 1e3
@@ -238,7 +241,7 @@ def main():
                                    f"(2 views + 2 reports each), {H}x{W} images, {T}-token reports, breast_clip loss, "
                                    f"AdamW; fwd+loss+bwd+optimizer; dropout/drop-connect on",
                        "global_batch": b * world, "parallelism": f"dp{world}" + (f" x {args.micro_batches} micro-batches" if args.micro_batches > 1 else ""),
-                       "loss": round(loss_val, 5)},
+                       "loss": round(loss_val, 5), "peak_hbm_gb": round(peak_gb, 1)},
             "roofline": first, "roofline_runner_up": second,
         }
         if world == 1 and not args.no_cpu_baseline:

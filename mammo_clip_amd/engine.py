@@ -114,10 +114,11 @@ class GradBuckets:
 
 class Trainer:
     def __init__(self, model, loss_func, optimizer, scheduler=None, device=None, bucket_mb: int = 256,
-                 overlap_micro: bool = True):
+                 overlap_micro: bool = True, keep_graphs: int = 1):
         self.model, self.loss_func, self.optimizer, self.scheduler = model, loss_func, optimizer, scheduler
         self.device = device
         self.overlap_micro = overlap_micro      # micro-batched step: reduce buckets from the last backward's hooks
+        self.keep_graphs = max(1, int(keep_graphs))   # micro-batched step: micro-batches forwarded once, graph kept
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self.buckets = GradBuckets(list(model.parameters()), bucket_mb << 20) if self.world > 1 else None
         if self.world > 1:
@@ -189,31 +190,37 @@ def _step_micro(self, batch: Dict, k: int) -> Dict[str, torch.Tensor]:
     mbs, b = _split_batch(batch, k)
     irng, trng = _rng_counters(model)
     keys = ("image_embeddings", "text_embeddings", "text_embeddings2", "image_view_embeddings")
+    keep = min(self.keep_graphs, k)            # micro-batches whose graph is kept (activation memory: `keep` micro-batches)
     counters, parts = [], []
     with torch.no_grad():
-        for mb in mbs[:-1]:
+        for mb in mbs[:k - keep]:
             counters.append((irng.calls, trng._calls))
             out = model(mb, self.device)
             parts.append({kk: out[kk] for kk in keys if kk in out})
-    # the LAST micro-batch is forwarded with its graph kept: it is back-propagated straight from the loss and never
-    # forwarded again (k - 1 extra forwards per step instead of k: at 4 micro-batches per GPU that is 6 % of the step)
-    out = model(mbs[-1], self.device)
-    live = {kk: out[kk] for kk in keys if kk in out}
+    # the LAST `keep` micro-batches are forwarded with their graph kept: they are back-propagated straight from the loss
+    # and never forwarded again (k - keep extra forwards per step instead of k: at 4 micro-batches per GPU and keep = 1
+    # that is 6 % of the step; keep = 2 needs the activations of two micro-batches, ~230 GB at 32 pairs each)
+    lives = []
+    for mb in mbs[k - keep:]:
+        out = model(mb, self.device)
+        lives.append({kk: out[kk] for kk in keys if kk in out})
     after = (irng.calls, trng._calls)
-    leaf = {kk: torch.cat([p_[kk] for p_ in parts]).detach().requires_grad_(True) for kk in live}
-    full = {kk: torch.cat([leaf[kk], live[kk]]) for kk in live}
+    leaf = {kk: torch.cat([p_[kk] for p_ in parts]).detach().requires_grad_(True) for kk in lives[0]} if parts else {}
+    full = {kk: torch.cat(([leaf[kk]] if parts else []) + [lv[kk] for lv in lives]) for kk in lives[0]}
     n = next(iter(full.values())).shape[0]
     outputs = dict(full, labels=torch.arange(n, device=self.device), logit_scale=model.logit_scale.exp())
+    if self.buckets is not None and self.overlap_micro and not parts:
+        self.buckets.enabled = True            # every micro-batch kept: this is the only backward
     loss_dict = self.loss_func(**outputs, is_train=True)
-    loss_dict["total"].backward()              # d loss / d embeddings of micro-batches 0 .. k-2, full backward of the last one
-    del out, live, full, outputs
+    loss_dict["total"].backward()              # d loss / d embeddings of the re-run micro-batches, full backward of the kept ones
+    del out, lives, full, outputs
     bns = [m for m in model.modules() if hasattr(m, "track_update")]
     for m in bns:
         m.track_update = False
     try:
-        for i, mb in enumerate(mbs[:-1]):
+        for i, mb in enumerate(mbs[:k - keep]):
             irng.calls, trng._calls = counters[i]
-            if self.buckets is not None and self.overlap_micro and i == len(mbs) - 2:
+            if self.buckets is not None and self.overlap_micro and i == k - keep - 1:
                 # gradients become final during the LAST backward: each bucket is all-reduced as soon as its parameters
                 # have accumulated their last contribution, overlapped with the rest of that backward
                 self.buckets.enabled = True
