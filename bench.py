@@ -14,8 +14,9 @@ symmetric InfoNCE (breast_clip loss), backward, gradient all-reduce, AdamW updat
 Default workload = the configuration BASELINE.json's metric is quoted on (configs[3], "cfg4"): EfficientNet-B5 +
 BioClinicalBERT, GLOBAL batch 1024, 1520x912 images, 256-token reports, bf16 compute.  Each GPU takes 1024 / N pairs
 per step (strong scaling) in micro-batches of 32 pairs: the contrastive loss runs over all 1024 pairs of the step, the
-micro-batching costs one extra forward per step (engine.Trainer.step(batch, micro_batches=k)).  At N = 1 a step is
-32 micro-batches (about 12.6 s).  "--workload cfg3" is BASELINE configs[2], 32 pairs per GPU in one pass (weak scaling).
+micro-batching costs k - 2 extra forwards per step of k micro-batches (engine.Trainer.step(batch, micro_batches=k) with
+keep_graphs = 2: the last two micro-batches are forwarded once, graph kept, 232 GB peak).  At N = 1 a step is
+32 micro-batches (about 12.5 s).  "--workload cfg3" is BASELINE configs[2], 32 pairs per GPU in one pass (weak scaling).
 
 The JSON line carries, besides the contract fields:
   roofline     -- the dominant kernel of the step (largest share of GPU time in the rocprofv3 kernel stats under
@@ -125,8 +126,9 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="pairs per GPU (0 = workload default)")
     ap.add_argument("--micro-batches", type=int, default=1,
                     help="cut the per-GPU batch into k micro-batches (one extra forward per step; for batches beyond one pass)")
-    ap.add_argument("--keep-graphs", type=int, default=1,
-                    help="micro-batched step: micro-batches forwarded once with their graph kept (activation memory x this)")
+    ap.add_argument("--keep-graphs", type=int, default=0,
+                    help="micro-batched step: micro-batches forwarded once with their graph kept (activation memory x this); "
+                         "0 = 2 for the global-batch workloads (2 x 32 pairs = 232 GB of the 288 GB), 1 otherwise")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fp8", action="store_true", help="fp8 (e4m3) operands for the late-stage 1x1 convolutions (config #5 arithmetic on any workload)")
     ap.add_argument("--op-profile", action="store_true", help="print a per-entry-point HIP-event breakdown (rank 0)")
@@ -167,6 +169,8 @@ def main():
         b = b // world
         args.micro_batches = max(1, b // 32)
     fp8 = args.workload == "cfg5" or args.fp8
+    if args.keep_graphs <= 0:
+        args.keep_graphs = 2 if strong else 1
     util.GlobalEnv.reset()
     torch.manual_seed(10)
     model = build_model(model_cfg(enc_name, fp8), LOSS_CFG, types.SimpleNamespace(vocab_size=28996)).to(device)
