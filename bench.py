@@ -128,7 +128,7 @@ def main():
                     help="cut the per-GPU batch into k micro-batches (one extra forward per step; for batches beyond one pass)")
     ap.add_argument("--keep-graphs", type=int, default=0,
                     help="micro-batched step: micro-batches forwarded once with their graph kept (activation memory x this); "
-                         "0 = 2 for the global-batch workloads (2 x 32 pairs = 232 GB of the 288 GB), 1 otherwise")
+                         "0 = 2 for the global-batch workloads at <= 512 pairs per GPU (2 x 32 pairs = 232 GB of the 288 GB), 1 otherwise")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fp8", action="store_true", help="fp8 (e4m3) operands for the late-stage 1x1 convolutions (config #5 arithmetic on any workload)")
     ap.add_argument("--op-profile", action="store_true", help="print a per-entry-point HIP-event breakdown (rank 0)")
@@ -170,7 +170,9 @@ def main():
         args.micro_batches = max(1, b // 32)
     fp8 = args.workload == "cfg5" or args.fp8
     if args.keep_graphs <= 0:
-        args.keep_graphs = 2 if strong else 1
+        # two kept graphs = 232 GB of activations; at N = 1 the 1024-pair fp32 input batch itself occupies 34 GB (262 GB
+        # peak measured): one kept graph there, two from N = 2 (512 pairs per GPU) on
+        args.keep_graphs = 2 if (strong and b <= 512) else 1
     util.GlobalEnv.reset()
     torch.manual_seed(10)
     model = build_model(model_cfg(enc_name, fp8), LOSS_CFG, types.SimpleNamespace(vocab_size=28996)).to(device)
