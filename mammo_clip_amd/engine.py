@@ -252,12 +252,22 @@ def init_distributed():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    device = torch.device(f"cuda:{local}")
+    # one process per GPU.  (Developer override MC_DIST_BACKEND=gloo: lets the multi-rank flow -- launcher, parameter
+    # broadcast, fused gather, gradient buckets -- be exercised with several ranks SHARING a device on a box with fewer
+    # GPUs than ranks, which RCCL refuses; never used by the product path.)
+    backend = os.environ.get("MC_DIST_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    if backend == "nccl" and world > ndev and world > 1:
+        raise RuntimeError(f"{world} ranks but {ndev} visible GPUs: RCCL needs one GPU per rank")
+    device = torch.device(f"cuda:{local % max(ndev, 1)}")
     torch.cuda.set_device(device)
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", init_method="env://", world_size=world, rank=rank, device_id=device)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", init_method="env://", world_size=world, rank=rank, device_id=device)
+        else:
+            dist.init_process_group(backend=backend, init_method="env://", world_size=world, rank=rank)
     return rank, local, world, device
 
 
