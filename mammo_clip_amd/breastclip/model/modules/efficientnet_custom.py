@@ -101,7 +101,10 @@ def _bn_stats(partials, count, bn: nn.BatchNorm2d, training: bool):
         st = ops.bn_finalize(partials, count, bn.weight, bn.bias, bn.running_mean, bn.running_var, BN_MOMENTUM, BN_EPS,
                              bn.track_update)
         if bn.track_update:
-            bn.num_batches_tracked += 1
+            if bn.defer_count is not None:
+                bn.defer_count.append(bn.num_batches_tracked)     # the encoder bumps all counters with ONE launch
+            else:
+                bn.num_batches_tracked += 1
         return st
     return ops.bn_eval_coeffs(bn.weight, bn.bias, bn.running_mean, bn.running_var, BN_EPS)
 
@@ -323,6 +326,7 @@ class _BN(nn.BatchNorm2d):
     def __init__(self, c):
         super().__init__(c, momentum=BN_MOMENTUM, eps=BN_EPS)
         self.track_update = True          # engine may switch running-stat updates off for re-forward passes
+        self.defer_count = None           # list collecting the counters of one encoder forward (see EfficientNet.forward)
 
     def forward(self, x):                 # pragma: no cover
         raise RuntimeError("BatchNorm arithmetic runs inside the fused HIP kernels, not here")
@@ -409,6 +413,7 @@ class EfficientNet(nn.Module):
         self.fp8 = False
         self.rng = _Seeds()
         self.register_buffer("_ones_b", torch.ones(1), persistent=False)
+        self._bn_layers = [m for m in self.modules() if isinstance(m, _BN)]
 
     # ---------------------------------------------------------------------------- construction API
     @classmethod
@@ -481,18 +486,37 @@ class EfficientNet(nn.Module):
         x = inputs if isinstance(inputs, ops.RawImages) or inputs.dtype == torch.float32 else inputs.float()
         seed = self.rng.next()
         self._last_seed = seed
-        y = _StemFn.apply(x, self._conv_stem.weight, self._bn0.weight, self._bn0.bias, self)
-        n, h, w = self._geo
-        scales = self._drop_connect_scales(n, x.device, seed)
-        for blk, rs in zip(self._blocks, scales):
-            y = blk(y, n, h, w, rs)
-            n, h, w = blk._out_geo
+        # num_batches_tracked of the ~120 BatchNorm layers: collected during the forward, incremented by one
+        # multi-tensor launch at its end (116 one-element add launches per forward otherwise)
+        counters = [] if self.training else None
+        bns = self._bn_layers if counters is not None else ()
+        for bn in bns:
+            bn.defer_count = counters
+        try:
+            y = _StemFn.apply(x, self._conv_stem.weight, self._bn0.weight, self._bn0.bias, self)
+            n, h, w = self._geo
+            scales = self._drop_connect_scales(n, x.device, seed)
+            for blk, rs in zip(self._blocks, scales):
+                y = blk(y, n, h, w, rs)
+                n, h, w = blk._out_geo
+        finally:
+            for bn in bns:
+                bn.defer_count = None
+        self._pending_counters = counters
         return y, n, h, w
+
+    def _flush_counters(self):
+        c = getattr(self, "_pending_counters", None)
+        if c:
+            with torch.no_grad():
+                torch._foreach_add_(c, 1)
+        self._pending_counters = None
 
     def extract_features(self, inputs):
         """Final feature map after head conv + BN + swish, NCHW fp32 (API parity; not on the training hot path)."""
         y, n, h, w = self._features_nhwc(inputs)
         _HeadFn.apply(y, self._conv_head.weight, self._bn1.weight, self._bn1.bias, self, n, h, w)
+        self._flush_counters()
         e, st, n, h, w, cout = self._head_cache
         fmap = ops.bnact_apply(e, n, h * w, cout, st.scale, st.shift, 1)
         return ops.cast_f32(fmap).view(n, h, w, cout).permute(0, 3, 1, 2)
@@ -504,6 +528,7 @@ class EfficientNet(nn.Module):
         x = inputs["image"] if want_map else inputs
         y, n, h, w = self._features_nhwc(x)
         pooled = _HeadFn.apply(y, self._conv_head.weight, self._bn1.weight, self._bn1.bias, self, n, h, w)
+        self._flush_counters()
         if self.training and self._dropout_p > 0.0:
             pooled = _DropoutFn.apply(pooled, self._dropout_p, self._last_seed, 999)
         if want_map:
