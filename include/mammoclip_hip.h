@@ -289,7 +289,7 @@ int mc_colsum_bf16(const mc_bf16* x, long long m, int c, long long ld, float* pa
  *   r = silu(w1 . pooled + b1);  gate = sigmoid(w2 . r + b2);  w1 [cs, c], w2 [c, cs] fp32 */
 int mc_se_fwd(const float* pooled, const float* w1, const float* b1, const float* w2, const float* b2,
               int n, int c, int cs, float* gate, float* ws /* float[n*cs] scratch */, void* stream);
-/* ws: float[n * (c + 2*cs)] scratch; dw*, db* are accumulated (+=) */
+/* ws: float[n * (c + 2*cs)] scratch; dw*, db* are WRITTEN (every element by exactly one thread: no zero-fill needed) */
 int mc_se_bwd(const float* pooled, const float* gate, const float* dgate, const float* w1, const float* b1,
               const float* w2, const float* b2, int n, int c, int cs, float* dpooled, float* dw1, float* db1,
               float* dw2, float* db2, float* ws, void* stream);

@@ -236,7 +236,7 @@ class _MBConvFn(torch.autograd.Function):
         else:
             dw_in, pro0 = x, None
         dwdw = ops.dwconv_bwd_weight(dw_in, dd, n, h, w, a.cexp, k, s, l, t, oh, ow, pro=pro0)
-        wflip = sv["wkkc"].flip(0).contiguous() if s == 1 else None     # tap order reversed = 180 degree rotation
+        wflip = ops.flipped_taps_f32(blk._depthwise_conv.weight.view(a.cexp, k * k)) if s == 1 else None   # 180 degree rotation
         grads = {}
         if a.expand != 1 and s == 1:
             # stride 1: the data-gradient kernel finishes the bn0 + swish backward in its epilogue -- it reads e at the

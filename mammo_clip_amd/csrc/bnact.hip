@@ -527,27 +527,27 @@ __global__ void se_wgrad_k(const float* __restrict__ pooled, const float* __rest
     const long long stride = c + 2 * cs;
     long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long n1 = (long long)c * cs;
-    if (e < n1) {                       // dw2[ci, j] += sum_n ds[n,ci] * r[n,j]
+    if (e < n1) {                       // dw2[ci, j] = sum_n ds[n,ci] * r[n,j]
         int ci = (int)(e / cs), j = (int)(e % cs);
         float s = 0.f;
         for (int i = 0; i < n; ++i) s += ws[i * stride + ci] * ws[i * stride + c + j];
-        dw2[e] += s;
-    } else if (e < 2 * n1) {            // dw1[j, ci] += sum_n du[n,j] * pooled[n,ci]
+        dw2[e] = s;
+    } else if (e < 2 * n1) {            // dw1[j, ci] = sum_n du[n,j] * pooled[n,ci]
         long long e2 = e - n1;
         int j = (int)(e2 / c), ci = (int)(e2 % c);
         float s = 0.f;
         for (int i = 0; i < n; ++i) s += ws[i * stride + c + cs + j] * pooled[(long long)i * c + ci];
-        dw1[e2] += s;
+        dw1[e2] = s;
     } else if (e < 2 * n1 + c) {
         int ci = (int)(e - 2 * n1);
         float s = 0.f;
         for (int i = 0; i < n; ++i) s += ws[i * stride + ci];
-        db2[ci] += s;
+        db2[ci] = s;
     } else if (e < 2 * n1 + c + cs) {
         int j = (int)(e - 2 * n1 - c);
         float s = 0.f;
         for (int i = 0; i < n; ++i) s += ws[i * stride + c + cs + j];
-        db1[j] += s;
+        db1[j] = s;
     }
 }
 

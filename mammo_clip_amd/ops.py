@@ -347,6 +347,14 @@ def cast_f32(src):
     return dst
 
 
+def flipped_taps_f32(w_ck):
+    """fp32 depthwise weight [c, k*k] -> taps-major, tap order reversed [k*k, c] (= the filter rotated by 180 degrees: the
+    stride-1 data gradient is a forward conv with it); cached per parameter version like the other weight images"""
+    def make():
+        return transpose_f32(w_ck).flip(0).contiguous()
+    return _cached("tfl", w_ck, make)
+
+
 def transpose_f32(src, cache=False):
     def make():
         rows, cols = src.shape
@@ -580,14 +588,17 @@ def bnact_bwd(x, n_img, hw, c, stats, gamma, act, g=None, mul=None, add=None, ro
         a.partials = _p(part)
         _note(2 * n_img * hw * c * (2 if g is not None else 1))
         L.call("mc_bnact_bwd_reduce", C.byref(a), _st())
-    buf = empty((5, c), torch.float32, x)        # dgamma, dbeta, coefA, coefB, coefC
+    # dgamma / dbeta are handed to autograd as parameter gradients: own tensors (a row of a shared buffer is a view, which
+    # AccumulateGrad clones -- one copy launch per gradient); coefA/B/C stay together
+    dgamma, dbeta = empty((c,), torch.float32, x), empty((c,), torch.float32, x)
+    coef = empty((3, c), torch.float32, x)
     L.call("mc_bn_bwd_finalize", _p(part), rows, c, float(n_img * hw), _p(gamma), _p(stats.mean), _p(stats.invstd),
-           _p(buf[0]), _p(buf[1]), _p(buf[2]), _st())
+           _p(dgamma), _p(dbeta), _p(coef), _st())
     dx = empty((n_img * hw, c), BF16, x)
-    a.coef, a.dx = _p(buf[2]), _p(dx)
+    a.coef, a.dx = _p(coef), _p(dx)
     _note(2 * n_img * hw * c * (3 if g is not None else 2))
     L.call("mc_bnact_bwd_apply", C.byref(a), _st())
-    return dx, buf[0], buf[1]
+    return dx, dgamma, dbeta
 
 
 # ------------------------------------------------------------------------------------------- SE / dropout
@@ -604,11 +615,10 @@ def se_bwd(pooled, gate, dgate, w1, b1, w2, b2):
     n, c = pooled.shape
     cs = w1.shape[0]
     dpooled = empty((n, c), torch.float32, pooled)
-    # one zero-filled allocation for the four accumulated outputs (one memset instead of four); slices 16-byte aligned
-    n1, pad = cs * c, lambda v: (v + 3) // 4 * 4
-    flat = torch.zeros(2 * n1 + pad(cs) + pad(c), dtype=torch.float32, device=pooled.device)
-    dw1, dw2 = flat[:n1].view(cs, c), flat[n1:2 * n1].view(c, cs)
-    db1, db2 = flat[2 * n1:2 * n1 + cs], flat[2 * n1 + pad(cs):2 * n1 + pad(cs) + c]
+    # four own tensors (they are handed to autograd as parameter gradients: views of a shared buffer would be cloned by
+    # AccumulateGrad); the kernel writes every element, so no zero-fill either
+    dw1, dw2 = empty((cs, c), torch.float32, pooled), empty((c, cs), torch.float32, pooled)
+    db1, db2 = empty((cs,), torch.float32, pooled), empty((c,), torch.float32, pooled)
     ws = empty((n, c + 2 * cs), torch.float32, pooled)
     L.call("mc_se_bwd", _p(pooled), _p(gate), _p(dgate), _p(w1), _p(b1), _p(w2), _p(b2), n, c, cs, _p(dpooled),
            _p(dw1), _p(db1), _p(dw2), _p(db2), _p(ws), _st())
