@@ -326,6 +326,20 @@ int mc_softmax_fwd(const float* scores, long long rows, int t, float p, unsigned
 /* dscores = probs * (dp - sum(probs*dp)) * alpha with dp = dprobs_drop * mask/(1-p); bf16 out */
 int mc_softmax_bwd(const mc_bf16* probs, const float* dprobs_drop, long long rows, int t, float p,
                    unsigned long long seed, unsigned int stream_id, float alpha, mc_bf16* dscores, void* stream);
+/* Fused self-attention core (attn.hip), head size 64, 32 <= t <= 256, t % 32 == 0 (mc_attn_supported):
+ *   ctx[b*t, nh*64] = dropout(softmax(alpha * Q K^T + mask_bias[b, key])) V   per (sequence, head),
+ * qkv = [b*t, 3*nh*64] (Q | K | V column blocks).  The [b, nh, t, t] scores / probabilities are never stored: the
+ * forward keeps lse[b*nh*t][2] = (row max, 1 / row sum) and the backward recomputes them.  Dropout masks are the
+ * same function of (seed, stream_id, element) as mc_softmax_fwd's.
+ * Replaces transformers BertSelfAttention.forward as called from the reference's text encoder
+ * [ref: model/modules/text_encoder.py:47-49]. */
+int mc_attn_supported(int t, int head_dim);
+int mc_attn_fwd(const mc_bf16* qkv, const float* mask_bias, int b, int t, int nh, float alpha, float p,
+                unsigned long long seed, unsigned int stream_id, mc_bf16* ctx, float* lse, void* stream);
+/* dqkv [b*t, 3*nh*64] (every element written) from dctx [b*t, nh*64] */
+int mc_attn_bwd(const mc_bf16* qkv, const float* mask_bias, const mc_bf16* dctx, const float* lse, int b, int t,
+                int nh, float alpha, float p, unsigned long long seed, unsigned int stream_id, mc_bf16* dqkv,
+                void* stream);
 int mc_gelu_fwd(const mc_bf16* x, mc_bf16* y, long long n, void* stream);
 int mc_gelu_bwd(const mc_bf16* dy, const mc_bf16* x, mc_bf16* dx, long long n, void* stream);
 /* mask bias for attention: out[b, t] = (1 - mask[b,t]) * -3.0e38-ish (finfo.min)  */

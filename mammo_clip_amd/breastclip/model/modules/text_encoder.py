@@ -72,15 +72,22 @@ class _LayerFn(torch.autograd.Function):
             lyr._qkv_cache = cache = (ver, wqkv, bqkv)
         _, wqkv, bqkv = cache
         qkv = ops.linear_fwd(x, wqkv, bias=bqkv)
-        scores = torch.empty((b, nh, t, t), dtype=torch.float32, device=x.device)
-        ops.gemm(qkv, qkv[:, H:], scores, t, t, hd, 3 * H, 3 * H, t, c_f32=1, batch=b * nh, nb2=nh,
-                 sA=(t * 3 * H, hd), sB=(t * 3 * H, hd), sC=(nh * t * t, t * t), bias=maskb, bias_stride1=t,
-                 alpha=hd ** -0.5)
-        probs, pd = ops.softmax_fwd(scores, pa, seed, sid)
-        del scores
-        ctxv = torch.empty((M, H), dtype=torch.bfloat16, device=x.device)
-        ops.gemm(pd, qkv[:, 2 * H:], ctxv, t, hd, t, t, 3 * H, H, b_kmajor=1, batch=b * nh, nb2=nh,
-                 sA=(nh * t * t, t * t), sB=(t * 3 * H, hd), sC=(t * H, hd))
+        fused = ops.attn_supported(t, hd)
+        if fused:
+            # one kernel: scores, mask, softmax, dropout and context; only (row max, 1/row sum) are kept for backward
+            ctxv, lse = ops.attn_fwd(qkv, maskb, b, t, nh, hd ** -0.5, pa, seed, sid)
+            probs = pd = None
+        else:
+            lse = None
+            scores = torch.empty((b, nh, t, t), dtype=torch.float32, device=x.device)
+            ops.gemm(qkv, qkv[:, H:], scores, t, t, hd, 3 * H, 3 * H, t, c_f32=1, batch=b * nh, nb2=nh,
+                     sA=(t * 3 * H, hd), sB=(t * 3 * H, hd), sC=(nh * t * t, t * t), bias=maskb, bias_stride1=t,
+                     alpha=hd ** -0.5)
+            probs, pd = ops.softmax_fwd(scores, pa, seed, sid)
+            del scores
+            ctxv = torch.empty((M, H), dtype=torch.bfloat16, device=x.device)
+            ops.gemm(pd, qkv[:, 2 * H:], ctxv, t, hd, t, t, 3 * H, H, b_kmajor=1, batch=b * nh, nb2=nh,
+                     sA=(nh * t * t, t * t), sB=(t * 3 * H, hd), sC=(t * H, hd))
         wo = ops.cast_bf16(att.output.dense.weight)
         ao = ops.linear_fwd(ctxv, wo, bias=att.output.dense.bias)
         a, mean1, rstd1 = ops.add_ln_fwd(ao, x, att.output.LayerNorm.weight, att.output.LayerNorm.bias, lyr.eps, ph, seed,
@@ -94,7 +101,7 @@ class _LayerFn(torch.autograd.Function):
         y, mean2, rstd2 = ops.add_ln_fwd(o, a, lyr.output.LayerNorm.weight, lyr.output.LayerNorm.bias, lyr.eps, ph, seed,
                                          sid + 2)
         ctx.lyr, ctx.cfg = lyr, (b, t, seed, pa, ph, sid)
-        ctx.sv = dict(x=x, qkv=qkv, probs=probs, pd=pd, ctxv=ctxv, ao=ao, a=a, h1=h1, o=o, wqkv=wqkv, wo=wo, wi=wi, w2=w2,
+        ctx.sv = dict(x=x, qkv=qkv, probs=probs, pd=pd, lse=lse, maskb=maskb, ctxv=ctxv, ao=ao, a=a, h1=h1, o=o, wqkv=wqkv, wo=wo, wi=wi, w2=w2,
                       ln1=(mean1, rstd1), ln2=(mean2, rstd2))
         return y
 
@@ -129,19 +136,22 @@ class _LayerFn(torch.autograd.Function):
         dctx = ops.linear_dgrad(dao, sv["wo"], w_t=ops.cast_transpose_bf16(att.output.dense.weight))
         del dao
         # attention core
-        dpd = torch.empty((b, nh, t, t), dtype=torch.float32, device=x.device)
-        ops.gemm(dctx, qkv[:, 2 * H:], dpd, t, t, hd, H, 3 * H, t, c_f32=1, batch=b * nh, nb2=nh,
-                 sA=(t * H, hd), sB=(t * 3 * H, hd), sC=(nh * t * t, t * t))
-        dqkv = torch.empty((b * t, 3 * H), dtype=torch.bfloat16, device=x.device)
-        ops.gemm(pd, dctx, dqkv[:, 2 * H:], t, hd, t, t, H, 3 * H, a_kmajor=1, b_kmajor=1, batch=b * nh, nb2=nh,
-                 sA=(nh * t * t, t * t), sB=(t * H, hd), sC=(t * 3 * H, hd))                       # dV = Pd^T dO
-        ds = ops.softmax_bwd(probs, dpd, pa, seed, sid, hd ** -0.5)
-        del dpd
-        ops.gemm(ds, qkv[:, H:], dqkv, t, hd, t, t, 3 * H, 3 * H, b_kmajor=1, batch=b * nh, nb2=nh,
-                 sA=(nh * t * t, t * t), sB=(t * 3 * H, hd), sC=(t * 3 * H, hd))                   # dQ = dS K
-        ops.gemm(ds, qkv, dqkv[:, H:], t, hd, t, t, 3 * H, 3 * H, a_kmajor=1, b_kmajor=1, batch=b * nh, nb2=nh,
-                 sA=(nh * t * t, t * t), sB=(t * 3 * H, hd), sC=(t * 3 * H, hd))                   # dK = dS^T Q
-        del ds
+        if sv["lse"] is not None:
+            dqkv = ops.attn_bwd(qkv, sv["maskb"], dctx, sv["lse"], b, t, nh, hd ** -0.5, pa, seed, sid)
+        else:
+            dpd = torch.empty((b, nh, t, t), dtype=torch.float32, device=x.device)
+            ops.gemm(dctx, qkv[:, 2 * H:], dpd, t, t, hd, H, 3 * H, t, c_f32=1, batch=b * nh, nb2=nh,
+                     sA=(t * H, hd), sB=(t * 3 * H, hd), sC=(nh * t * t, t * t))
+            dqkv = torch.empty((b * t, 3 * H), dtype=torch.bfloat16, device=x.device)
+            ops.gemm(pd, dctx, dqkv[:, 2 * H:], t, hd, t, t, H, 3 * H, a_kmajor=1, b_kmajor=1, batch=b * nh, nb2=nh,
+                     sA=(nh * t * t, t * t), sB=(t * H, hd), sC=(t * 3 * H, hd))                       # dV = Pd^T dO
+            ds = ops.softmax_bwd(probs, dpd, pa, seed, sid, hd ** -0.5)
+            del dpd
+            ops.gemm(ds, qkv[:, H:], dqkv, t, hd, t, t, 3 * H, 3 * H, b_kmajor=1, batch=b * nh, nb2=nh,
+                     sA=(nh * t * t, t * t), sB=(t * 3 * H, hd), sC=(t * 3 * H, hd))                   # dQ = dS K
+            ops.gemm(ds, qkv, dqkv[:, H:], t, hd, t, t, 3 * H, 3 * H, a_kmajor=1, b_kmajor=1, batch=b * nh, nb2=nh,
+                     sA=(nh * t * t, t * t), sB=(t * 3 * H, hd), sC=(t * 3 * H, hd))                   # dK = dS^T Q
+            del ds
         dwqkv = ops.linear_wgrad(dqkv, x)
         dbqkv = ops.colsum(dqkv)
         wqkv_t = torch.empty((H, 3 * H), dtype=torch.bfloat16, device=x.device)      # [in, 3*out] = wqkv^T

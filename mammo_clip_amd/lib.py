@@ -132,6 +132,9 @@ _SIGS = {
     "mc_add_ln_bwd": ([P, P, P, P, P, P, LL, I, F, ULL, U, P, P, P, P, P], I),
     "mc_softmax_fwd": ([P, LL, I, F, ULL, U, P, P, P], I),
     "mc_softmax_bwd": ([P, P, LL, I, F, ULL, U, F, P, P], I),
+    "mc_attn_supported": ([I, I], I),
+    "mc_attn_fwd": ([P, P, I, I, I, F, F, ULL, U, P, P, P], I),
+    "mc_attn_bwd": ([P, P, P, P, I, I, I, F, F, ULL, U, P, P], I),
     "mc_gelu_fwd": ([P, P, LL, P], I),
     "mc_gelu_bwd": ([P, P, P, LL, P], I),
     "mc_mask_bias": ([P, P, LL, P], I),

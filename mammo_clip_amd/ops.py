@@ -692,6 +692,29 @@ def softmax_bwd(probs, dpd, p, seed, sid, alpha):
     return ds
 
 
+def attn_supported(t, head_dim):
+    """Whether the fused attention kernels take this shape (otherwise: batched GEMM + softmax kernels)."""
+    import os
+    if os.environ.get("MC_FUSED_ATTN", "1") == "0":      # developer switch: A/B against the unfused kernels
+        return False
+    return bool(L.load().mc_attn_supported(int(t), int(head_dim)))
+
+
+def attn_fwd(qkv, maskb, b, t, nh, alpha, p, seed, sid):
+    """ctx [b*t, nh*64] bf16 and lse [b*nh*t, 2] fp32 from qkv [b*t, 3*nh*64] (fused scores/softmax/dropout/context)."""
+    ctx = empty((b * t, nh * 64), BF16, qkv)
+    lse = empty((b * nh * t, 2), torch.float32, qkv)
+    L.call("mc_attn_fwd", _p(qkv), _p(maskb), b, t, nh, float(alpha), float(p), int(seed), int(sid), _p(ctx), _p(lse), _st())
+    return ctx, lse
+
+
+def attn_bwd(qkv, maskb, dctx, lse, b, t, nh, alpha, p, seed, sid):
+    dqkv = empty(qkv.shape, BF16, qkv)
+    L.call("mc_attn_bwd", _p(qkv), _p(maskb), _p(dctx), _p(lse), b, t, nh, float(alpha), float(p), int(seed), int(sid),
+           _p(dqkv), _st())
+    return dqkv
+
+
 def gelu_fwd(x):
     y = torch.empty_like(x)
     L.call("mc_gelu_fwd", _p(x), _p(y), x.numel(), _st())

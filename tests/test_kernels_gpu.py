@@ -844,3 +844,90 @@ def test_dwconv_dgrad_with_bn_backward_epilogue(k, n, h, w, c):
     check(de, de_ref, 1.5e-2, "dE through the fused epilogue")
     check(dg, dg_ref, 1e-2, "dgamma")
     check(db, db_ref, 1e-2, "dbeta")
+
+
+# ------------------------------------------------------------------------------------------- fused attention
+def _attn_inputs(b, t, nh, seed):
+    H = nh * 64
+    qkv = rnd(b * t, 3 * H, seed=seed, scale=1.5)
+    mask = torch.ones(b, t, dtype=torch.long, device=DEV)
+    for i in range(b):
+        mask[i, t - (i * 7) % (t // 2):] = 0 if (i * 7) % (t // 2) else 1          # ragged report lengths
+    maskb = ops.mask_bias(mask)
+    dctx = rnd(b * t, H, seed=seed + 1)
+    return qkv, mask, maskb, dctx
+
+
+def _attn_torch(qkv, mask, dctx, b, t, nh, keep=None, p=0.0):
+    """fp32 reference of BertSelfAttention's core on the same bf16 operands (keep = dropout keep mask [b,nh,t,t])."""
+    H = nh * 64
+    x = qkv.float().requires_grad_(True)
+    q, k, v = (x[:, i * H:(i + 1) * H].view(b, t, nh, 64).permute(0, 2, 1, 3) for i in range(3))
+    s = q @ k.transpose(-1, -2) * 0.125 + (1 - mask.float())[:, None, None, :] * torch.finfo(torch.float32).min
+    pr = torch.softmax(s, -1)
+    if keep is not None:
+        pr = pr * keep / (1 - p)
+    ctx = (pr @ v).permute(0, 2, 1, 3).reshape(b * t, H)
+    ctx.backward(dctx.float())
+    return ctx.detach(), x.grad
+
+
+@pytest.mark.parametrize("b,t,nh", [(3, 256, 12), (5, 64, 12), (2, 32, 2), (4, 128, 3), (2, 224, 4)])
+def test_fused_attention_vs_torch(b, t, nh):
+    """fused QK^T -> mask -> softmax -> PV kernel and its backward against fp32 torch on the same operands"""
+    assert ops.attn_supported(t, 64)
+    qkv, mask, maskb, dctx = _attn_inputs(b, t, nh, 300 + t)
+    ctx, lse = ops.attn_fwd(qkv, maskb, b, t, nh, 0.125, 0.0, 1, 0)
+    ref, dref = _attn_torch(qkv, mask, dctx, b, t, nh)
+    check(ctx, ref, 1e-2, "attention context")
+    dqkv = ops.attn_bwd(qkv, maskb, dctx, lse, b, t, nh, 0.125, 0.0, 1, 0)
+    H = nh * 64
+    for i, nm in enumerate("QKV"):
+        check(dqkv[:, i * H:(i + 1) * H], dref[:, i * H:(i + 1) * H], 1.5e-2, "attention d" + nm)
+    # masked keys get no gradient through K / V
+    dead = (mask == 0).view(-1)
+    if dead.any():
+        assert float(dqkv[dead][:, H:].float().abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("b,t,nh", [(3, 256, 12), (4, 64, 2)])
+def test_fused_attention_dropout_matches_unfused_kernels(b, t, nh):
+    """same (seed, stream, element) dropout function as mc_softmax_fwd: the fused kernels reproduce the unfused
+    batched-GEMM + softmax path mask for mask, forward and backward"""
+    H, M, hd, p, seed, sid = nh * 64, b * t, 64, 0.1, 1234, 16
+    qkv, mask, maskb, dctx = _attn_inputs(b, t, nh, 400 + t)
+    ctx, lse = ops.attn_fwd(qkv, maskb, b, t, nh, 0.125, p, seed, sid)
+    dqkv = ops.attn_bwd(qkv, maskb, dctx, lse, b, t, nh, 0.125, p, seed, sid)
+    # unfused kernels (the path taken for shapes the fused kernel does not cover)
+    scores = torch.empty((b, nh, t, t), dtype=torch.float32, device=DEV)
+    ops.gemm(qkv, qkv[:, H:], scores, t, t, hd, 3 * H, 3 * H, t, c_f32=1, batch=b * nh, nb2=nh,
+             sA=(t * 3 * H, hd), sB=(t * 3 * H, hd), sC=(nh * t * t, t * t), bias=maskb, bias_stride1=t, alpha=0.125)
+    probs, pd = ops.softmax_fwd(scores, p, seed, sid)
+    ctx2 = torch.empty((M, H), dtype=BF, device=DEV)
+    ops.gemm(pd, qkv[:, 2 * H:], ctx2, t, hd, t, t, 3 * H, H, b_kmajor=1, batch=b * nh, nb2=nh,
+             sA=(nh * t * t, t * t), sB=(t * 3 * H, hd), sC=(t * H, hd))
+    check(ctx, ctx2, 4e-3, "fused vs unfused context (same dropout mask)")
+    keep = (pd.float() > 0) | (probs.float() == 0)
+    ref, dref = _attn_torch(qkv, mask, dctx, b, t, nh, keep=keep.float(), p=p)
+    check(ctx, ref, 1.5e-2, "dropout attention context vs torch")
+    dpd = torch.empty((b, nh, t, t), dtype=torch.float32, device=DEV)
+    ops.gemm(dctx, qkv[:, 2 * H:], dpd, t, t, hd, H, 3 * H, t, c_f32=1, batch=b * nh, nb2=nh,
+             sA=(t * H, hd), sB=(t * 3 * H, hd), sC=(nh * t * t, t * t))
+    dq2 = torch.empty((M, 3 * H), dtype=BF, device=DEV)
+    ops.gemm(pd, dctx, dq2[:, 2 * H:], t, hd, t, t, H, 3 * H, a_kmajor=1, b_kmajor=1, batch=b * nh, nb2=nh,
+             sA=(nh * t * t, t * t), sB=(t * H, hd), sC=(t * 3 * H, hd))
+    ds = ops.softmax_bwd(probs, dpd, p, seed, sid, 0.125)
+    ops.gemm(ds, qkv[:, H:], dq2, t, hd, t, t, 3 * H, 3 * H, b_kmajor=1, batch=b * nh, nb2=nh,
+             sA=(nh * t * t, t * t), sB=(t * 3 * H, hd), sC=(t * 3 * H, hd))
+    ops.gemm(ds, qkv, dq2[:, H:], t, hd, t, t, 3 * H, 3 * H, a_kmajor=1, b_kmajor=1, batch=b * nh, nb2=nh,
+             sA=(nh * t * t, t * t), sB=(t * 3 * H, hd), sC=(t * 3 * H, hd))
+    for i, nm in enumerate("QKV"):
+        check(dqkv[:, i * H:(i + 1) * H], dq2[:, i * H:(i + 1) * H], 6e-3, "fused vs unfused d" + nm)
+        check(dqkv[:, i * H:(i + 1) * H], dref[:, i * H:(i + 1) * H], 2e-2, "dropout attention d%s vs torch" % nm)
+
+
+def test_fused_attention_rejects_unsupported_shapes():
+    assert not ops.attn_supported(48, 64) and not ops.attn_supported(512, 64) and not ops.attn_supported(64, 32)
+    qkv, mask, maskb, dctx = _attn_inputs(1, 32, 1, 9)
+    with pytest.raises(mammo_clip_amd.lib.MammoClipHipError):
+        ops.attn_fwd(qkv[:24], maskb[:, :24].contiguous(), 1, 24, 1, 0.125, 0.0, 1, 0)
