@@ -14,9 +14,9 @@ symmetric InfoNCE (breast_clip loss), backward, gradient all-reduce, AdamW updat
 Default workload = the configuration BASELINE.json's metric is quoted on (configs[3], "cfg4"): EfficientNet-B5 +
 BioClinicalBERT, GLOBAL batch 1024, 1520x912 images, 256-token reports, bf16 compute.  Each GPU takes 1024 / N pairs
 per step (strong scaling) in micro-batches of 32 pairs: the contrastive loss runs over all 1024 pairs of the step, the
-micro-batching costs k - 2 extra forwards per step of k micro-batches (engine.Trainer.step(batch, micro_batches=k) with
-keep_graphs = 2: the last two micro-batches are forwarded once, graph kept, 232 GB peak).  At N = 1 a step is
-32 micro-batches (about 12.5 s).  "--workload cfg3" is BASELINE configs[2], 32 pairs per GPU in one pass (weak scaling).
+micro-batching costs k - keep extra forwards per step of k micro-batches (engine.Trainer.step(batch, micro_batches=k):
+the last `keep` micro-batches are forwarded once, graph kept; 2 full graphs = 232 GB, or all 4 graphs of the N = 8 load
+with the MBConv recompute mode 3).  At N = 1 a step is 32 micro-batches (about 12.4 s).  "--workload cfg3" is BASELINE configs[2], 32 pairs per GPU in one pass (weak scaling).
 
 The JSON line carries, besides the contract fields:
   roofline     -- the dominant kernel of the step (largest share of GPU time in the rocprofv3 kernel stats under
@@ -69,9 +69,10 @@ ROOFLINE_KERNEL = "bnact_bwd_k<true> (BatchNorm+SiLU backward apply pass)"
 STREAM_OPS = (ROOFLINE_OP, "mc_gemm_bf16")
 
 
-def model_cfg(enc_name, fp8=False):
+def model_cfg(enc_name, fp8=False, recompute=0):
     return {"name": "clip_custom", "temperature": 0.07,
-            "image_encoder": {"source": "cnn", "name": enc_name, "pretrained": True, "model_type": "cnn", "fp8": fp8},
+            "image_encoder": {"source": "cnn", "name": enc_name, "pretrained": True, "model_type": "cnn", "fp8": fp8,
+                              "recompute": recompute},
             "text_encoder": {"source": "huggingface", "name": "emilyalsentzer/Bio_ClinicalBERT", "pretrained": False,
                              "gradient_checkpointing": False, "pooling": "eos", "cache_dir": "", "trust_remote_code": True},
             "projection_head": {"name": "linear", "dropout": 0.1, "proj_dim": 512}}
@@ -129,6 +130,8 @@ def main():
     ap.add_argument("--keep-graphs", type=int, default=0,
                     help="micro-batched step: micro-batches forwarded once with their graph kept (activation memory x this); "
                          "0 = 2 for the global-batch workloads at <= 512 pairs per GPU (2 x 32 pairs = 232 GB of the 288 GB), 1 otherwise")
+    ap.add_argument("--recompute", type=int, default=-1, choices=(-1, 0, 1, 2, 3),
+                    help="MBConv activation recompute mode (EfficientNet.set_recompute); -1 = chosen with --keep-graphs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fp8", action="store_true", help="fp8 (e4m3) operands for the late-stage 1x1 convolutions (config #5 arithmetic on any workload)")
     ap.add_argument("--op-profile", action="store_true", help="print a per-entry-point HIP-event breakdown (rank 0)")
@@ -169,13 +172,21 @@ def main():
         b = b // world
         args.micro_batches = max(1, b // 32)
     fp8 = args.workload == "cfg5" or args.fp8
+    # Kept graphs against activation memory (measured on one MI355X at the per-GPU load, scripts/recompute_sweep.sh):
+    #   128 pairs/GPU (N = 8): recompute mode 3 makes a 32-pair graph small enough to keep all four (216 GB peak, no
+    #     re-forward at all): 1305 ms/step against 1384 ms with two full graphs kept (227 GB) -- mode 1 with four kept is
+    #     1271 ms but peaks at 295 GB, too close to the 309 GB of the device;
+    #   256 / 512 pairs/GPU: two full graphs (231 GB); mode 3 needs five kept graphs (273 GB) to win 1.6 % -- not taken;
+    #   1024 pairs/GPU (N = 1): the fp32 input batch itself occupies 34 GB: one kept graph.
+    if args.keep_graphs <= 0 and args.recompute < 0 and strong and b <= 128:
+        args.keep_graphs, args.recompute = args.micro_batches, 3
     if args.keep_graphs <= 0:
-        # two kept graphs = 232 GB of activations; at N = 1 the 1024-pair fp32 input batch itself occupies 34 GB (262 GB
-        # peak measured): one kept graph there, two from N = 2 (512 pairs per GPU) on
         args.keep_graphs = 2 if (strong and b <= 512) else 1
     util.GlobalEnv.reset()
     torch.manual_seed(10)
-    model = build_model(model_cfg(enc_name, fp8), LOSS_CFG, types.SimpleNamespace(vocab_size=28996)).to(device)
+    if args.recompute < 0:
+        args.recompute = 0
+    model = build_model(model_cfg(enc_name, fp8, args.recompute), LOSS_CFG, types.SimpleNamespace(vocab_size=28996)).to(device)
     loss_func = build_loss(LOSS_CFG)
     opt = build_optimizer(model, {"name": "adamw", "config": {"lr": 5e-5, "weight_decay": 1e-4}})
     sched = LinearWarmupCosineAnnealingLR(opt, total_steps=10000, warmup_steps=100)
@@ -247,7 +258,8 @@ def main():
                                    f"(2 views + 2 reports each), {H}x{W} images, {T}-token reports, breast_clip loss, "
                                    f"AdamW; fwd+loss+bwd+optimizer; dropout/drop-connect on",
                        "global_batch": b * world, "parallelism": f"dp{world}" + (f" x {args.micro_batches} micro-batches" if args.micro_batches > 1 else ""),
-                       "loss": round(loss_val, 5), "peak_hbm_gb": round(peak_gb, 1)},
+                       "loss": round(loss_val, 5), "peak_hbm_gb": round(peak_gb, 1),
+                       "keep_graphs": args.keep_graphs, "recompute": args.recompute},
             "roofline": first, "roofline_runner_up": second,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -21,6 +21,8 @@ def load_image_encoder(config_image_encoder: Dict):
         raise KeyError(f"Not supported image encoder: {config_image_encoder}")
     # extension key (BASELINE config #5): fp8 (OCP e4m3, per-tensor scaled) operands for the late-stage 1x1 convolutions
     enc.set_fp8(bool(config_image_encoder.get("fp8", False)))
+    # extension key: activation recompute mode of the MBConv blocks (memory of a kept graph vs backward work)
+    enc.set_recompute(int(config_image_encoder.get("recompute", 0)))
     return enc
 
 

@@ -144,6 +144,17 @@ class _StemFn(torch.autograd.Function):
         return None, dw[:, :27].reshape(c0, 3, 3, 3), dgamma, dbeta, None
 
 
+def _expand_conv(blk, x, we, rows):
+    """_expand_conv of one block: e [rows, cexp] bf16 + the BatchNorm0 column-statistic partials (deterministic: the
+    backward's recompute mode reproduces the forward's tensor bit for bit)."""
+    a = blk.args
+    if blk.fp8 and a.cin % 16 == 0 and not ops._rows_ok(rows, a.cexp, a.cin, None, 0):
+        # config #5: fp8 (e4m3, per-tensor scale) activations and weights on the fp8 MFMA; BatchNorm statistics
+        # and everything downstream stay on the bf16 / fp32 path; backward uses the bf16 tensors (straight-through)
+        return ops.linear_fwd_fp8(x, we, stats=True)
+    return ops.linear_fwd(x, we, stats=True)
+
+
 class _MBConvFn(torch.autograd.Function):
     """One MBConvBlock, forward + hand-derived backward [ref: efficientnet_custom.py:91-132]."""
 
@@ -156,17 +167,13 @@ class _MBConvFn(torch.autograd.Function):
         oh, ow = _out_extent(h, t, b, k, s), _out_extent(w, l, r, k, s)
         hw, ohw = h * w, oh * ow
         saved = {}
+        rc = blk.recompute
         if a.expand != 1:
             we = ops.cast_bf16(blk._expand_conv.weight.view(a.cexp, a.cin))
-            if blk.fp8 and a.cin % 16 == 0 and not ops._rows_ok(n * hw, a.cexp, a.cin, None, 0):
-                # config #5: fp8 (e4m3, per-tensor scale) activations and weights on the fp8 MFMA; BatchNorm statistics
-                # and everything downstream stay on the bf16 / fp32 path; backward uses the bf16 tensors (straight-through)
-                e, part0 = ops.linear_fwd_fp8(x, we, stats=True)
-            else:
-                e, part0 = ops.linear_fwd(x, we, stats=True)
+            e, part0 = _expand_conv(blk, x, we, n * hw)
             st0 = _bn_stats(part0, n * hw, blk._bn0, training)
             dw_in, pro0 = e, (st0.scale, st0.shift)
-            saved.update(we=we, e=e, st0=st0)
+            saved.update(we=we, e=None if rc >= 1 else e, st0=st0)
         else:
             dw_in, pro0 = x, None
         wkkc = ops.transpose_f32(blk._depthwise_conv.weight.view(a.cexp, k * k), cache=True)
@@ -192,7 +199,11 @@ class _MBConvFn(torch.autograd.Function):
         st2 = _bn_stats(part2, n * ohw, blk._bn2, training)
         y = ops.bnact_apply(p, n, ohw, a.cout, st2.scale, st2.shift, 0,
                             rowscale=rowscale if a.skip else None, res=x if a.skip else None)
-        saved.update(x=x, d=d, p=p, wkkc=wkkc, wp=wp, st1=st1, st2=st2, pooled=pooled, gate=gate, act1=act1,
+        # recompute modes (activation memory of a kept graph, see EfficientNet.set_recompute): 1 drops the expanded
+        # tensor e, 2 also the depthwise output d (+ the stored activation of the late stages); the backward rebuilds
+        # them from the block input x and the saved BatchNorm coefficients
+        saved.update(x=x, d=None if rc >= 2 else d, p=p, wkkc=wkkc, wp=wp, st1=st1, st2=st2, pooled=pooled, gate=gate,
+                     act1=None if rc >= 2 else act1, keep_act=keep,
                      rowscale=rowscale if a.skip else None, geo=(n, h, w, oh, ow))
         ctx.blk, ctx.saved = blk, saved
         blk._out_geo = (n, oh, ow)
@@ -209,13 +220,24 @@ class _MBConvFn(torch.autograd.Function):
         dy = dy.contiguous()
         x, d, p = sv["x"], sv["d"], sv["p"]
         st1, st2, gate, pooled = sv["st1"], sv["st2"], sv["gate"], sv["pooled"]
+        e, act1 = sv.get("e"), sv["act1"]
+        if a.expand != 1:
+            st0 = sv["st0"]
+            if e is None:
+                e = _expand_conv(blk, x, sv["we"], n * hw)[0]
+        if d is None:
+            d = ops.dwconv_fwd(e if a.expand != 1 else x, sv["wkkc"], n, h, w, a.cexp, k, s, l, t, oh, ow,
+                               pro=(st0.scale, st0.shift) if a.expand != 1 else None, stats=True)[0]
+            if sv["keep_act"]:
+                act1 = ops.bnact_pool(d, n, ohw, a.cexp, st1.scale, st1.shift, 1, keep_act=True)[1]
         # y = bn2(p) * rowscale + x
         dp, dg2, db2 = ops.bnact_bwd(p, n, ohw, a.cout, st2, blk._bn2.weight, 0, g=dy, rowscale=sv["rowscale"])
         # project 1x1: p = A1 . wp^T, A1 = silu(bn1(d)) * gate   (A1 is recomputed inside the wgrad GEMM)
         wp_t = ops.cast_transpose_bf16(blk._project_conv.weight.view(a.cout, a.cexp))      # [cexp, cout]
         da1 = ops.linear_dgrad(dp, sv["wp"], w_t=wp_t)
-        if sv["act1"] is not None:
-            dwp = ops.linear_wgrad(dp, sv["act1"], pro=(None, None, gate, ohw))
+        if act1 is not None:
+            dwp = ops.linear_wgrad(dp, act1, pro=(None, None, gate, ohw))
+            del act1
         else:
             dwp = ops.linear_wgrad(dp, d, pro=(st1.scale, st1.shift, gate, ohw))
         # squeeze-excite
@@ -230,9 +252,9 @@ class _MBConvFn(torch.autograd.Function):
                                       add_scale=1.0 / ohw, partials=part1)
         del da1
         # depthwise
+        del d
         if a.expand != 1:
-            st0 = sv["st0"]
-            dw_in, pro0 = sv["e"], (st0.scale, st0.shift)
+            dw_in, pro0 = e, (st0.scale, st0.shift)
         else:
             dw_in, pro0 = x, None
         dwdw = ops.dwconv_bwd_weight(dw_in, dd, n, h, w, a.cexp, k, s, l, t, oh, ow, pro=pro0)
@@ -243,16 +265,16 @@ class _MBConvFn(torch.autograd.Function):
             # output position, writes dZ0 = dA0 * silu'(bn0(e)) and leaves the BatchNorm-backward reductions behind, so
             # the separate reduce pass over (e, dA0) is gone and the apply pass is a plain linear combination
             dz0, part0 = ops.dwconv_bwd_data(dd, sv["wkkc"], n, h, w, a.cexp, k, s, l, t, oh, ow, w_kkc_flipped=wflip,
-                                             epi=(sv["e"], st0))
+                                             epi=(e, st0))
             del dd
-            de, dg0, db0 = ops.bnact_bwd(sv["e"], n, hw, a.cexp, st0, blk._bn0.weight, 0, g=dz0, partials=part0)
-            del dz0
+            de, dg0, db0 = ops.bnact_bwd(e, n, hw, a.cexp, st0, blk._bn0.weight, 0, g=dz0, partials=part0)
+            del dz0, e, dw_in
         else:
             da0 = ops.dwconv_bwd_data(dd, sv["wkkc"], n, h, w, a.cexp, k, s, l, t, oh, ow, w_kkc_flipped=wflip)
             del dd
             if a.expand != 1:
-                de, dg0, db0 = ops.bnact_bwd(sv["e"], n, hw, a.cexp, st0, blk._bn0.weight, 1, g=da0)
-                del da0
+                de, dg0, db0 = ops.bnact_bwd(e, n, hw, a.cexp, st0, blk._bn0.weight, 1, g=da0)
+                del da0, e, dw_in
         if a.expand != 1:
             we_t = ops.cast_transpose_bf16(blk._expand_conv.weight.view(a.cexp, a.cin))     # [cin, cexp]
             dx = ops.linear_dgrad(de, sv["we"], residual=dy if a.skip else None, w_t=we_t)
@@ -371,6 +393,7 @@ class MBConvBlock(nn.Module):
                          bool(a.id_skip and s == 1 and cin == a.output_filters))
         self._param_names = [n for n, _ in self.named_parameters()]
         self.fp8 = False
+        self.recompute = 0
         self.register_buffer("_ones", torch.ones(cin), persistent=False)
         self.register_buffer("_zeros", torch.zeros(cin), persistent=False)
 
@@ -461,6 +484,20 @@ class EfficientNet(nn.Module):
         self.fp8 = bool(on)
         for blk in self._blocks:
             blk.fp8 = bool(on)
+        return self
+
+    def set_recompute(self, mode: int = 0):
+        """Activation memory of a kept autograd graph against backward work (the micro-batched contrastive step keeps as
+        many micro-batch graphs as fit and re-runs the forward of the others): 0 = every MBConv block stores its expanded
+        tensor e and its depthwise output d (the two big ones, ~72 % of the graph); 1 = e is rebuilt in the backward by
+        one more expand GEMM from the block input; 2 = e and d (and the stored late-stage activation) are rebuilt
+        (expand GEMM + depthwise forward); 3 = mode 1 everywhere plus mode 2 on the blocks whose depthwise stage is a
+        stride-1 3x3 (the depthwise kernels that run near HBM rate: 45 % of the d bytes of B5 for ~1.5 % more work).
+        Same kernels on the same operands: gradients agree across modes to the spread of the atomically reduced ones."""
+        assert mode in (0, 1, 2, 3)
+        for blk in self._blocks:
+            a = blk.args
+            blk.recompute = int(mode) if mode < 3 else (2 if (a.k == 3 and a.s == 1 and a.expand != 1) else 1)
         return self
 
     def set_swish(self, memory_efficient=True):

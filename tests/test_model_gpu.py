@@ -459,3 +459,36 @@ def test_fp8_pointwise_convs_config5():
     for n, p in model.named_parameters():
         assert p.grad is None or torch.isfinite(p.grad).all(), n
     print("fp8", rep, float(ld["total"]))
+
+
+def test_recompute_modes_same_gradients_less_memory():
+    """EfficientNet.set_recompute(1 | 2): the MBConv backward rebuilds the expanded tensor (and the depthwise output) from
+    the block input instead of keeping them in the graph -- same kernels on the same operands, so loss and embeddings are
+    bit-identical and gradients agree to the run-to-run spread of the atomically reduced ones; the graph held between
+    forward and backward shrinks with every mode."""
+    z = np.load(os.path.join(GOLDEN, "e2e_b5_small.npz"))
+    b, H, W, T = [int(v) for v in z["meta"]]
+    model, lossf, sd = _build("tf_efficientnet_b5_ns-detect", "efficientnet-b5")
+    batch = ow.synth_batch(b, H, W, T, seed=33)
+    res = {}
+    for mode in (0, 1, 3, 2):
+        model.image_encoder.set_recompute(mode)
+        assert {blk.recompute for blk in model.image_encoder._blocks} == ({mode} if mode < 3 else {1, 2})
+        model.zero_grad(set_to_none=True)
+        torch.cuda.synchronize()
+        base = torch.cuda.memory_allocated()
+        out, ld = _run(model, lossf, batch, True)
+        torch.cuda.synchronize()
+        held = torch.cuda.memory_allocated() - base
+        ld["total"].backward()
+        res[mode] = (float(ld["total"]), out["image_embeddings"].detach().clone(),
+                     {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}, held)
+    for mode in (1, 2, 3):
+        assert res[mode][0] == res[0][0]
+        assert torch.equal(res[mode][1], res[0][1])
+        assert res[mode][2].keys() == res[0][2].keys()
+        for n, g in res[0][2].items():
+            assert relerr(res[mode][2][n], g) < 1e-3, (mode, n, relerr(res[mode][2][n], g))
+    print("graph bytes held after forward by mode:", {m: res[m][3] for m in res})
+    assert res[1][3] < 0.8 * res[0][3] and res[2][3] < 0.6 * res[0][3] and res[2][3] < res[3][3] < res[1][3], \
+        {m: res[m][3] for m in res}
