@@ -123,6 +123,7 @@ typedef struct mc_gemm_rows_args {
     const float* pro_gate;
     long long pro_rows_per_img;
     float* stat_partials;
+    const float* bias;       /* optional float[N], added to every output row (after the statistics, with the residual) */
 } mc_gemm_rows_args;
 int mc_gemm_rows_supported(int n, int k);
 int mc_gemm_rows_blocks(long long m);
@@ -278,6 +279,20 @@ int mc_bn_partials_from_se_sums(const float* sums, const float* gate, const floa
 int mc_bn_bwd_finalize(const float* partials, int rows, int c, double count, const float* gamma,
                        const float* mean, const float* invstd, float* dgamma, float* dbeta, float* coef,
                        void* stream);
+
+/* Training-mode BatchNorm backward folded into the 1x1 convolution in front of it (bnfold.hip; MBConv expand conv +
+ * _bn0 [ref: efficientnet_custom.py:104-107]): with e = x We^T (We [n, k] fp32), coef = (A, B, C) from
+ * mc_bn_bwd_finalize, dbeta = sum dz and rows = pixels,
+ *     dx  = dz (A.We) + x G + cvec        dWe = A.(dz^T x - mean(dz) (x) colsum(x)) + (B.We) Sxx
+ * so the consumers of de read dz and x only.  prepare: w1t [k, n] = bf16((A.We)^T), wb [n, k] = bf16(B.We),
+ * sxx [k, k] = bf16(x^T x - colsum(x) (x) colsum(x) / rows);  cvec: gt [k, k] = (We^T wb)^T fp32 -> gtb bf16 and
+ * cvec [k];  wgrad: dwe = A.(t1 - mean(dz) (x) colsum(x)) + wx  with t1 = dz^T x and wx = wb . sxx */
+int mc_bn_fold_prepare(const float* we, const float* coef, const float* xtx, const float* colsum_x, double rows, int n,
+                       int k, mc_bf16* w1t, mc_bf16* wb, mc_bf16* sxx, void* stream);
+int mc_bn_fold_cvec(const float* gt, const float* we, const float* coef, const float* dbeta, const float* colsum_x,
+                    double rows, int n, int k, mc_bf16* gtb, float* cvec, void* stream);
+int mc_bn_fold_wgrad(const float* t1, const float* wx, const float* coef, const float* dbeta, const float* colsum_x,
+                     double rows, int n, int k, float* dwe, void* stream);
 
 /* column sums of a bf16 matrix: out[c] = sum_m x[m, c]  (bias gradients).  partials: float[rows][c] */
 int mc_colsum_rows(long long m, int c);

@@ -21,6 +21,8 @@ import math
 from collections import namedtuple
 from typing import List, Optional
 
+import os
+
 import torch
 from torch import nn
 
@@ -107,6 +109,11 @@ def _bn_stats(partials, count, bn: nn.BatchNorm2d, training: bool):
                 bn.num_batches_tracked += 1
         return st
     return ops.bn_eval_coeffs(bn.weight, bn.bias, bn.running_mean, bn.running_var, BN_EPS)
+
+
+# expanded-tensor bytes per call from which the BatchNorm0 backward is folded into the expand conv's gradient GEMMs
+# (ops.bn_fold_expand_bwd) instead of running the apply pass; tests set it to 0 to exercise the folded path at small sizes
+BN_FOLD_MIN_BYTES = int(os.environ.get("MC_BN_FOLD_MIN_BYTES", 400_000_000))
 
 
 class _StemFn(torch.autograd.Function):
@@ -267,8 +274,20 @@ class _MBConvFn(torch.autograd.Function):
             dz0, part0 = ops.dwconv_bwd_data(dd, sv["wkkc"], n, h, w, a.cexp, k, s, l, t, oh, ow, w_kkc_flipped=wflip,
                                              epi=(e, st0))
             del dd
-            de, dg0, db0 = ops.bnact_bwd(e, n, hw, a.cexp, st0, blk._bn0.weight, 0, g=dz0, partials=part0)
-            del dz0, e, dw_in
+            if 2 * n * hw * a.cexp >= BN_FOLD_MIN_BYTES:
+                # bn0 backward is linear in (dZ0, e) and e = x We^T: it is folded into the operands of the expand conv's
+                # two gradient GEMMs (ops.bn_fold_expand_bwd) -- de is never formed, e is not read again.  Three passes
+                # over the expanded tensor against ~10 small launches and 6 passes over the (6x smaller) block input:
+                # pays from ~0.4 GB of expanded tensor per call (measured: B5 blocks 4-12 at 32 x 1520 x 912)
+                del e, dw_in
+                coef0, dg0, db0 = ops.bn_bwd_coefs(part0, n * hw, st0, blk._bn0.weight)
+                dx, dwe = ops.bn_fold_expand_bwd(dz0, x, blk._expand_conv.weight.view(a.cexp, a.cin), sv["we"], coef0,
+                                                 db0, n * hw, residual=dy if a.skip else None)
+                de = None
+            else:
+                de, dg0, db0 = ops.bnact_bwd(e, n, hw, a.cexp, st0, blk._bn0.weight, 0, g=dz0, partials=part0)
+                del e, dw_in
+            del dz0
         else:
             da0 = ops.dwconv_bwd_data(dd, sv["wkkc"], n, h, w, a.cexp, k, s, l, t, oh, ow, w_kkc_flipped=wflip)
             del dd
@@ -276,9 +295,10 @@ class _MBConvFn(torch.autograd.Function):
                 de, dg0, db0 = ops.bnact_bwd(e, n, hw, a.cexp, st0, blk._bn0.weight, 1, g=da0)
                 del da0, e, dw_in
         if a.expand != 1:
-            we_t = ops.cast_transpose_bf16(blk._expand_conv.weight.view(a.cexp, a.cin))     # [cin, cexp]
-            dx = ops.linear_dgrad(de, sv["we"], residual=dy if a.skip else None, w_t=we_t)
-            dwe = ops.linear_wgrad(de, x)
+            if de is not None:
+                we_t = ops.cast_transpose_bf16(blk._expand_conv.weight.view(a.cexp, a.cin))     # [cin, cexp]
+                dx = ops.linear_dgrad(de, sv["we"], residual=dy if a.skip else None, w_t=we_t)
+                dwe = ops.linear_wgrad(de, x)
             grads["_expand_conv.weight"] = dwe.view(a.cexp, a.cin, 1, 1)
             grads["_bn0.weight"], grads["_bn0.bias"] = dg0, db0
         else:

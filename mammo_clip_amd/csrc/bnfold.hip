@@ -1,0 +1,99 @@
+// Training-mode BatchNorm backward folded into the 1x1 convolution in front of it (MBConv expand conv + _bn0):
+//     e = x We^T,  z = bn0(e),  dz = dL/dz (already through the activation),
+//     de = A (dz - m) + B (e - mu),   A = gamma*invstd,  B = -gamma*invstd^2 * mean(dz*xhat),  m = mean(dz)
+// is LINEAR in dz and e, and e - mu = (x - xbar) We^T, so the two consumers of de need neither de nor e:
+//     dx  = de We      = dz (A.We) + x G + cvec,         G = We^T diag(B) We,  cvec = -(A.m) We - xbar G
+//     dWe = de^T x     = A.(dz^T x - m (x) colsum(x)) + (B.We) Sxx,      Sxx = x^T x - colsum(x) (x) colsum(x) / rows
+// The three small-matrix kernels below build the folded operands; the big passes are plain GEMMs over dz and x
+// (the expanded tensors e / de are not touched again: three passes over the expanded tensor per block are gone).
+// [ref: efficientnet_custom.py:104-107 (_expand_conv, _bn0, swish), torch BatchNorm2d training-mode backward]
+#include "common_hip.h"
+#include "../../include/mammoclip_hip.h"
+
+namespace {
+
+// w1t[j][i] = bf16(We[i][j] * A[i]);  wb[i][j] = bf16(We[i][j] * B[i]);  sxx[i][j] = bf16(xtx[i][j] - cs[i] cs[j] / rows)
+__global__ void fold_prepare_k(const float* __restrict__ we, const float* __restrict__ coef, const float* __restrict__ xtx,
+                               const float* __restrict__ cs, double rows, int n, int k, bf16_t* __restrict__ w1t,
+                               bf16_t* __restrict__ wb, bf16_t* __restrict__ sxx) {
+    const long long nk = (long long)n * k, total = nk + (long long)k * k;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        if (idx < nk) {
+            const int i = (int)(idx / k), j = (int)(idx % k);
+            const float w = we[idx];
+            w1t[(long long)j * n + i] = f2bf(w * coef[i]);
+            wb[idx] = f2bf(w * coef[n + i]);
+        } else {
+            const long long r = idx - nk;
+            const int i = (int)(r / k), j = (int)(r % k);
+            sxx[r] = f2bf((float)((double)xtx[r] - (double)cs[i] * (double)cs[j] / rows));
+        }
+    }
+}
+
+// one workgroup per output column j: gtb[j][:] = bf16(gt[j][:]),
+// cvec[j] = -sum_i A[i] m[i] We[i][j] - sum_i xbar[i] gtb[j][i]      (m = dbeta / rows, xbar = cs / rows)
+__global__ __launch_bounds__(256) void fold_cvec_k(const float* __restrict__ gt, const float* __restrict__ we,
+                                                   const float* __restrict__ coef, const float* __restrict__ dbeta,
+                                                   const float* __restrict__ cs, double rows, int n, int k,
+                                                   bf16_t* __restrict__ gtb, float* __restrict__ cvec) {
+    const int j = blockIdx.x;
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) acc += (double)coef[i] * (double)dbeta[i] * (double)we[(long long)i * k + j];
+    for (int i = threadIdx.x; i < k; i += 256) {
+        const bf16_t g = f2bf(gt[(long long)j * k + i]);
+        gtb[(long long)j * k + i] = g;
+        acc += (double)cs[i] * (double)bf2f(g);
+    }
+    __shared__ double red[256];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) cvec[j] = (float)(-red[0] / rows);
+}
+
+// dwe[i][j] = A[i] * (t1[i][j] - m[i] cs[j]) + wx[i][j]
+__global__ void fold_wgrad_k(const float* __restrict__ t1, const float* __restrict__ wx, const float* __restrict__ coef,
+                             const float* __restrict__ dbeta, const float* __restrict__ cs, double rows, int n, int k,
+                             float* __restrict__ dwe) {
+    const long long total = (long long)n * k;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int i = (int)(idx / k), j = (int)(idx % k);
+        const float m = (float)((double)dbeta[i] / rows);
+        dwe[idx] = coef[i] * (t1[idx] - m * cs[j]) + wx[idx];
+    }
+}
+
+}  // namespace
+
+extern "C" int mc_bn_fold_prepare(const float* we, const float* coef, const float* xtx, const float* colsum_x, double rows,
+                                  int n, int k, mc_bf16* w1t, mc_bf16* wb, mc_bf16* sxx, void* stream) {
+    MC_CHECK(we && coef && xtx && colsum_x && w1t && wb && sxx && n > 0 && k > 0 && rows > 0, "bn_fold_prepare: bad args");
+    const long long total = (long long)n * k + (long long)k * k;
+    hipLaunchKernelGGL(fold_prepare_k, dim3((unsigned)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048)), dim3(256), 0,
+                       (hipStream_t)stream, we, coef, xtx, colsum_x, rows, n, k, (bf16_t*)w1t, (bf16_t*)wb, (bf16_t*)sxx);
+    MC_LAUNCH_CHECK();
+    return MC_OK;
+}
+
+extern "C" int mc_bn_fold_cvec(const float* gt, const float* we, const float* coef, const float* dbeta,
+                               const float* colsum_x, double rows, int n, int k, mc_bf16* gtb, float* cvec, void* stream) {
+    MC_CHECK(gt && we && coef && dbeta && colsum_x && gtb && cvec && n > 0 && k > 0 && rows > 0, "bn_fold_cvec: bad args");
+    hipLaunchKernelGGL(fold_cvec_k, dim3(k), dim3(256), 0, (hipStream_t)stream, gt, we, coef, dbeta, colsum_x, rows, n, k,
+                       (bf16_t*)gtb, cvec);
+    MC_LAUNCH_CHECK();
+    return MC_OK;
+}
+
+extern "C" int mc_bn_fold_wgrad(const float* t1, const float* wx, const float* coef, const float* dbeta,
+                                const float* colsum_x, double rows, int n, int k, float* dwe, void* stream) {
+    MC_CHECK(t1 && wx && coef && dbeta && colsum_x && dwe && n > 0 && k > 0 && rows > 0, "bn_fold_wgrad: bad args");
+    const long long total = (long long)n * k;
+    hipLaunchKernelGGL(fold_wgrad_k, dim3((unsigned)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048)), dim3(256), 0,
+                       (hipStream_t)stream, t1, wx, coef, dbeta, colsum_x, rows, n, k, dwe);
+    MC_LAUNCH_CHECK();
+    return MC_OK;
+}

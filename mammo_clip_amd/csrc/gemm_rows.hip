@@ -66,9 +66,10 @@ __global__ __launch_bounds__(256, 2) void gemm_rows_kernel(const mc_gemm_rows_ar
     const int slots = 64 / cpr;                     // rows written concurrently by one wave
     const int c8 = lane % cpr, rs = lane / cpr;
     const bool ep_active = rs < slots;
-    float ssum[8], ssq[8];
+    float ssum[8], ssq[8], bias8[8];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) { ssum[q] = 0.f; ssq[q] = 0.f; }
+    for (int q = 0; q < 8; ++q) { ssum[q] = 0.f; ssq[q] = 0.f; bias8[q] = 0.f; }
+    if (p.bias && ep_active) load8f(p.bias + n0 + c8 * 8, bias8);
 
     // PF 32-row groups per wave are in flight (narrow K = few bytes per group: latency needs several groups ahead)
     uint4 xn[PF][RG][KC];
@@ -156,11 +157,13 @@ __global__ __launch_bounds__(256, 2) void gemm_rows_kernel(const mc_gemm_rows_ar
 #pragma unroll
                             for (int q = 0; q < 8; ++q) { ssum[q] += a[q]; ssq[q] += a[q] * a[q]; }
                         }
-                        if (p.R) {
+                        if (p.R || p.bias) {
                             float b[8];
-                            unpack8(*reinterpret_cast<const uint4*>(p.R + m * p.ldr + n0 + c8 * 8), b);
 #pragma unroll
-                            for (int q = 0; q < 8; ++q) a[q] += b[q];
+                            for (int q = 0; q < 8; ++q) b[q] = 0.f;
+                            if (p.R) unpack8(*reinterpret_cast<const uint4*>(p.R + m * p.ldr + n0 + c8 * 8), b);
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) a[q] += b[q] + bias8[q];
                             v = pack8(a);
                         }
                         *reinterpret_cast<uint4*>(p.C + m * p.ldc + n0 + c8 * 8) = v;

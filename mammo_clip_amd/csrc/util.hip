@@ -221,7 +221,21 @@ __global__ __launch_bounds__(256) void colsum_partial_k(const bf16_t* __restrict
 #pragma unroll
         for (int q = 0; q < 8; ++q) acc[q] = 0.f;
         if (rl < rpb && v < cv) {
-            for (long long r = (long long)blockIdx.x * rpb + rl; r < m; r += (long long)gridDim.x * rpb) {
+            const long long rstep = (long long)gridDim.x * rpb;
+            long long r = (long long)blockIdx.x * rpb + rl;
+            for (; r + 3 * rstep < m; r += 4 * rstep) {            // four independent 16-byte loads in flight per thread
+                uint4 u[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) u[i] = *reinterpret_cast<const uint4*>(x + (r + i * rstep) * ld + v * 8);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float f[8];
+                    unpack8(u[i], f);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) acc[q] += f[q];
+                }
+            }
+            for (; r < m; r += rstep) {
                 float f[8];
                 unpack8(*reinterpret_cast<const uint4*>(x + r * ld + v * 8), f);
 #pragma unroll

@@ -44,7 +44,7 @@ class GemmRowsArgs(C.Structure):
         ("C", P), ("ldc", LL),
         ("R", P), ("ldr", LL),
         ("pro_scale", P), ("pro_shift", P), ("pro_gate", P), ("pro_rows_per_img", LL),
-        ("stat_partials", P),
+        ("stat_partials", P), ("bias", P),
     ]
 
 
@@ -132,6 +132,9 @@ _SIGS = {
     "mc_add_ln_bwd": ([P, P, P, P, P, P, LL, I, F, ULL, U, P, P, P, P, P], I),
     "mc_softmax_fwd": ([P, LL, I, F, ULL, U, P, P, P], I),
     "mc_softmax_bwd": ([P, P, LL, I, F, ULL, U, F, P, P], I),
+    "mc_bn_fold_prepare": ([P, P, P, P, D, I, I, P, P, P, P], I),
+    "mc_bn_fold_cvec": ([P, P, P, P, P, D, I, I, P, P, P], I),
+    "mc_bn_fold_wgrad": ([P, P, P, P, P, D, I, I, P, P], I),
     "mc_attn_supported": ([I, I], I),
     "mc_attn_fwd": ([P, P, I, I, I, F, F, ULL, U, P, P, P], I),
     "mc_attn_bwd": ([P, P, P, P, I, I, I, F, F, ULL, U, P, P], I),

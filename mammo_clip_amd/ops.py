@@ -129,7 +129,7 @@ def linear_fwd_fp8(x, w, amax_x=None, amax_w=None, stats=False, batch_w=None):
 ROWS_MIN_M = 8192       # below this the tiled kernel is as good
 
 
-def gemm_rows(x, w, y, residual=None, pro=None, stat_partials=None, kind=None):
+def gemm_rows(x, w, y, residual=None, pro=None, stat_partials=None, kind=None, bias=None):
     a = L.GemmRowsArgs()
     M, K = x.shape
     N = w.shape[0]
@@ -140,13 +140,13 @@ def gemm_rows(x, w, y, residual=None, pro=None, stat_partials=None, kind=None):
         a.R, a.ldr = _p(residual), residual.stride(0)
     if pro is not None:
         a.pro_scale, a.pro_shift, a.pro_gate, a.pro_rows_per_img = _p(pro[0]), _p(pro[1]), _p(pro[2]), pro[3]
-    a.stat_partials = _p(stat_partials)
+    a.stat_partials, a.bias = _p(stat_partials), _p(bias)
     _note(2 * M * (K + N) + 2 * N * K + (2 * M * N if residual is not None else 0), 2 * M * N * K)
     L.call("mc_gemm_rows_bf16", C.byref(a), _st(), kind=kind)
 
 
 def _rows_ok(M, N, K, bias, act):
-    return bias is None and act == 0 and M >= ROWS_MIN_M and L.load().mc_gemm_rows_supported(N, K)
+    return act == 0 and M >= ROWS_MIN_M and L.load().mc_gemm_rows_supported(N, K)
 
 
 # Derived weight images (bf16 casts / transposes of fp32 master parameters) are reused until the parameter changes:
@@ -214,14 +214,14 @@ def cast_transpose_bf16(src2d):
     return _cached("ct", src2d, make)
 
 
-def linear_fwd(x, w, bias=None, act=0, residual=None, stats=False, pro=None, out=None):
+def linear_fwd(x, w, bias=None, act=0, residual=None, stats=False, pro=None, out=None, tag=""):
     """y[M,N] = x[M,K] . w[N,K]^T (+bias)(act)(+residual).  stats -> also returns [rows,2,N] partials."""
     M, K = x.shape
     N = w.shape[0]
     y = out if out is not None else empty((M, N), BF16, x)
     if _rows_ok(M, N, K, bias, act) and (pro is None or pro[0] is not None):
         part = empty((L.load().mc_gemm_rows_blocks(M), 2, N), torch.float32, x) if stats else None
-        gemm_rows(x, w, y, residual=residual, pro=pro, stat_partials=part, kind="fwd_rows")
+        gemm_rows(x, w, y, residual=residual, pro=pro, stat_partials=part, kind="fwd_rows" + tag, bias=bias)
         return (y, part) if stats else y
     if pro is not None and pro[0] is None and residual is None and bias is None and M % pro[3] == 0 and pro[3] >= 256:
         # x is already activated and only carries the per-image gate: one GEMM per image (batched) whose weight tile
@@ -241,7 +241,7 @@ def linear_fwd(x, w, bias=None, act=0, residual=None, stats=False, pro=None, out
     if pro is not None:
         p = (1, pro[0], pro[1], pro[2], pro[3], K)
     part = gemm(x, w, y, M, N, K, x.stride(0), w.stride(0), y.stride(0), bias=bias, act=act, R=residual,
-                ldr=(residual.stride(0) if residual is not None else 0), pro=p, stats=stats, kind="fwd")
+                ldr=(residual.stride(0) if residual is not None else 0), pro=p, stats=stats, kind="fwd" + tag)
     return (y, part) if stats else y
 
 
@@ -280,7 +280,7 @@ def _wgrad_splits(m, n, k):
     return s
 
 
-def linear_wgrad(dy, x, pro=None, out=None):
+def linear_wgrad(dy, x, pro=None, out=None, tag=""):
     """dw[N,K] (fp32) = dy[M,N]^T . x'[M,K]; x' = prologue(x) when pro = (scale, shift, gate, rows_per_img)."""
     M, N = dy.shape
     K = x.shape[1]
@@ -294,7 +294,7 @@ def linear_wgrad(dy, x, pro=None, out=None):
         if pro is not None:
             a.pro_scale, a.pro_shift, a.pro_gate, a.pro_rows_per_img = _p(pro[0]), _p(pro[1]), _p(pro[2]), pro[3]
         _note(2 * M * (N + K) + 4 * N * K, 2 * M * N * K)
-        L.call("mc_wgrad_rows_bf16", C.byref(a), _st(), kind="wgrad_rows")
+        L.call("mc_wgrad_rows_bf16", C.byref(a), _st(), kind="wgrad_rows" + tag)
         return dw
     if pro is not None and pro[0] is None and M % pro[3] == 0:
         # x is already activated and only carries the per-image gate: cut the reduction at image boundaries and apply
@@ -307,7 +307,7 @@ def linear_wgrad(dy, x, pro=None, out=None):
         splits = n_img * sub
         ws = empty((splits, N, K), torch.float32, dy)
         gemm(dy, x, dw, N, K, M, dy.stride(0), x.stride(0), dw.stride(0), a_kmajor=1, b_kmajor=1, c_f32=1,
-             c_atomic=(1 if out is not None else 0), splits=splits, splitk_ws=ws, split_groups=(hw, sub, pro[2]), kind="wgrad")
+             c_atomic=(1 if out is not None else 0), splits=splits, splitk_ws=ws, split_groups=(hw, sub, pro[2]), kind="wgrad" + tag)
         return dw
     p = None
     if pro is not None:
@@ -315,7 +315,7 @@ def linear_wgrad(dy, x, pro=None, out=None):
     splits = _wgrad_splits(N, K, M)
     ws = empty((splits, N, K), torch.float32, dy) if splits > 1 else None
     gemm(dy, x, dw, N, K, M, dy.stride(0), x.stride(0), dw.stride(0), a_kmajor=1, b_kmajor=1, c_f32=1,
-         c_atomic=(1 if out is not None else 0), splits=splits, pro=p, splitk_ws=ws, kind="wgrad")
+         c_atomic=(1 if out is not None else 0), splits=splits, pro=p, splitk_ws=ws, kind="wgrad" + tag)
     return dw
 
 
@@ -599,6 +599,39 @@ def bnact_bwd(x, n_img, hw, c, stats, gamma, act, g=None, mul=None, add=None, ro
     _note(2 * n_img * hw * c * (3 if g is not None else 2))
     L.call("mc_bnact_bwd_apply", C.byref(a), _st())
     return dx, dgamma, dbeta
+
+
+def bn_bwd_coefs(partials, count, stats, gamma):
+    """Finalize a BatchNorm-backward reduction: partials [rows, 2, c] = (sum dz, sum dz*xhat) -> (coef [3, c], dgamma,
+    dbeta) with dx = coef[0]*dz + coef[1]*x + coef[2] (the apply pass, or the folded GEMM operands of bn_fold_*)."""
+    c = partials.shape[-1]
+    dgamma, dbeta = empty((c,), torch.float32, partials), empty((c,), torch.float32, partials)
+    coef = empty((3, c), torch.float32, partials)
+    L.call("mc_bn_bwd_finalize", _p(partials), partials.shape[0], c, float(count), _p(gamma), _p(stats.mean),
+           _p(stats.invstd), _p(dgamma), _p(dbeta), _p(coef), _st())
+    return coef, dgamma, dbeta
+
+
+def bn_fold_expand_bwd(dz, x, we_f32, we_bf16, coef, dbeta, rows, residual=None):
+    """Backward of e = x We^T under training-mode BatchNorm, from dz = dL/d bn(e) alone (bnfold.hip): returns
+    (dx [rows, cin] bf16 (+ residual), dWe [cexp, cin] fp32).  Neither e nor de is read or written: the BatchNorm
+    backward's linear combination lives in the small folded operands (A.We, G = We^T diag(B) We, Sxx)."""
+    n, k = we_f32.shape
+    t1 = linear_wgrad(dz, x)                               # dz^T x   [cexp, cin]
+    xtx = linear_wgrad(x, x, tag="_xtx")                   # x^T x    [cin, cin]
+    cs = colsum(x)
+    w1t, wb, sxx = empty((k, n), BF16, x), empty((n, k), BF16, x), empty((k, k), BF16, x)
+    L.call("mc_bn_fold_prepare", _p(we_f32), _p(coef), _p(xtx), _p(cs), float(rows), n, k, _p(w1t), _p(wb), _p(sxx), _st())
+    gt = linear_wgrad(we_bf16, wb, tag="_gt")              # (We^T (B.We))^T  [cin, cin] fp32
+    gtb, cvec = empty((k, k), BF16, x), empty((k,), torch.float32, x)
+    L.call("mc_bn_fold_cvec", _p(gt), _p(we_f32), _p(coef), _p(dbeta), _p(cs), float(rows), n, k, _p(gtb), _p(cvec), _st())
+    r = linear_fwd(x, gtb, bias=cvec, residual=residual, tag="_fold")   # x G + cvec (+ skip gradient)
+    dx = linear_dgrad(dz, we_bf16, residual=r, w_t=w1t)    # + dz (A.We)
+    wx = empty((n, k), torch.float32, x)
+    gemm(wb, sxx, wx, n, k, k, k, k, k, c_f32=1, kind="fold")      # (B.We) Sxx  (Sxx symmetric)
+    dwe = t1
+    L.call("mc_bn_fold_wgrad", _p(t1), _p(wx), _p(coef), _p(dbeta), _p(cs), float(rows), n, k, _p(dwe), _st())
+    return dx, dwe
 
 
 # ------------------------------------------------------------------------------------------- SE / dropout

@@ -931,3 +931,59 @@ def test_fused_attention_rejects_unsupported_shapes():
     qkv, mask, maskb, dctx = _attn_inputs(1, 32, 1, 9)
     with pytest.raises(mammo_clip_amd.lib.MammoClipHipError):
         ops.attn_fwd(qkv[:24], maskb[:, :24].contiguous(), 1, 24, 1, 0.125, 0.0, 1, 0)
+
+
+# ------------------------------------------------------------------------------------------- folded BatchNorm backward
+@pytest.mark.parametrize("n_img,hw,cin,cexp,skip,mean_shift", [
+    (4, 4096, 40, 240, True, 0.0),        # streaming kernels (M >= ROWS_MIN_M)
+    (2, 8208, 24, 144, False, 1.5),       # inputs with a large mean: the centred scatter matrix has to absorb it
+    (3, 1392, 304, 1824, True, 0.5),      # late stage: tiled GEMMs
+    (2, 2784, 512, 3072, False, 0.0),
+])
+def test_bn_fold_expand_backward(n_img, hw, cin, cexp, skip, mean_shift):
+    """Backward of x -> e = x We^T -> bn0(e) from dZ alone (ops.bn_fold_expand_bwd) against fp32 autograd through
+    conv + training-mode BatchNorm on the same bf16 operands, and against the explicit path it replaces
+    (BatchNorm apply pass -> de, then the two gradient GEMMs)."""
+    M = n_img * hw
+    x = (rnd(M, cin, seed=501) .float() + mean_shift).to(BF)
+    we = (rnd(cexp, cin, seed=502, dtype=torch.float32) * cin ** -0.5).contiguous()
+    gamma = rnd(cexp, seed=503, dtype=torch.float32).abs() + 0.5
+    beta = rnd(cexp, seed=504, dtype=torch.float32)
+    dz = rnd(M, cexp, seed=505)
+    dy = rnd(M, cin, seed=506) if skip else None
+    web = ops.cast_bf16(we)
+    e, part = ops.linear_fwd(x, web, stats=True)
+    st = ops.bn_finalize(part, M, gamma, beta, torch.zeros(cexp, device=DEV), torch.ones(cexp, device=DEV), 0.01, 1e-3, False)
+    # reduction partials of (dz, dz * xhat) the way the depthwise data-gradient epilogue leaves them: [rows, 2, c]
+    xhat = (e.float() - st.mean) * st.invstd
+    part0 = torch.stack([dz.float().sum(0), (dz.float() * xhat).sum(0)])[None].contiguous()
+    coef, dg, db = ops.bn_bwd_coefs(part0, M, st, gamma)
+    dx, dwe = ops.bn_fold_expand_bwd(dz, x, we, web, coef, db, M, residual=dy)
+    # (a) fp32 autograd: e from the bf16 operands in fp32, BatchNorm with batch statistics
+    xr = x.float().requires_grad_(True)
+    wr = web.float().requires_grad_(True)
+    er = xr @ wr.t()
+    zr = F.batch_norm(er, None, None, gamma, beta, True, 0.0, 1e-3)
+    zr.backward(dz.float())
+    ref_dx = xr.grad + (dy.float() if skip else 0)
+    check(dx, ref_dx, 1.5e-2, "folded dx vs autograd")
+    check(dwe, wr.grad, 1.5e-2, "folded dWe vs autograd")
+    # (b) the explicit path: apply pass writes de (bf16), then dgrad / wgrad GEMMs over de
+    de, dg2, db2 = ops.bnact_bwd(e, n_img, hw, cexp, st, gamma, 0, g=dz, partials=part0)
+    dx2 = ops.linear_dgrad(de, web, residual=dy, w_t=ops.cast_transpose_bf16(we))
+    dwe2 = ops.linear_wgrad(de, x)
+    assert relerr(dx, ref_dx) <= 1.5 * relerr(dx2, ref_dx) + 2e-3, (relerr(dx, ref_dx), relerr(dx2, ref_dx))
+    assert relerr(dwe, wr.grad) <= 1.5 * relerr(dwe2, wr.grad) + 2e-3, (relerr(dwe, wr.grad), relerr(dwe2, wr.grad))
+    print("fold", (n_img, hw, cin, cexp), "dx err", relerr(dx, ref_dx), "explicit", relerr(dx2, ref_dx),
+          "dWe err", relerr(dwe, wr.grad), "explicit", relerr(dwe2, wr.grad))
+
+
+def test_gemm_rows_bias():
+    x = rnd(40000, 40, seed=510)
+    w = rnd(40, 40, seed=511, scale=0.2)
+    bias = rnd(40, seed=512, dtype=torch.float32)
+    r = rnd(40000, 40, seed=513)
+    y = ops.linear_fwd(x, w, bias=bias, residual=r)
+    check(y, x.float() @ w.float().t() + bias + r.float(), 1e-2, "rows gemm + bias + residual")
+    y2 = ops.linear_fwd(x, w, bias=bias)
+    check(y2, x.float() @ w.float().t() + bias, 1e-2, "rows gemm + bias")
