@@ -114,6 +114,7 @@ def _bn_stats(partials, count, bn: nn.BatchNorm2d, training: bool):
 # expanded-tensor bytes per call from which the BatchNorm0 backward is folded into the expand conv's gradient GEMMs
 # (ops.bn_fold_expand_bwd) instead of running the apply pass; tests set it to 0 to exercise the folded path at small sizes
 BN_FOLD_MIN_BYTES = int(os.environ.get("MC_BN_FOLD_MIN_BYTES", 400_000_000))
+BN_FOLD_S2_MIN_BYTES = int(os.environ.get("MC_BN_FOLD_S2_MIN_BYTES", 0))
 
 
 class _StemFn(torch.autograd.Function):
@@ -291,7 +292,17 @@ class _MBConvFn(torch.autograd.Function):
         else:
             da0 = ops.dwconv_bwd_data(dd, sv["wkkc"], n, h, w, a.cexp, k, s, l, t, oh, ow, w_kkc_flipped=wflip)
             del dd
-            if a.expand != 1:
+            if a.expand != 1 and 2 * n * hw * a.cexp >= max(BN_FOLD_MIN_BYTES, BN_FOLD_S2_MIN_BYTES):
+                # stride 2: one pass writes dZ0 = dA0 * silu'(bn0(e)) and the BatchNorm-backward reductions, then the
+                # folded expand-conv gradients as above (no separate reduce pass, no apply pass)
+                dz0, part0 = ops.bnact_bwd_reduce_dz(e, n, hw, a.cexp, st0, 1, da0)
+                del da0, e, dw_in
+                coef0, dg0, db0 = ops.bn_bwd_coefs(part0, n * hw, st0, blk._bn0.weight)
+                dx, dwe = ops.bn_fold_expand_bwd(dz0, x, blk._expand_conv.weight.view(a.cexp, a.cin), sv["we"], coef0,
+                                                 db0, n * hw, residual=dy if a.skip else None)
+                del dz0
+                de = None
+            elif a.expand != 1:
                 de, dg0, db0 = ops.bnact_bwd(e, n, hw, a.cexp, st0, blk._bn0.weight, 1, g=da0)
                 del da0, e, dw_in
         if a.expand != 1:

@@ -310,7 +310,7 @@ __global__ __launch_bounds__(256) void bnact_bwd_k(const mc_bnact_args p) {
     const long long img = blockIdx.y;
     const bf16_t* xb = p.x + img * p.hw * p.c;
     const bf16_t* gb = p.g ? p.g + img * p.hw * p.c : nullptr;
-    bf16_t* dxb = APPLY ? p.dx + img * p.hw * p.c : nullptr;
+    bf16_t* dxb = p.dx ? p.dx + img * p.hw * p.c : nullptr;      // reduce pass: optional store of dz (folded BatchNorm backward)
     const float rs = p.rowscale ? p.rowscale[img] : 1.f;
     const float asc = (p.add_scale == 0.f) ? 1.f : p.add_scale;
     for (int cbase = 0; cbase < rm.cv; cbase += rm.cvp) {
@@ -358,6 +358,7 @@ __global__ __launch_bounds__(256) void bnact_bwd_k(const mc_bnact_args p) {
                 } else {
 #pragma unroll
                     for (int q = 0; q < 8; ++q) { a0[q] += dz[q]; a1[q] += dz[q] * (x[q] - k0[q]) * k1[q]; }
+                    if (dxb) nt_store16(dxb + r * p.c + v * 8, pack8(dz));
                 }
             };
             const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);

@@ -32,14 +32,17 @@ __global__ void fold_prepare_k(const float* __restrict__ we, const float* __rest
 }
 
 // one workgroup per output column j: gtb[j][:] = bf16(gt[j][:]),
-// cvec[j] = -sum_i A[i] m[i] We[i][j] - sum_i xbar[i] gtb[j][i]      (m = dbeta / rows, xbar = cs / rows)
+// cvec[j] = -sum_i m[i] bf16(A[i] We[i][j]) - sum_i xbar[i] gtb[j][i]      (m = dbeta / rows, xbar = cs / rows)
 __global__ __launch_bounds__(256) void fold_cvec_k(const float* __restrict__ gt, const float* __restrict__ we,
                                                    const float* __restrict__ coef, const float* __restrict__ dbeta,
                                                    const float* __restrict__ cs, double rows, int n, int k,
                                                    bf16_t* __restrict__ gtb, float* __restrict__ cvec) {
     const int j = blockIdx.x;
     double acc = 0.0;
-    for (int i = threadIdx.x; i < n; i += 256) acc += (double)coef[i] * (double)dbeta[i] * (double)we[(long long)i * k + j];
+    // with the ROUNDED operand the dz GEMM uses (w1t = bf16(We * A)): the column sums of dx then cancel exactly, like the
+    // column sums of de do -- a constant offset of 2^-9 |m (A.We)| per row would otherwise survive into every bias /
+    // BatchNorm-shift gradient upstream, which are sums over all pixels
+    for (int i = threadIdx.x; i < n; i += 256) acc += (double)dbeta[i] * (double)bf2f(f2bf(we[(long long)i * k + j] * coef[i]));
     for (int i = threadIdx.x; i < k; i += 256) {
         const bf16_t g = f2bf(gt[(long long)j * k + i]);
         gtb[(long long)j * k + i] = g;

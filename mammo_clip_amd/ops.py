@@ -601,6 +601,22 @@ def bnact_bwd(x, n_img, hw, c, stats, gamma, act, g=None, mul=None, add=None, ro
     return dx, dgamma, dbeta
 
 
+def bnact_bwd_reduce_dz(x, n_img, hw, c, stats, act, g):
+    """One pass over (x, g): dz = g * act'(bn(x)) stored (bf16) AND the BatchNorm-backward reductions (sum dz,
+    sum dz*xhat) as partials -- the input of bn_bwd_coefs / bn_fold_expand_bwd for blocks whose data-gradient kernel has
+    no BatchNorm epilogue (stride 2)."""
+    a = _bnact(x, n_img, hw, c, stats.scale, stats.shift, act)
+    a.g = _p(g)
+    a.mean, a.invstd = _p(stats.mean), _p(stats.invstd)
+    rows = L.load().mc_bnact_rows(C.byref(a))
+    part = empty((rows, 2, c), torch.float32, x)
+    dz = empty((n_img * hw, c), BF16, x)
+    a.partials, a.dx = _p(part), _p(dz)
+    _note(2 * n_img * hw * c * 3)
+    L.call("mc_bnact_bwd_reduce", C.byref(a), _st(), kind="dz")
+    return dz, part
+
+
 def bn_bwd_coefs(partials, count, stats, gamma):
     """Finalize a BatchNorm-backward reduction: partials [rows, 2, c] = (sum dz, sum dz*xhat) -> (coef [3, c], dgamma,
     dbeta) with dx = coef[0]*dz + coef[1]*x + coef[2] (the apply pass, or the folded GEMM operands of bn_fold_*)."""

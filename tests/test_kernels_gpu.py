@@ -987,3 +987,27 @@ def test_gemm_rows_bias():
     check(y, x.float() @ w.float().t() + bias + r.float(), 1e-2, "rows gemm + bias + residual")
     y2 = ops.linear_fwd(x, w, bias=bias)
     check(y2, x.float() @ w.float().t() + bias, 1e-2, "rows gemm + bias")
+
+
+def test_bnact_bwd_reduce_with_dz_store():
+    """the stride-2 blocks' one-pass form: dz = g * silu'(bn(x)) stored + (sum dz, sum dz*xhat) partials"""
+    n_img, hw, c = 3, 1000, 144
+    x = rnd(n_img * hw, c, seed=520)
+    g = rnd(n_img * hw, c, seed=521)
+    gamma = rnd(c, seed=522, dtype=torch.float32).abs() + 0.5
+    beta = rnd(c, seed=523, dtype=torch.float32)
+    xf = x.float()
+    mean, var = xf.mean(0), xf.var(0, unbiased=False)
+    st = ops.BNStats()
+    st.mean, st.invstd = mean.contiguous(), (var + 1e-3).rsqrt().contiguous()
+    st.scale, st.shift = (gamma * st.invstd).contiguous(), (beta - mean * gamma * st.invstd).contiguous()
+    dz, part = ops.bnact_bwd_reduce_dz(x, n_img, hw, c, st, 1, g)
+    zr = (xf * st.scale + st.shift).requires_grad_(True)
+    F.silu(zr).backward(g.float())
+    check(dz, zr.grad, 1e-2, "dz")
+    sums = part.sum(0)
+    check(sums[0], zr.grad.sum(0), 2e-3, "sum dz")
+    check(sums[1], (zr.grad * (xf - mean) * st.invstd).sum(0), 2e-3, "sum dz*xhat")
+    # the plain reduce pass leaves the same partials and stores nothing
+    de, dg, db = ops.bnact_bwd(x, n_img, hw, c, st, gamma, 1, g=g)
+    check(db, sums[0], 1e-5, "dbeta == sum dz")
