@@ -225,7 +225,7 @@ template <int FN, int KC> size_t lds_bytes() {
 
 template <int FN, int KC> int launch_rows(const mc_gemm_rows_args& p, int blocks, hipStream_t st) {
     constexpr int RG = (FN >= 6 || KC >= 12) ? 1 : 2;   // wide outputs / deep K: 16 rows per iteration (register budget)
-    constexpr int PF = KC >= 6 ? 1 : 8 / KC;            // ~8-16 KB of activations in flight per wave
+    constexpr int PF = KC >= 12 ? 1 : (KC >= 6 ? (RG == 1 ? 2 : 1) : 8 / KC);   // ~8-16 KB of activations in flight per wave
     size_t lds = lds_bytes<FN, KC>();
     static bool attr_set = false;
     if (lds > 64 * 1024 && !attr_set) {
