@@ -224,13 +224,14 @@ def main():
         pairs = b * world * args.steps / dt
         sc, st, sb, _ = summ.get(ROOFLINE_OP, (0, 0.0, 0, 0))
         ach = sb / (st * 1e-3) / 1e9 if st > 0 else 0.0
-        traffic = gtraffic = None
+        traffic = gtraffic = g256traffic = None
         tpath = os.path.join(ROOT, "profiles", "r02_roofline_traffic.json")
         if not os.path.exists(tpath):
             tpath = os.path.join(ROOT, "profiles", "r01_roofline_traffic.json")
         if os.path.exists(tpath) and args.workload in ("cfg3", "cfg4") and not args.batch:   # same 32-pair kernel launches
             tj = json.load(open(tpath))                                     # PMC passes (rocprofv3 --pmc), same workload
             traffic, gtraffic = tj.get("hbm_bytes_per_launch"), tj.get("gemm_nt_hbm_bytes_per_launch")
+            g256traffic = tj.get("gemm256_hbm_bytes_per_launch")
         # the two kernels that share the top of the rocprofv3 kernel statistics (profiles/r01_cfg4_kernel_stats.csv):
         # the HBM-bound BN-backward apply pass and the MFMA NT GEMM instance; the one with more GPU time in THIS run
         # is reported as "roofline", the other as "roofline_runner_up"
@@ -253,7 +254,7 @@ def main():
                     "gpu_ms_in_timed_steps": round(gt, 1), "timing": timing}
         # the plain NT MFMA tile kernels are two different kernels (rocprofv3 lists them separately): timed separately
         r_g128 = mfma_entry(lambda k: k.startswith("mc_gemm_bf16") and k.endswith("|glnt"), GEMM_KERNEL, gtraffic)
-        r_g256 = mfma_entry(lambda k: k.startswith("mc_gemm_bf16") and k.endswith("|glnt256"), GEMM256_KERNEL, None)
+        r_g256 = mfma_entry(lambda k: k.startswith("mc_gemm_bf16") and k.endswith("|glnt256"), GEMM256_KERNEL, g256traffic)
         ranked = sorted([r_hbm, r_g128, r_g256], key=lambda r: -r["gpu_ms_in_timed_steps"])
         first, second, third = ranked
         res = {
