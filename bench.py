@@ -175,12 +175,15 @@ def main():
     fp8 = args.workload == "cfg5" or args.fp8
     # Kept graphs against activation memory (measured on one MI355X at the per-GPU load, scripts/recompute_sweep.sh):
     #   128 pairs/GPU (N = 8): recompute mode 3 makes a 32-pair graph small enough to keep all four (216 GB peak, no
-    #     re-forward at all): 1305 ms/step against 1384 ms with two full graphs kept (227 GB) -- mode 1 with four kept is
-    #     1271 ms but peaks at 295 GB, too close to the 309 GB of the device;
-    #   256 / 512 pairs/GPU: two full graphs (231 GB); mode 3 needs five kept graphs (273 GB) to win 1.6 % -- not taken;
+    #     re-forward at all): 1293-1305 ms/step against 1384 ms with two full graphs kept (227 GB) -- mode 1 with four kept
+    #     is 1271 ms but peaks at 295 GB, too close to the 309 GB of the device;
+    #   256 pairs/GPU (N = 4): mode 2 (28 GB per graph), all eight kept: 2758 ms/step, 219 GB, against 2894 ms with two
+    #     full graphs (231 GB);
+    #   512 pairs/GPU (N = 2): two full graphs (mode 2 with five kept graphs: 6394 ms -- every backward pays the recompute,
+    #     eleven micro-batches are still forwarded twice);
     #   1024 pairs/GPU (N = 1): the fp32 input batch itself occupies 34 GB: one kept graph.
-    if args.keep_graphs <= 0 and args.recompute < 0 and strong and b <= 128:
-        args.keep_graphs, args.recompute = args.micro_batches, 3
+    if args.keep_graphs <= 0 and args.recompute < 0 and strong and b <= 256:
+        args.keep_graphs, args.recompute = args.micro_batches, (3 if b <= 128 else 2)
     if args.keep_graphs <= 0:
         args.keep_graphs = 2 if (strong and b <= 512) else 1
     util.GlobalEnv.reset()
