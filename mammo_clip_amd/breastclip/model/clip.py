@@ -3,6 +3,7 @@ Same constructor, attributes (image_encoder, text_encoder, image_projection, tex
 logit_scale, text_pooling) and ``forward(batch, device) -> dict`` contract as the reference."""
 import logging
 import math
+import os
 from typing import Dict
 
 import torch
@@ -45,6 +46,9 @@ class _L2NormFn(torch.autograd.Function):
     def backward(ctx, dy):
         y, norm = ctx.saved_tensors
         return ops.l2norm_bwd(dy, y, norm)
+
+
+_TEXT_ONE_CALL = os.environ.get("MC_TEXT_ONE_CALL", "1") != "0"      # developer switch: A/B against two encoder calls
 
 
 class BreastClip(nn.Module):
@@ -96,14 +100,31 @@ class BreastClip(nn.Module):
     def forward(self, batch, device=None):
         device = batch["images"].device if device is None else device
         img = self.encode_image(batch["images"].to(device))
-        txt = self.encode_text(_tokens.to_device(batch["text_tokens"], device))
+        tok = _tokens.to_device(batch["text_tokens"], device)
+        two = "text_tokens2" in batch and "image_views" in batch
+        txt2 = None
+        if two:
+            # Both reports of a pair go through the text encoder in ONE call when their token tensors have the same
+            # shape: BERT has no cross-sample interaction (LayerNorm per token, attention per sequence), so the result
+            # equals two calls [ref: clip.py:92,103 calls encode_text twice] while every GEMM sees twice the rows, the
+            # weight gradients are produced once and ~360 launches per step disappear.
+            tok2 = _tokens.to_device(batch["text_tokens2"], device)
+            if _TEXT_ONE_CALL and tok.keys() == tok2.keys() and all(torch.is_tensor(tok[k]) and tok[k].shape == tok2[k].shape for k in tok):
+                nb = tok["input_ids"].shape[0]
+                both = self.encode_text({k: torch.cat([tok[k], tok2[k]]) for k in tok})
+                txt, txt2 = both[:nb], both[nb:]
+            else:
+                txt = self.encode_text(tok)
+        else:
+            txt = self.encode_text(tok)
         img_e = self.image_projection(img) if self.projection else img
         txt_e = self.text_projection(txt) if self.projection else txt
         img_e, txt_e = _L2NormFn.apply(img_e), _L2NormFn.apply(txt_e)
         out = {"image_embeddings": img_e, "text_embeddings": txt_e,
                "labels": torch.arange(img_e.shape[0], device=device), "logit_scale": self.logit_scale.exp()}
-        if "text_tokens2" in batch and "image_views" in batch:
-            txt2 = self.encode_text(_tokens.to_device(batch["text_tokens2"], device))
+        if two:
+            if txt2 is None:
+                txt2 = self.encode_text(tok2)
             txt2_e = self.text_projection(txt2) if self.projection else txt      # [ref quirk: clip.py:105]
             out["text_embeddings2"] = _L2NormFn.apply(txt2_e)
             view = self.encode_image(batch["image_views"].to(device))
