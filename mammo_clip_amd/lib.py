@@ -169,6 +169,11 @@ def load():
         raise MammoClipHipError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  The HIP path is the only path.")
+    # torch first: its wheel bundles its own libamdhip64 -- the kernels launch on torch's streams and touch torch's device
+    # memory, so both must live in ONE HIP runtime.  Loaded after torch, this library's libamdhip64.so.7 dependency
+    # resolves to the copy torch already mapped; loaded before it, the process ends up with /opt/rocm's runtime AND
+    # torch's, and the first launch fails with "no ROCm-capable device is detected".
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     lib.mc_last_error.argtypes = []
     lib.mc_last_error.restype = C.c_char_p
