@@ -17,6 +17,20 @@ import torch
 import torch.nn.functional as F
 
 
+# Storage-rounding emulation, see oracle/efficientnet.py (same switch semantics): "W" linear weights, "X" hidden state
+# (embedding / LayerNorm outputs: GEMM operand AND residual), "XR" the residual-path copy of the hidden state only,
+# "QKV", "PR" attention probabilities, "CTX", "AO" attention-output dense, "H1" FFN1 pre-activation, "HG" GELU output,
+# "O" FFN2 output.
+ROUND = None
+ROUND_DTYPE = torch.bfloat16
+
+
+def _q(tag, x):
+    if ROUND is None or tag not in ROUND:
+        return x
+    return x + (x.to(ROUND_DTYPE).to(x.dtype) - x).detach()
+
+
 @dataclass
 class BertShape:
     vocab: int = 28996
@@ -35,8 +49,8 @@ def embeddings(sd: Dict[str, torch.Tensor], p: str, input_ids, token_type_ids, c
     x = (sd[p + "embeddings.word_embeddings.weight"][input_ids]
          + sd[p + "embeddings.token_type_embeddings.weight"][token_type_ids]
          + sd[p + "embeddings.position_embeddings.weight"][pos][None])
-    return F.layer_norm(x, (cfg.hidden,), sd[p + "embeddings.LayerNorm.weight"],
-                        sd[p + "embeddings.LayerNorm.bias"], cfg.ln_eps)
+    return _q("X", F.layer_norm(x, (cfg.hidden,), sd[p + "embeddings.LayerNorm.weight"],
+                                sd[p + "embeddings.LayerNorm.bias"], cfg.ln_eps))
 
 
 def layer(sd, p: str, x, ext_mask, cfg: BertShape, taps=None):
@@ -45,22 +59,22 @@ def layer(sd, p: str, x, ext_mask, cfg: BertShape, taps=None):
     nh, hd = cfg.heads, cfg.hidden // cfg.heads
 
     def lin(name, t):
-        return F.linear(t, sd[p + name + ".weight"], sd[p + name + ".bias"])
+        return F.linear(t, _q("W", sd[p + name + ".weight"]), sd[p + name + ".bias"])
 
     def split(t):
         return t.view(b, T, nh, hd).permute(0, 2, 1, 3)
 
-    q, k, v = split(lin("attention.self.query", x)), split(lin("attention.self.key", x)), \
-        split(lin("attention.self.value", x))
+    q, k, v = split(_q("QKV", lin("attention.self.query", x))), split(_q("QKV", lin("attention.self.key", x))), \
+        split(_q("QKV", lin("attention.self.value", x)))
     scores = q @ k.transpose(-1, -2) / math.sqrt(hd) + ext_mask
-    probs = torch.softmax(scores, dim=-1)
-    ctx = (probs @ v).permute(0, 2, 1, 3).reshape(b, T, H)
-    a = F.layer_norm(lin("attention.output.dense", ctx) + x, (H,),
-                     sd[p + "attention.output.LayerNorm.weight"],
-                     sd[p + "attention.output.LayerNorm.bias"], cfg.ln_eps)
-    h = F.gelu(lin("intermediate.dense", a))          # exact erf GELU
-    y = F.layer_norm(lin("output.dense", h) + a, (H,), sd[p + "output.LayerNorm.weight"],
-                     sd[p + "output.LayerNorm.bias"], cfg.ln_eps)
+    probs = _q("PR", torch.softmax(scores, dim=-1))
+    ctx = _q("CTX", (probs @ v).permute(0, 2, 1, 3).reshape(b, T, H))
+    a = _q("X", F.layer_norm(_q("AO", lin("attention.output.dense", ctx)) + _q("XR", x), (H,),
+                             sd[p + "attention.output.LayerNorm.weight"],
+                             sd[p + "attention.output.LayerNorm.bias"], cfg.ln_eps))
+    h = _q("HG", F.gelu(_q("H1", lin("intermediate.dense", a))))          # exact erf GELU
+    y = _q("X", F.layer_norm(_q("O", lin("output.dense", h)) + _q("XR", a), (H,), sd[p + "output.LayerNorm.weight"],
+                             sd[p + "output.LayerNorm.bias"], cfg.ln_eps))
     if taps is not None:
         taps[p + "probs"] = probs
         taps[p + "attn_out"] = a

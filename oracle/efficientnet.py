@@ -16,6 +16,21 @@ import torch.nn.functional as F
 
 from .arch import Arch, BN_EPS, BN_MOMENTUM
 
+# Storage-rounding emulation (tests / scripts/rounding_ablation.py only): a set of tensor-class tags whose members are
+# rounded to ``ROUND_DTYPE`` and back where the HIP path STORES (or feeds an MFMA with) that class -- "E" expand-conv
+# output, "D" depthwise output, "P" project-conv output, "Y" block output / residual stream (also the stem output),
+# "A1" the gated activation operand of the project GEMM, "W" the 1x1 / stem convolution weights, "H" the head-conv
+# output, "IN" the stem's input patches.  None = the plain fp32 restatement.  Straight-through in backward (the rounding has zero-width gradient
+# support otherwise).
+ROUND = None
+ROUND_DTYPE = torch.bfloat16
+
+
+def _q(tag, x):
+    if ROUND is None or tag not in ROUND:
+        return x
+    return x + (x.to(ROUND_DTYPE).to(x.dtype) - x).detach()
+
 
 def swish(x):
     """efficient_net_custom_utils.py:64-69 (forward of SwishImplementation)."""
@@ -47,11 +62,11 @@ def mbconv(sd, p: str, x, blk, train: bool, new_buffers=None, taps: Optional[dic
     """MBConvBlock.forward (efficientnet_custom.py:91-132) with drop_connect disabled."""
     inp = x
     if blk.expand != 1:
-        x = F.conv2d(x, sd[p + "._expand_conv.weight"])
+        x = _q("E", F.conv2d(x, _q("W", sd[p + "._expand_conv.weight"])))
         if taps is not None:
             taps[p + ".expand_out"] = x
         x = swish(_bn(sd, p + "._bn0", x, train, new_buffers))
-    x = _conv_static_same(x, sd[p + "._depthwise_conv.weight"], None, blk.s, blk.pad, groups=blk.cexp)
+    x = _q("D", _conv_static_same(x, sd[p + "._depthwise_conv.weight"], None, blk.s, blk.pad, groups=blk.cexp))
     if taps is not None:
         taps[p + ".dw_out"] = x
     x = swish(_bn(sd, p + "._bn1", x, train, new_buffers))
@@ -60,29 +75,29 @@ def mbconv(sd, p: str, x, blk, train: bool, new_buffers=None, taps: Optional[dic
     sq = F.conv2d(sq, sd[p + "._se_reduce.weight"], sd[p + "._se_reduce.bias"])
     sq = swish(sq)
     sq = F.conv2d(sq, sd[p + "._se_expand.weight"], sd[p + "._se_expand.bias"])
-    x = torch.sigmoid(sq) * x
-    x = F.conv2d(x, sd[p + "._project_conv.weight"])
+    x = _q("A1", torch.sigmoid(sq) * x)
+    x = _q("P", F.conv2d(x, _q("W", sd[p + "._project_conv.weight"])))
     if taps is not None:
         taps[p + ".project_out"] = x
     x = _bn(sd, p + "._bn2", x, train, new_buffers)
     if blk.skip:
         x = x + inp
-    return x
+    return _q("Y", x)
 
 
 def extract_features(sd, x, arch: Arch, train: bool, prefix: str = "", new_buffers=None,
                      taps: Optional[dict] = None):
     """EfficientNet.extract_features (efficientnet_custom.py:262-285)."""
     p = prefix
-    x = _conv_static_same(x, sd[p + "_conv_stem.weight"], None, 2, arch.stem_pad)
-    x = swish(_bn(sd, p + "_bn0", x, train, new_buffers))
+    x = _q("E", _conv_static_same(_q("IN", x), _q("W", sd[p + "_conv_stem.weight"]), None, 2, arch.stem_pad))
+    x = _q("Y", swish(_bn(sd, p + "_bn0", x, train, new_buffers)))
     if taps is not None:
         taps["stem"] = x
     for blk in arch.blocks:
         x = mbconv(sd, f"{p}_blocks.{blk.idx}", x, blk, train, new_buffers, taps)
         if taps is not None:
             taps[f"block{blk.idx}"] = x
-    x = F.conv2d(x, sd[p + "_conv_head.weight"])
+    x = _q("H", F.conv2d(x, _q("W", sd[p + "_conv_head.weight"])))
     x = swish(_bn(sd, p + "_bn1", x, train, new_buffers))
     return x
 
