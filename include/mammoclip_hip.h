@@ -91,6 +91,13 @@ int mc_gemm_stat_rows(const mc_gemm_args* args);
 /* which tile kernel serves `args`: 256 = the 256 x 256 x 64 direct-to-LDS kernel (gemm256.hip: plain NT operands, bf16
  * output, enough well-filled tiles for the 256 CUs), 128 = the 128-row tile family (gemm.hip) */
 int mc_gemm_tile_config(const mc_gemm_args* args);
+/* Weight-gradient (TN) problems -- a_kmajor = b_kmajor = 1, fp32 output, plain operands, K = the long pixel / token
+ * reduction [ref: autograd backward of efficientnet_custom.py:104,122,283, text_encoder.py:47-49] -- run on the
+ * 256 x 256 x 64 transpose-read kernel of gemm256_tn.hip when mc_gemm256_tn_eligible() says so (mc_gemm_bf16 routes them
+ * itself).  mc_gemm256_tn_splits: the number of K splits that kernel wants (splitk_ws = float[splits*M*N]); with
+ * group_rows > 0 (grouped form, split_group_rows) the number of sub-splits per group (split_sub). */
+int mc_gemm256_tn_eligible(const mc_gemm_args* args);
+int mc_gemm256_tn_splits(long long m, long long n, long long k, long long group_rows);
 
 /* fp8 operand preparation (BASELINE config #5; OCP e4m3 as implemented by gfx950).
  * mc_amax_bf16:       amax[0] = max(amax[0], max |x|)   (caller zero-fills amax; integer atomic, deterministic)

@@ -149,7 +149,9 @@ class _StemFn(torch.autograd.Function):
         l, r, t, b = mod.stem_pad
         patches = ops.stem_im2col(x, l, t, oh, ow)                 # recomputed, not stored
         dw = ops.linear_wgrad(de, patches)                         # [c0, 32]
-        return None, dw[:, :27].reshape(c0, 3, 3, 3), dgamma, dbeta, None
+        gw, gg, gb = ops.deliver_param_grads((mod._conv_stem.weight, mod._bn0.weight, mod._bn0.bias),
+                                             (dw[:, :27].reshape(c0, 3, 3, 3), dgamma, dbeta))
+        return None, gw, gg, gb, None
 
 
 def _expand_conv(blk, x, we, rows):
@@ -323,7 +325,7 @@ class _MBConvFn(torch.autograd.Function):
         grads["_project_conv.weight"] = dwp.view(a.cout, a.cexp, 1, 1)
         grads["_bn2.weight"], grads["_bn2.bias"] = dg2, db2
         ctx.saved = None
-        return (dx, None, None, None, None, None) + tuple(grads[nm] for nm in blk._param_names)
+        return (dx, None, None, None, None, None) + ops.deliver_param_grads(blk._params(), [grads[nm] for nm in blk._param_names])
 
 
 class _HeadFn(torch.autograd.Function):
@@ -353,7 +355,9 @@ class _HeadFn(torch.autograd.Function):
                                           add_scale=1.0 / (h * wd))
         dx = ops.linear_dgrad(de, wb, w_t=ops.cast_transpose_bf16(mod._conv_head.weight.view(cout, cin)))
         dw = ops.linear_wgrad(de, x)
-        return dx, dw.view(cout, cin, 1, 1), dgamma, dbeta, None, None, None, None
+        gw, gg, gb = ops.deliver_param_grads((mod._conv_head.weight, mod._bn1.weight, mod._bn1.bias),
+                                             (dw.view(cout, cin, 1, 1), dgamma, dbeta))
+        return dx, gw, gg, gb, None, None, None, None
 
 
 class _DropoutFn(torch.autograd.Function):
@@ -428,9 +432,15 @@ class MBConvBlock(nn.Module):
         self.register_buffer("_ones", torch.ones(cin), persistent=False)
         self.register_buffer("_zeros", torch.zeros(cin), persistent=False)
 
+    def _params(self):
+        """the block's Parameter objects in ``_param_names`` order (cached: ``named_parameters`` walks the module tree)"""
+        ps = self.__dict__.get("_plist")
+        if ps is None:          # Parameter OBJECTS survive .to() / load_state_dict (both write .data in place)
+            ps = self.__dict__["_plist"] = [p for _, p in self.named_parameters()]
+        return ps
+
     def forward(self, inputs, n, h, w, rowscale=None):
-        params = [p for _, p in self.named_parameters()]
-        return _MBConvFn.apply(inputs, rowscale, self, n, h, w, *params)
+        return _MBConvFn.apply(inputs, rowscale, self, n, h, w, *self._params())
 
 
 class EfficientNet(nn.Module):

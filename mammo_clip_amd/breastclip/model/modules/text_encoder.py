@@ -35,6 +35,7 @@ class _EmbedFn(torch.autograd.Function):
     def forward(ctx, word, pos, typ, gamma, beta, ids, tt, eps, p, seed, sid):
         y, mean, rstd = ops.bert_embed_fwd(ids, tt, word, pos, typ, gamma, beta, eps, p, seed, sid)
         ctx.cfg = (p, seed, sid)
+        ctx.params = (word, pos, typ, gamma, beta)
         ctx.save_for_backward(word, pos, typ, gamma, ids, tt, mean, rstd)
         return y
 
@@ -45,7 +46,7 @@ class _EmbedFn(torch.autograd.Function):
         dword, dpos, dtyp, dgamma, dbeta = ops.bert_embed_bwd(dy.contiguous(), ids, tt, word, pos, typ, gamma, mean, rstd,
                                                               p, seed, sid)
         dword[0].zero_()       # nn.Embedding(padding_idx=0) never accumulates a gradient for the [PAD] row
-        return dword, dpos, dtyp, dgamma, dbeta, None, None, None, None, None, None
+        return ops.deliver_param_grads(ctx.params, (dword, dpos, dtyp, dgamma, dbeta)) + (None,) * 6
 
 
 class _LayerFn(torch.autograd.Function):
@@ -97,11 +98,13 @@ class _LayerFn(torch.autograd.Function):
         hg = ops.gelu_fwd(h1)
         w2 = ops.cast_bf16(lyr.output.dense.weight)
         o = ops.linear_fwd(hg, w2, bias=lyr.output.dense.bias)
-        del hg
         y, mean2, rstd2 = ops.add_ln_fwd(o, a, lyr.output.LayerNorm.weight, lyr.output.LayerNorm.bias, lyr.eps, ph, seed,
                                          sid + 2)
         ctx.lyr, ctx.cfg = lyr, (b, t, seed, pa, ph, sid)
-        ctx.sv = dict(x=x, qkv=qkv, probs=probs, pd=pd, lse=lse, maskb=maskb, ctxv=ctxv, ao=ao, a=a, h1=h1, o=o, wqkv=wqkv, wo=wo, wi=wi, w2=w2,
+        # hg = gelu(h1) is kept for the FFN2 weight gradient (100 MB per layer at 16384 rows: memory is not the constraint
+        # of the text side, a recomputing GELU pass per layer and backward was)
+        ctx.sv = dict(x=x, qkv=qkv, probs=probs, pd=pd, lse=lse, maskb=maskb, ctxv=ctxv, ao=ao, a=a, h1=h1, hg=hg, o=o, wqkv=wqkv, wo=wo, wi=wi, w2=w2,
+                      qkv_ver=ver,
                       ln1=(mean1, rstd1), ln2=(mean2, rstd2))
         return y
 
@@ -117,7 +120,7 @@ class _LayerFn(torch.autograd.Function):
         # y = LN2(dropout(o) + a)
         do, da_res, g["output.LayerNorm.weight"], g["output.LayerNorm.bias"] = ops.add_ln_bwd(
             dy, sv["o"], a, lyr.output.LayerNorm.weight, sv["ln2"][0], sv["ln2"][1], ph, seed, sid + 2)
-        hg = ops.gelu_fwd(sv["h1"])                                  # recomputed
+        hg = sv.pop("hg")
         g["output.dense.weight"] = ops.linear_wgrad(do, hg)
         g["output.dense.bias"] = ops.colsum(do)
         dhg = ops.linear_dgrad(do, sv["w2"], w_t=ops.cast_transpose_bf16(lyr.output.dense.weight))
@@ -154,15 +157,19 @@ class _LayerFn(torch.autograd.Function):
             del ds
         dwqkv = ops.linear_wgrad(dqkv, x)
         dbqkv = ops.colsum(dqkv)
-        wqkv_t = torch.empty((H, 3 * H), dtype=torch.bfloat16, device=x.device)      # [in, 3*out] = wqkv^T
-        for i, m_ in enumerate((att.self.query, att.self.key, att.self.value)):
-            wqkv_t[:, i * H:(i + 1) * H].copy_(ops.cast_transpose_bf16(m_.weight))
+        tc = getattr(lyr, "_qkv_t_cache", None)                      # [in, 3*out] = wqkv^T, rebuilt only when a weight changed
+        if tc is None or tc[0] != sv["qkv_ver"] or tc[1].device != x.device:
+            wqkv_t = torch.empty((H, 3 * H), dtype=torch.bfloat16, device=x.device)
+            for i, m_ in enumerate((att.self.query, att.self.key, att.self.value)):
+                wqkv_t[:, i * H:(i + 1) * H].copy_(ops.cast_transpose_bf16(m_.weight))
+            lyr._qkv_t_cache = tc = (sv["qkv_ver"], wqkv_t)
+        wqkv_t = tc[1]
         dx = ops.linear_dgrad(dqkv, sv["wqkv"], residual=dx_res, w_t=wqkv_t)
         for i, nm in enumerate(("query", "key", "value")):
             g[f"attention.self.{nm}.weight"] = dwqkv[i * H:(i + 1) * H]
             g[f"attention.self.{nm}.bias"] = dbqkv[i * H:(i + 1) * H]
         ctx.sv = None
-        return (dx, None, None, None, None, None) + tuple(g[nm] for nm in lyr._param_names)
+        return (dx, None, None, None, None, None) + ops.deliver_param_grads(lyr._params(), [g[nm] for nm in lyr._param_names])
 
 
 # ---------------------------------------------------------------------------------------------- containers
@@ -210,8 +217,14 @@ class BertLayerHIP(nn.Module):
         self.p_attn, self.p_hidden = cfg.attention_probs_dropout_prob, cfg.hidden_dropout_prob
         self._param_names = [n for n, _ in self.named_parameters()]
 
+    def _params(self):
+        ps = self.__dict__.get("_plist")
+        if ps is None:          # Parameter OBJECTS survive .to() / load_state_dict (both write .data in place)
+            ps = self.__dict__["_plist"] = [p for _, p in self.named_parameters()]
+        return ps
+
     def forward(self, x, maskb, b, t, seed):
-        return _LayerFn.apply(x, maskb, self, b, t, seed, *[p for _, p in self.named_parameters()])
+        return _LayerFn.apply(x, maskb, self, b, t, seed, *self._params())
 
 
 class _Embeddings(nn.Module):

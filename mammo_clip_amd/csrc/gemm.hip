@@ -819,6 +819,8 @@ static int pick_grid_m(const mc_gemm_args& p) {
 extern "C" int mc_gemm256_eligible(const mc_gemm_args* a);      // gemm256.hip: 256 x 256 tiles for plain NT problems
 extern "C" int mc_gemm256_stat_rows(const mc_gemm_args* a);
 extern "C" int mc_gemm256_launch(const mc_gemm_args* a, void* stream);
+extern "C" int mc_gemm256_tn_eligible(const mc_gemm_args* a);   // gemm256_tn.hip: 256 x 256 tiles for plain TN (weight gradient) problems
+extern "C" int mc_gemm256_tn_launch(const mc_gemm_args* a, void* stream);
 
 extern "C" int mc_gemm_tile_config(const mc_gemm_args* a) {
     // 256: the 256 x 256 x 64 kernel of gemm256.hip will run this problem; 128: the tile family of this file
@@ -866,6 +868,16 @@ extern "C" int mc_gemm_bf16(const mc_gemm_args* a, void* stream) {
     MC_CHECK(!p.R || (!p.c_f32 && p.ldr % 8 == 0), "gemm: residual needs bf16 output and ldr % 8 == 0");
     if (p.alpha == 0.f) p.alpha = 1.f;
     if (mc_gemm256_eligible(&p)) return mc_gemm256_launch(&p, stream);
+    if (mc_gemm256_tn_eligible(&p)) {
+        const int rc = mc_gemm256_tn_launch(&p, stream);
+        if (rc != MC_OK || p.splits <= 1) return rc;
+        const long long mn = p.M * p.N;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(mc_div_up(mc_div_up(mn, 4), 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                           p.splitk_ws, p.splits, mn, p.N, reinterpret_cast<float*>(p.C), p.ldc, p.c_atomic, p.split_scale,
+                           p.split_sub > 0 ? p.split_sub : 1);
+        MC_LAUNCH_CHECK();
+        return MC_OK;
+    }
     MC_CHECK(!p.ab_fp8 && !p.alpha_dev, "gemm: fp8 operands / alpha_dev need the plain NT bf16-output form (gemm256)");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int grid_m = pick_grid_m(p);

@@ -16,6 +16,8 @@ from typing import Dict, List, Optional
 import torch
 import torch.distributed as dist
 
+from . import ops
+
 
 class GradBuckets:
     """Flat fp32 gradient buckets filled in reverse registration order (the order backward produces them)."""
@@ -114,10 +116,15 @@ class GradBuckets:
 
 class Trainer:
     def __init__(self, model, loss_func, optimizer, scheduler=None, device=None, bucket_mb: int = 256,
-                 overlap_micro: bool = True, keep_graphs: int = 1):
+                 overlap_micro: bool = False, keep_graphs: int = 1, grad_sink: bool = True):
         self.model, self.loss_func, self.optimizer, self.scheduler = model, loss_func, optimizer, scheduler
         self.device = device
-        self.overlap_micro = overlap_micro      # micro-batched step: reduce buckets from the last backward's hooks
+        # Gradient reduction: by default the flat buckets are all-reduced AFTER the last backward (reduce_all) -- the whole
+        # exchange is 552 MB per step against >= 1.2 s of backward at 128 pairs per GPU, there is nothing worth hiding, and
+        # that mode does not depend on autograd's hook order.  overlap_micro = True (needs grad_sink = False) launches each
+        # bucket from the post-accumulate hooks of the last backward instead.
+        self.grad_sink = bool(grad_sink)        # parameter gradients combined by multi-tensor adds (ops.GradSink)
+        self.overlap_micro = bool(overlap_micro) and not self.grad_sink
         self.keep_graphs = max(1, int(keep_graphs))   # micro-batched step: micro-batches forwarded once, graph kept
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self.buckets = GradBuckets(list(model.parameters()), bucket_mb << 20) if self.world > 1 else None
@@ -133,15 +140,41 @@ class Trainer:
         self.optimizer.zero_grad(set_to_none=True)
         if self.buckets is not None:
             self.buckets.begin()
+            self.buckets.enabled = not self.grad_sink
         outputs = self.model(batch, self.device)
         loss_dict = self.loss_func(**outputs, is_train=True)
-        loss_dict["total"].backward()
-        if self.buckets is not None:
-            self.buckets.finish()
+        self._backward(lambda: loss_dict["total"].backward())
+        self._grads_done(hooked=not self.grad_sink)
         self.optimizer.step()
         if self.scheduler is not None:
             self.scheduler.step()
         return {k: v.detach() for k, v in loss_dict.items()}
+
+    def _backward(self, run):
+        """one backward call; with the gradient sink the hand-written functions deliver their parameter gradients to it"""
+        if not self.grad_sink:
+            return run()
+        if ops.GRAD_SINK is None:
+            ops.GRAD_SINK = ops.GradSink()
+        try:
+            run()
+        except BaseException:
+            ops.GRAD_SINK = None
+            raise
+        ops.GRAD_SINK.flush()
+
+    def _grads_done(self, hooked: bool):
+        """after the last backward of a step: sink -> param.grad, then the data-parallel mean.  ``hooked``: the bucket
+        hooks were armed during the backward that made the gradients final (they have launched the full buckets)."""
+        if self.grad_sink and ops.GRAD_SINK is not None:
+            ops.GRAD_SINK.finish()
+            ops.GRAD_SINK = None
+        if self.buckets is not None:
+            if hooked:
+                self.buckets.finish()
+            else:
+                self.buckets.reduce_all()
+            self.buckets.enabled = True
 
 
 # ---------------------------------------------------------------------------------------- micro-batched step
@@ -212,7 +245,7 @@ def _step_micro(self, batch: Dict, k: int) -> Dict[str, torch.Tensor]:
     if self.buckets is not None and self.overlap_micro and not parts:
         self.buckets.enabled = True            # every micro-batch kept: this is the only backward
     loss_dict = self.loss_func(**outputs, is_train=True)
-    loss_dict["total"].backward()              # d loss / d embeddings of the re-run micro-batches, full backward of the kept ones
+    self._backward(lambda: loss_dict["total"].backward())   # d loss / d embeddings of the re-run micro-batches, full backward of the kept ones
     del out, lives, full, outputs
     bns = [m for m in model.modules() if hasattr(m, "track_update")]
     for m in bns:
@@ -226,18 +259,12 @@ def _step_micro(self, batch: Dict, k: int) -> Dict[str, torch.Tensor]:
                 self.buckets.enabled = True
             out = model(mb, self.device)
             ks = list(leaf)
-            torch.autograd.backward([out[kk] for kk in ks], [leaf[kk].grad[i * b:(i + 1) * b] for kk in ks])
+            self._backward(lambda: torch.autograd.backward([out[kk] for kk in ks], [leaf[kk].grad[i * b:(i + 1) * b] for kk in ks]))
     finally:
         for m in bns:
             m.track_update = True
         irng.calls, trng._calls = after
-        if self.buckets is not None:
-            self.buckets.enabled = True
-    if self.buckets is not None:
-        if self.overlap_micro:
-            self.buckets.finish()
-        else:
-            self.buckets.reduce_all()
+    self._grads_done(hooked=self.overlap_micro)
     self.optimizer.step()
     if self.scheduler is not None:
         self.scheduler.step()

@@ -88,6 +88,8 @@ _SIGS = {
     "mc_gemm_bf16": ([C.POINTER(GemmArgs), P], I),
     "mc_gemm_stat_rows": ([C.POINTER(GemmArgs)], I),
     "mc_gemm_tile_config": ([C.POINTER(GemmArgs)], I),
+    "mc_gemm256_tn_eligible": ([C.POINTER(GemmArgs)], I),
+    "mc_gemm256_tn_splits": ([LL, LL, LL, LL], I),
     "mc_amax_bf16": ([P, LL, P, P], I),
     "mc_quant_fp8_bf16": ([P, LL, P, P, P, P, P], I),
     "mc_gemm_rows_supported": ([I, I], I),

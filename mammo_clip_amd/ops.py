@@ -280,6 +280,18 @@ def _wgrad_splits(m, n, k):
     return s
 
 
+def _tn256_plan(n_out, k_out, rows, lddy, ldx, group_rows=0):
+    """K splits (sub-splits per group in the grouped form) the 256 x 256 TN tile kernel (gemm256_tn.hip) wants for
+    dW[n_out, k_out] = dY[rows, n_out]^T . X[rows, k_out]; 0 = that kernel does not take the problem"""
+    a = L.GemmArgs()
+    a.M, a.N, a.K, a.lda, a.ldb, a.ldc = n_out, k_out, rows, lddy, ldx, k_out
+    a.a_kmajor, a.b_kmajor, a.c_f32, a.batch, a.nb2, a.splits = 1, 1, 1, 1, 1, 2
+    a.splitk_ws = 16                                       # any non-null value: only looked at, never dereferenced
+    if not L.load().mc_gemm256_tn_eligible(C.byref(a)):
+        return 0
+    return L.load().mc_gemm256_tn_splits(n_out, k_out, rows, group_rows)
+
+
 def linear_wgrad(dy, x, pro=None, out=None, tag=""):
     """dw[N,K] (fp32) = dy[M,N]^T . x'[M,K]; x' = prologue(x) when pro = (scale, shift, gate, rows_per_img)."""
     M, N = dy.shape
@@ -300,10 +312,12 @@ def linear_wgrad(dy, x, pro=None, out=None, tag=""):
         # x is already activated and only carries the per-image gate: cut the reduction at image boundaries and apply
         # the gate when the partials are combined (dW = sum_img gate_img (.) dW_img) -- a plain TN GEMM, no prologue
         n_img, hw = M // pro[3], pro[3]
-        tiles = math.ceil(N / 128) * math.ceil(K / 128)
-        sub = max(1, min(math.ceil(768 / (tiles * n_img)), hw // 512))
-        if (n_img * sub) % 8 and n_img * sub >= 16:
-            sub = max(1, sub - 1) if (n_img * (sub - 1)) % 8 == 0 and sub > 1 else sub
+        sub = _tn256_plan(N, K, M, dy.stride(0), x.stride(0), group_rows=hw)
+        if not sub:
+            tiles = math.ceil(N / 128) * math.ceil(K / 128)
+            sub = max(1, min(math.ceil(768 / (tiles * n_img)), hw // 512))
+            if (n_img * sub) % 8 and n_img * sub >= 16:
+                sub = max(1, sub - 1) if (n_img * (sub - 1)) % 8 == 0 and sub > 1 else sub
         splits = n_img * sub
         ws = empty((splits, N, K), torch.float32, dy)
         gemm(dy, x, dw, N, K, M, dy.stride(0), x.stride(0), dw.stride(0), a_kmajor=1, b_kmajor=1, c_f32=1,
@@ -312,7 +326,7 @@ def linear_wgrad(dy, x, pro=None, out=None, tag=""):
     p = None
     if pro is not None:
         p = (2, pro[0], pro[1], pro[2], pro[3], K)
-    splits = _wgrad_splits(N, K, M)
+    splits = (_tn256_plan(N, K, M, dy.stride(0), x.stride(0)) if pro is None else 0) or _wgrad_splits(N, K, M)
     ws = empty((splits, N, K), torch.float32, dy) if splits > 1 else None
     gemm(dy, x, dw, N, K, M, dy.stride(0), x.stride(0), dw.stride(0), a_kmajor=1, b_kmajor=1, c_f32=1,
          c_atomic=(1 if out is not None else 0), splits=splits, pro=p, splitk_ws=ws, kind="wgrad" + tag)
@@ -828,3 +842,77 @@ def ce_fwd_bwd(logits, label_offset, w, loss_out, smoothing=0.0, labels=None):
     row_ws = empty((rows,), torch.float32, logits)
     L.call("mc_ce_fwd_bwd", _p(logits), rows, n, _p(labels), int(label_offset), float(w), float(smoothing), _p(loss_out),
            _p(row_ws), _st())
+
+
+# ------------------------------------------------------------------------------------------- gradient sink
+class GradSink:
+    """Parameter gradients of the hand-written backward functions, combined by multi-tensor adds.
+
+    Autograd sums the gradients a parameter receives with one ``at::native add`` launch per parameter and contribution:
+    both image views use the image encoder's ~700 parameters (two contributions per backward), a micro-batched step runs
+    up to 32 backward calls -- 38 000 tiny launches per 1024-pair step, 2 % of its GPU time.  With a sink installed
+    (``ops.GRAD_SINK``, engine.Trainer does it) the stem / MBConv / head / BERT functions hand their parameter gradients
+    over here and return None to autograd; ``flush()`` (after every backward call) folds the pending gradients into one
+    accumulator per parameter with ``torch._foreach_add_`` (a handful of launches for all tensors), ``finish()`` leaves the
+    result in ``param.grad``.  No sink installed: plain autograd semantics (what DDP wrappers and third-party loops see).
+    """
+
+    def __init__(self):
+        self.acc = {}
+        self.pending = []
+
+    def deliver(self, params, grads):
+        for p_, g in zip(params, grads):
+            if g is not None and p_.requires_grad:
+                self.pending.append((p_, g))
+
+    @torch.no_grad()
+    def flush(self):
+        """Same summation order as autograd: the contributions of ONE backward call are summed among themselves first
+        (in arrival order, like the engine's input buffer), then added to what earlier calls left (like AccumulateGrad)."""
+        if not self.pending:
+            return
+        groups = {}
+        for p_, g in self.pending:
+            groups.setdefault(p_, []).append(g if g.dtype == p_.dtype else g.to(p_.dtype))
+        self.pending = []
+        level = 1
+        while True:
+            dst = [gs[0] for gs in groups.values() if len(gs) > level]
+            if not dst:
+                break
+            torch._foreach_add_(dst, [gs[level] for gs in groups.values() if len(gs) > level])
+            level += 1
+        dst, src = [], []
+        for p_, gs in groups.items():
+            a = self.acc.get(p_)
+            if a is None:
+                self.acc[p_] = gs[0]                       # the first gradient becomes the accumulator
+            else:
+                dst.append(a)
+                src.append(gs[0])
+        if dst:
+            torch._foreach_add_(dst, src)
+
+    @torch.no_grad()
+    def finish(self):
+        self.flush()
+        for p_, a in self.acc.items():
+            a = a.view_as(p_) if a.shape != p_.shape else a
+            if p_.grad is None:
+                p_.grad = a
+            else:
+                p_.grad.add_(a)
+        self.acc = {}
+
+
+GRAD_SINK = None
+
+
+def deliver_param_grads(params, grads):
+    """backward functions: hand ``grads`` (same order as ``params``) to the installed sink and return Nones for autograd,
+    or return them unchanged when no sink is installed"""
+    if GRAD_SINK is None:
+        return tuple(grads)
+    GRAD_SINK.deliver(params, grads)
+    return (None,) * len(grads)

@@ -134,7 +134,7 @@ if micro > 1:
         lyr.p_attn = lyr.p_hidden = 0.0
     model.text_encoder.text_encoder.config.hidden_dropout_prob = 0.0
 tr = engine.Trainer(model, build_loss(loss_cfg), torch.optim.SGD(model.parameters(), lr=0.0), None, dev, bucket_mb=16,
-                    overlap_micro=overlap)
+                    overlap_micro=overlap, grad_sink=not overlap)    # overlapped hooks <-> plain autograd accumulation; serial <-> sink
 assert tr.buckets is not None and len(tr.buckets.buckets) > 3
 out = tr.step(bt, micro_batches=micro)
 torch.save({"loss": float(out["total"]), "grads": {n: p.grad.detach().cpu() for n, p in model.named_parameters() if p.grad is not None}},

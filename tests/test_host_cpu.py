@@ -360,3 +360,25 @@ def test_world2_gather_reduce_scatter_and_grad_buckets():
     ret = mgr.dict()
     mp.spawn(_w2_worker, args=(29731, ret), nprocs=2, join=True)
     assert ret[0] and ret[1]
+
+
+def test_grad_sink_sums_like_autograd():
+    """ops.GradSink: contributions of one backward call are summed among themselves, then added to the accumulator of
+    earlier calls (autograd's order); parameters without a contribution keep grad None; finish() adds to an existing
+    ``.grad`` (parameters that also receive plain autograd gradients)."""
+    import torch
+    from mammo_clip_amd import ops
+    p1, p2, p3 = (torch.nn.Parameter(torch.zeros(s)) for s in ((3,), (2, 2), (4,)))
+    sk = ops.GradSink()
+    sk.deliver([p1, p2], [torch.full((3,), 1.0), torch.full((2, 2), 0.5)])
+    sk.deliver([p1], [torch.full((3,), 2.0)])
+    sk.flush()
+    sk.deliver([p1, p2], [torch.full((3,), 4.0), None])
+    sk.deliver([p1], [torch.full((3,), 8.0)])
+    sk.deliver([p1], [torch.full((3,), 16.0)])
+    p2.grad = torch.ones(2, 2)
+    sk.finish()
+    assert torch.equal(p1.grad, torch.full((3,), 31.0)) and torch.equal(p2.grad, torch.full((2, 2), 1.5)) and p3.grad is None
+    assert not sk.acc and not sk.pending
+    # no sink installed: the backward functions return their gradients to autograd unchanged
+    assert ops.GRAD_SINK is None and ops.deliver_param_grads([p1], [p1.grad]) == (p1.grad,)

@@ -6,6 +6,7 @@ bf16 round-off: max-abs error <= 1e-2 * max|ref| (2^-8 = 3.9e-3 per rounding) un
 kernels are held to 1e-4.
 """
 import math
+import os
 
 import pytest
 import torch
@@ -18,6 +19,7 @@ if not torch.cuda.is_available():
 
 import mammo_clip_amd  # noqa: E402,F401
 from mammo_clip_amd import ops  # noqa: E402
+import mammo_clip_amd.lib as L  # noqa: E402
 
 DEV = torch.device("cuda:0")
 BF = torch.bfloat16
@@ -90,6 +92,51 @@ def test_gemm_wgrad_tn(M, N, K):
     dy, x = rnd(M, N, seed=11), rnd(M, K, seed=12)
     dw = ops.linear_wgrad(dy, x)
     check(dw, dy.float().T @ x.float(), 2e-3, "wgrad")
+
+
+class _force_gemm256_tn:
+    def __enter__(self):
+        self.old = os.environ.get("MC_GEMM_256TN")
+        os.environ["MC_GEMM_256TN"] = "2"
+
+    def __exit__(self, *a):
+        if self.old is None:
+            os.environ.pop("MC_GEMM_256TN", None)
+        else:
+            os.environ["MC_GEMM_256TN"] = self.old
+
+
+@pytest.mark.parametrize("M,N,K", [(4096, 304, 1824), (44544, 1824, 304), (5000, 176, 1056), (16384, 768, 3072), (3000, 264, 40),
+                                   (700, 256, 256), (64, 8, 8)])
+def test_gemm256_tn_wgrad(M, N, K):
+    """256 x 256 x 64 transpose-read TN kernel (gemm256_tn.hip): dW = dY^T X, split-K through the workspace (plan from
+    mc_gemm256_tn_splits), ragged output tiles, K ranges that end inside a K tile, accumulation into an existing dW, and
+    the production route (rule-based eligibility) giving the same result."""
+    dy, x = rnd(M, N, seed=11), rnd(M, K, seed=12)
+    ref = dy.float().T @ x.float()
+    with _force_gemm256_tn():
+        assert ops._tn256_plan(N, K, M, N, K) >= 1
+        dw = ops.linear_wgrad(dy, x)
+        check(dw, ref, 2e-3, "gemm256_tn wgrad")
+        if not L.load().mc_wgrad_rows_supported(N, K):
+            dw2 = ops.linear_wgrad(dy, x, out=dw.clone())
+            check(dw2, 2 * ref, 2e-3, "gemm256_tn wgrad accumulate")
+    check(ops.linear_wgrad(dy, x), ref, 2e-3, "wgrad (default route)")
+
+
+@pytest.mark.parametrize("n_img,hw,N,K", [(4, 1392, 304, 1824), (3, 5415, 176, 1056), (5, 700, 512, 3072)])
+def test_gemm256_tn_grouped_gate(n_img, hw, N, K):
+    """grouped split-K on the TN tile kernel: reduction cut at image boundaries, the SE gate applied to each image's
+    partial when the partials are combined [ref: efficientnet_custom.py:114-122 backward]"""
+    M = n_img * hw
+    x, dy = rnd(M, K, seed=101), rnd(M, N, seed=104)
+    gate = torch.sigmoid(rnd(n_img, K, seed=103, dtype=torch.float32))
+    img = torch.arange(M, device=DEV) // hw
+    ref = dy.float().T @ (x.float() * gate[img])
+    with _force_gemm256_tn():
+        assert ops._tn256_plan(N, K, M, N, K, group_rows=hw) >= 1
+        dw = ops.linear_wgrad(dy, x, pro=(None, None, gate, hw))
+    check(dw, ref, 3e-3, "gemm256_tn grouped gate wgrad")
 
 
 def test_gemm_prologue_a_and_b():
