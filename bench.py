@@ -19,12 +19,16 @@ the last `keep` micro-batches are forwarded once, graph kept; 2 full graphs = 23
 with the MBConv recompute mode 3).  At N = 1 a step is 32 micro-batches (about 12.4 s).  "--workload cfg3" is BASELINE configs[2], 32 pairs per GPU in one pass (weak scaling).
 
 The JSON line carries, besides the contract fields:
-  roofline     -- the dominant kernel of the step (largest share of GPU time in the rocprofv3 kernel stats under
-                  profiles/).  The candidates at the top of that table -- bnact_bwd_k<true>, the HBM-bound
-                  BatchNorm(+SiLU) backward apply pass, and the two plain NT MFMA tile kernels (128x128 and 256x256) --
-                  are each bracketed by HIP events on the launch stream at every launch inside the timed steps; the one
-                  with the most GPU time in the run is "roofline", then "roofline_runner_up", "roofline_third";
-                  achieved = algorithmic bytes (flops) per launch / average launch duration
+  roofline     -- the dominant kernel class of THIS run.  The last warm-up step is run with HIP events around every C-ABI
+                  launch (all ~70 entry points, keyed by entry point + shape class, e.g. "mc_dwconv_fwd:k5s1"); the three
+                  classes with the most GPU time are then bracketed by HIP events on the launch stream at every launch
+                  inside the timed steps and reported as "roofline", "roofline_runner_up", "roofline_third"
+                  (achieved = algorithmic bytes or flops per launch / average launch duration; bound = hbm or mfma by
+                  the class's flop / byte ratio against the 2.5 PFLOP/s : 8 TB/s ridge; traffic = PMC bytes per launch
+                  from profiles/r03_roofline_traffic.json where that class was measured, else null)
+  n8_load      -- (default workload, N = 1 only) ms/step of the step ONE GPU runs at N = 8: 128 pairs as 4 micro-batches,
+                  recompute mode 3, all four graphs kept, no communication -- the like-for-like single-GPU time a
+                  1 -> 8 scaling curve should be read against (the N = 1 point itself carries 31 re-forwards)
   cpu_baseline -- the CPU oracle (oracle/, torch-fp32 restatement of the reference) timed on this box's host cores
                   on a bounded sample of the same workload (rank 0, N = 1 only)
 """
@@ -54,20 +58,52 @@ WORKLOADS = {
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 MFMA_PEAK_TFS = 2500.0         # dense bf16 MFMA peak
 
-# The top of the rocprofv3 kernel statistics of the default command (profiles/r02_cfg4_kernel_stats.csv):
-#  * bnact_bwd_k<true>, the BatchNorm(+SiLU) backward "apply" pass  dx = A*dz + B*x + C  (reads the saved conv output x
-#    and the upstream gradient g, writes dx): HBM-bound, 3 x rows x channels x 2 B algorithmic bytes per launch;
-#  * the plain NT direct-to-LDS MFMA tile kernels (forward / data-gradient 1x1 convolutions of the late stages and the BERT
-#    linears): gemm_kernel<128,128,64,2,2,0,0,false,true> and, where its 256 x 256 tiles fill the 256 CUs well,
-#    g256::gemm256_kernel (mc_gemm_tile_config): MFMA-bound, 2 M N K flop per launch.
-# All three are timed live and ranked by GPU time in the run: "roofline", "roofline_runner_up", "roofline_third".
-GEMM_KERNEL = ("gemm_kernel<128,128,64,2,2,0,0,false,true> (plain NT direct-to-LDS MFMA tiles 128x128x64: late-stage 1x1 convs "
-               "fwd/dgrad, BERT linears -- the problems whose 256x256 tiling would not fill the 256 CUs)")
-GEMM256_KERNEL = ("g256::gemm256_kernel (plain NT direct-to-LDS MFMA tiles 256x256x64, 8 waves, 160 KB LDS: late-stage expand / "
-                  "projection convs, BERT FFN1, where mc_gemm_tile_config picks it)")
-ROOFLINE_OP = "mc_bnact_bwd_apply"
-ROOFLINE_KERNEL = "bnact_bwd_k<true> (BatchNorm+SiLU backward apply pass)"
-STREAM_OPS = (ROOFLINE_OP, "mc_gemm_bf16")
+RIDGE = MFMA_PEAK_TFS * 1e12 / (HBM_PEAK_GBS * 1e9)      # flop per byte above which a kernel class is MFMA-bound
+
+# entry point (+ shape class) -> the kernel behind it, for the report
+KERNEL_NAMES = {
+    "mc_bnact_bwd_apply": "bnact_bwd_k<true> (BatchNorm+SiLU backward apply pass: dx = A*dz + B*x + C)",
+    "mc_bnact_bwd_reduce": "bnact_bwd_k<false> (BatchNorm backward reduce pass)",
+    "mc_bnact_se_sums": "bnact_se_sums_k (SE-gate gradient + BatchNorm1 backward sums, one pass over (d, dA1))",
+    "mc_bnact_pool": "bnact_img_reduce_k (BN+SiLU + squeeze-excite average pool)",
+    "mc_bnact_apply": "bnact_apply_k (BatchNorm2 + drop-connect + residual)",
+    "mc_dwconv_fwd": "dwconv_march_fwd_kernel (depthwise conv forward / stride-1 data gradient, marching LDS kernel)",
+    "mc_dwconv_bwd_weight": "dwconv_march_bww_kernel (depthwise conv weight gradient)",
+    "mc_dwconv_bwd_data": "dwconv_march_bwd_s2_kernel (depthwise conv stride-2 data gradient)",
+    "mc_gemm_rows_bf16": "gemm_rows_kernel (row-streaming 1x1 conv forward / data gradient, weights resident in LDS)",
+    "mc_wgrad_rows_bf16": "wgrad_rows_kernel (row-streaming 1x1 conv weight gradient, LDS transpose-reads)",
+    "mc_gemm_bf16|glnt256": "g8::gemm8p_kernel (plain NT 256x256x64 MFMA tiles, 8 waves, 4 phases per K tile, LDS-direct DMA)",
+    "mc_gemm_bf16|glnt": "gemm_kernel<128,128,64,2,2,0,0,false,true> (plain NT 128x128x64 MFMA tiles)",
+    "mc_gemm_bf16|tn256": "g8t::gemm256_tn_kernel (TN weight-gradient 256x256x64 MFMA tiles, LDS transpose-reads, split-K)",
+    "mc_adamw_step": "adamw_multi_k (multi-tensor AdamW)",
+}
+
+
+def kernel_name(key):
+    """entry point ':' class tags -> kernel description; for the plain-operand GEMM entry point the class tag names the
+    kernel, and forward / data-gradient calls of one kernel are one class (class_key)"""
+    for k, v in KERNEL_NAMES.items():
+        ep, _, tag = k.partition("|")
+        if key.split(":")[0] == ep and (not tag or key.endswith("|" + tag)):
+            return v + (" [" + key + "]" if ":" in key else "")
+    return key
+
+
+def class_key(key):
+    """merge the timer's record keys into kernel classes: 'mc_gemm_bf16:fwd|glnt256' and ':dgrad|glnt256' -> one class"""
+    ep, _, kind = key.partition(":")
+    for tag in ("glnt256", "glnt", "tn256"):
+        if ep == "mc_gemm_bf16" and kind.endswith("|" + tag):
+            return f"{ep}:|{tag}"
+    return key
+
+
+def merged(summ):
+    out = {}
+    for k, (cnt, t_ms, by, fl) in summ.items():
+        c = out.get(class_key(k), (0, 0.0, 0, 0))
+        out[class_key(k)] = (c[0] + cnt, c[1] + t_ms, c[2] + by, c[3] + fl)
+    return out
 
 
 def model_cfg(enc_name, fp8=False, recompute=0):
@@ -134,6 +170,7 @@ def main():
     ap.add_argument("--recompute", type=int, default=-1, choices=(-1, 0, 1, 2, 3),
                     help="MBConv activation recompute mode (EfficientNet.set_recompute); -1 = chosen with --keep-graphs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-n8-load", action="store_true", help="skip the n8_load block of the default N = 1 run")
     ap.add_argument("--fp8", action="store_true", help="fp8 (e4m3) operands for the late-stage 1x1 convolutions (config #5 arithmetic on any workload)")
     ap.add_argument("--op-profile", action="store_true", help="print a per-entry-point HIP-event breakdown (rank 0)")
     args = ap.parse_args()
@@ -203,11 +240,23 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    # warm-up; the LAST warm-up step (an extra step when --warmup 0) is the survey step: HIP events around every C-ABI
+    # launch -> GPU time per kernel class -> the three classes the timed steps bracket
+    for _ in range(max(args.warmup - 1, 0)):
         ld = trainer.step(batch, args.micro_batches)
     sync()
-    timer = L.OpTimer(only=None if args.op_profile else STREAM_OPS, kind_contains={"mc_gemm_bf16": "|glnt"})
+    survey = L.OpTimer()
+    L.TIMER = survey
+    ld = trainer.step(batch, args.micro_batches)
+    sync()
+    L.TIMER = None
+    raw = survey.summary()
+    ssum = merged(raw)
+    del survey
+    top = [k for k, v in sorted(ssum.items(), key=lambda kv: -kv[1][1]) if v[2] > 0 or v[3] > 0][:3]
+    timer = L.OpTimer(keys=None if args.op_profile else [k for k in raw if class_key(k) in top])
     L.TIMER = timer
+    torch.cuda.reset_peak_memory_stats()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         ld = trainer.step(batch, args.micro_batches)
@@ -219,47 +268,54 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax)
     loss_val = float(ld["total"])
-    summ = timer.summary()
+    raw_timed = timer.summary()
+    summ = merged(raw_timed)
     peak_gb = torch.cuda.max_memory_allocated() / 1e9
+
+    n8 = None
+    if world == 1 and args.workload == "cfg4" and strong and not args.no_n8_load:
+        # the step one GPU runs at N = 8 (128 pairs = 4 micro-batches, recompute mode 3, four kept graphs), no communication
+        del batch, ld
+        trainer.optimizer.zero_grad(set_to_none=True)
+        torch.cuda.empty_cache()
+        model.image_encoder.set_recompute(3)
+        trainer.keep_graphs = 4
+        b8 = synth_batch_gpu(128, H, W, T, device, seed=99)
+        trainer.step(b8, 4)
+        torch.cuda.synchronize()
+        torch.cuda.reset_peak_memory_stats()
+        t8 = time.perf_counter()
+        for _ in range(2):
+            trainer.step(b8, 4)
+        torch.cuda.synchronize()
+        ms8 = (time.perf_counter() - t8) / 2 * 1e3
+        n8 = {"ms_per_step": round(ms8, 1), "pairs_per_s_per_gpu": round(128 / ms8 * 1e3, 2), "pairs_per_gpu": 128,
+              "micro_batches": 4, "keep_graphs": 4, "recompute": 3, "steps": 2, "peak_hbm_gb": round(torch.cuda.max_memory_allocated() / 1e9, 1),
+              "note": "per-GPU load of the N = 8 run of this workload on ONE GPU, no collectives; 8 x this rate is the no-communication ceiling of the 8-GPU point"}
+        del b8
 
     if rank == 0:
         ms = dt / args.steps * 1e3
         pairs = b * world * args.steps / dt
-        sc, st, sb, _ = summ.get(ROOFLINE_OP, (0, 0.0, 0, 0))
-        ach = sb / (st * 1e-3) / 1e9 if st > 0 else 0.0
-        traffic = gtraffic = g256traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r02_roofline_traffic.json")
-        if not os.path.exists(tpath):
-            tpath = os.path.join(ROOT, "profiles", "r01_roofline_traffic.json")
-        if os.path.exists(tpath) and args.workload in ("cfg3", "cfg4") and not args.batch:   # same 32-pair kernel launches
-            tj = json.load(open(tpath))                                     # PMC passes (rocprofv3 --pmc), same workload
-            traffic, gtraffic = tj.get("hbm_bytes_per_launch"), tj.get("gemm_nt_hbm_bytes_per_launch")
-            g256traffic = tj.get("gemm256_hbm_bytes_per_launch")
-        # the two kernels that share the top of the rocprofv3 kernel statistics (profiles/r01_cfg4_kernel_stats.csv):
-        # the HBM-bound BN-backward apply pass and the MFMA NT GEMM instance; the one with more GPU time in THIS run
-        # is reported as "roofline", the other as "roofline_runner_up"
-        timing = "HIP events on the launch stream around every launch inside the timed steps"
-        r_hbm = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                 "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "kernel": ROOFLINE_KERNEL, "launches": sc,
-                 "avg_launch_us": round(st / max(sc, 1) * 1e3, 1), "algorithmic_bytes_per_launch": int(sb / max(sc, 1)),
-                 "gpu_ms_in_timed_steps": round(st, 1), "timing": timing}
+        tpath = os.path.join(ROOT, "profiles", "r03_roofline_traffic.json")
+        tj = json.load(open(tpath)) if os.path.exists(tpath) and args.workload in ("cfg3", "cfg4") and not args.batch else {}
+        timing = "HIP events on the launch stream around every launch of this class inside the timed steps"
 
-        def mfma_entry(sel, name, traffic_bytes):
-            gc = sum(v[0] for k, v in summ.items() if sel(k))
-            gt = sum(v[1] for k, v in summ.items() if sel(k))
-            gb = sum(v[2] for k, v in summ.items() if sel(k))
-            gf = sum(v[3] for k, v in summ.items() if sel(k))
-            gach = gf / (gt * 1e-3) / 1e12 if gt > 0 else 0.0
-            return {"bound": "mfma", "achieved": round(gach, 1), "peak": MFMA_PEAK_TFS, "unit": "TFLOP/s",
-                    "frac": round(gach / MFMA_PEAK_TFS, 4), "traffic": traffic_bytes, "kernel": name, "launches": gc,
-                    "avg_launch_us": round(gt / max(gc, 1) * 1e3, 1), "algorithmic_flops_per_launch": int(gf / max(gc, 1)),
-                    "algorithmic_bytes_per_launch": int(gb / max(gc, 1)),
-                    "gpu_ms_in_timed_steps": round(gt, 1), "timing": timing}
-        # the plain NT MFMA tile kernels are two different kernels (rocprofv3 lists them separately): timed separately
-        r_g128 = mfma_entry(lambda k: k.startswith("mc_gemm_bf16") and k.endswith("|glnt"), GEMM_KERNEL, gtraffic)
-        r_g256 = mfma_entry(lambda k: k.startswith("mc_gemm_bf16") and k.endswith("|glnt256"), GEMM256_KERNEL, g256traffic)
-        ranked = sorted([r_hbm, r_g128, r_g256], key=lambda r: -r["gpu_ms_in_timed_steps"])
-        first, second, third = ranked
+        def entry(key):
+            cnt, t_ms, by, fl = summ.get(key, (0, 0.0, 0, 0))
+            mfma = by > 0 and fl / by >= RIDGE
+            if mfma:
+                ach, peak, unit = (fl / (t_ms * 1e-3) / 1e12 if t_ms > 0 else 0.0), MFMA_PEAK_TFS, "TFLOP/s"
+            else:
+                ach, peak, unit = (by / (t_ms * 1e-3) / 1e9 if t_ms > 0 else 0.0), HBM_PEAK_GBS, "GB/s"
+            return {"bound": "mfma" if mfma else "hbm", "achieved": round(ach, 1), "peak": peak, "unit": unit,
+                    "frac": round(ach / peak, 4), "traffic": tj.get(key), "kernel": kernel_name(key), "launches": cnt,
+                    "avg_launch_us": round(t_ms / max(cnt, 1) * 1e3, 1), "algorithmic_bytes_per_launch": int(by / max(cnt, 1)),
+                    "algorithmic_flops_per_launch": int(fl / max(cnt, 1)), "gpu_ms_in_timed_steps": round(t_ms, 1),
+                    "share_of_gpu_time_in_survey_step": round(ssum[key][1] / max(sum(v[1] for v in ssum.values()), 1e-9), 4),
+                    "timing": timing}
+        ranked = sorted((entry(k) for k in top), key=lambda r: -r["gpu_ms_in_timed_steps"])
+        first, second, third = (ranked + [None, None, None])[:3]
         res = {
             "metric": "image-text pairs/s (whole node), EN-B5+BioClinicalBERT contrastive pre-training step",
             "value": round(pairs, 3), "unit": "image-text pairs/s", "n_gpus": world, "steps": args.steps,
@@ -273,13 +329,15 @@ def main():
                        "keep_graphs": args.keep_graphs, "recompute": args.recompute},
             "roofline": first, "roofline_runner_up": second, "roofline_third": third,
         }
+        if n8 is not None:
+            res["n8_load"] = n8
         if world == 1 and not args.no_cpu_baseline:
             try:
                 res["cpu_baseline"] = cpu_baseline(arch_name, H, W, T)
             except Exception as e:                # pragma: no cover
                 res["cpu_baseline"] = {"value": None, "error": repr(e)}
         if args.op_profile:
-            rows = sorted(summ.items(), key=lambda kv: -kv[1][1])
+            rows = sorted(raw_timed.items(), key=lambda kv: -kv[1][1])
             tot = sum(v[1] for _, v in rows)
             print(f"# per-entry-point HIP-event time over {args.steps} steps (sum {tot:.1f} ms, wall {dt*1e3:.1f} ms)", file=sys.stderr)
             for k, (cnt, t_ms, by, fl) in rows:

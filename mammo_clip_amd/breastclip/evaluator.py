@@ -40,10 +40,22 @@ class Evaluator:
         return (emb / torch.norm(emb, dim=1, keepdim=True)).float().cpu().numpy()
 
     @staticmethod
-    def zeroshot_scores(image_embeddings: np.ndarray, text_embeddings: np.ndarray) -> np.ndarray:
-        """softmax over prompts of the cosine similarity [ref: evaluator.py:171]"""
-        a = image_embeddings / np.linalg.norm(image_embeddings, axis=1, keepdims=True)
-        b = text_embeddings / np.linalg.norm(text_embeddings, axis=1, keepdims=True)
-        s = a @ b.T
+    def zeroshot_scores(image_embeddings, text_embeddings) -> np.ndarray:
+        """softmax over prompts of the cosine similarity [ref: evaluator.py:171].  numpy inputs (what encode_image /
+        encode_text return, and what the reference computes on): host arithmetic like the reference; HIP tensors: the
+        normalisation and the similarity matrix run on the device (l2norm + fp32 GEMM kernels of head.hip)."""
+        if torch.is_tensor(image_embeddings) and image_embeddings.is_cuda:
+            from .. import ops
+            a, _ = ops.l2norm_fwd(image_embeddings.float().contiguous())
+            b, _ = ops.l2norm_fwd(text_embeddings.float().contiguous().to(a.device))
+            n, d = a.shape
+            m = b.shape[0]
+            st = torch.empty((n, m), dtype=torch.float32, device=a.device)
+            ops.sgemm(a, d, 1, b, 1, d, st, m, n, m, d)                       # a @ b.T
+            s = st.cpu().numpy()
+        else:
+            a = image_embeddings / np.linalg.norm(image_embeddings, axis=1, keepdims=True)
+            b = text_embeddings / np.linalg.norm(text_embeddings, axis=1, keepdims=True)
+            s = a @ b.T
         e = np.exp(s - s.max(axis=1, keepdims=True))
         return e / e.sum(axis=1, keepdims=True)

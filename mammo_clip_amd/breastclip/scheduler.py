@@ -33,12 +33,18 @@ def build_scheduler(optimizer, sched_config, total_steps=None, steps_per_epoch=N
             total = total_steps
         elif "total_epochs" in cfg and steps_per_epoch is not None:
             total = steps_per_epoch * cfg["total_epochs"]
-        else:
+        elif "total_steps" in cfg:
             total = cfg["total_steps"]
+        else:
+            raise ValueError("cosine scheduler: 'total_epochs' needs steps_per_epoch (= len(train_dataloader), what the "
+                             "reference resolves it with, trainer_ddp.py:146-153), or give 'total_steps'")
         if "warmup_epochs" in cfg and isinstance(cfg["warmup_epochs"], float):
             warm = cfg["warmup_epochs"]
         elif "warmup_epochs" in cfg and steps_per_epoch is not None:
             warm = steps_per_epoch * cfg["warmup_epochs"]
+        elif "warmup_epochs" in cfg and "warmup_steps" not in cfg:
+            raise ValueError("cosine scheduler: an integer 'warmup_epochs' needs steps_per_epoch (= len(train_dataloader)); "
+                             "silently training without warm-up is not what the config asks for")
         else:
             warm = cfg.get("warmup_steps", 0)
         return LinearWarmupCosineAnnealingLR(optimizer, total_steps=total, warmup_steps=warm)

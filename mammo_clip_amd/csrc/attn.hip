@@ -366,12 +366,9 @@ extern "C" int mc_attn_fwd(const mc_bf16* qkv, const float* mask_bias, int b, in
     attn_args a{};
     a.qkv = (const bf16_t*)qkv; a.maskb = mask_bias; a.ctx = (bf16_t*)ctx; a.lse = lse;
     a.t = t; a.nh = nh; a.alpha = alpha; a.p = p; a.seed = seed; a.sid = stream_id;
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)attn_fwd_k<true>, hipFuncAttributeMaxDynamicSharedMemorySize, FWD_LDS);
-        (void)hipFuncSetAttribute((const void*)attn_fwd_k<false>, hipFuncAttributeMaxDynamicSharedMemorySize, FWD_LDS);
-        attr = true;
-    }
+    static unsigned long long done_t = 0, done_f = 0;
+    MC_SET_MAX_LDS(done_t, attn_fwd_k<true>, FWD_LDS);
+    MC_SET_MAX_LDS(done_f, attn_fwd_k<false>, FWD_LDS);
     if (p > 0.f) hipLaunchKernelGGL(attn_fwd_k<true>, dim3(b * nh), dim3(512), FWD_LDS, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(attn_fwd_k<false>, dim3(b * nh), dim3(512), FWD_LDS, (hipStream_t)stream, a);
     MC_LAUNCH_CHECK();
@@ -387,12 +384,9 @@ extern "C" int mc_attn_bwd(const mc_bf16* qkv, const float* mask_bias, const mc_
     a.qkv = (const bf16_t*)qkv; a.maskb = mask_bias; a.dctx = (const bf16_t*)dctx; a.dqkv = (bf16_t*)dqkv;
     a.lse = const_cast<float*>(lse);
     a.t = t; a.nh = nh; a.alpha = alpha; a.p = p; a.seed = seed; a.sid = stream_id;
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)attn_bwd_k<true>, hipFuncAttributeMaxDynamicSharedMemorySize, BWD_LDS);
-        (void)hipFuncSetAttribute((const void*)attn_bwd_k<false>, hipFuncAttributeMaxDynamicSharedMemorySize, BWD_LDS);
-        attr = true;
-    }
+    static unsigned long long done_t = 0, done_f = 0;
+    MC_SET_MAX_LDS(done_t, attn_bwd_k<true>, BWD_LDS);
+    MC_SET_MAX_LDS(done_f, attn_bwd_k<false>, BWD_LDS);
     if (p > 0.f) hipLaunchKernelGGL(attn_bwd_k<true>, dim3(b * nh), dim3(512), BWD_LDS, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(attn_bwd_k<false>, dim3(b * nh), dim3(512), BWD_LDS, (hipStream_t)stream, a);
     MC_LAUNCH_CHECK();

@@ -127,5 +127,21 @@ __device__ __forceinline__ void dropout_scale8(unsigned long long seed, uint32_t
     }
 }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute: a process that touches more than one device (the
+// shared-device multi-rank modes, a test on cuda:1) must set it on each.  `done` = a 64-bit per-call-site device mask.
+#define MC_SET_MAX_LDS(done, func, bytes)                                                                          \
+    do {                                                                                                           \
+        int dev__ = 0;                                                                                             \
+        (void)hipGetDevice(&dev__);                                                                                \
+        const unsigned long long bit__ = 1ULL << (dev__ & 63);                                                     \
+        if (!((done) & bit__)) {                                                                                   \
+            if (hipFuncSetAttribute((const void*)(func), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)) != hipSuccess) { \
+                mc_set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");                            \
+                return MC_ERR_LAUNCH;                                                                              \
+            }                                                                                                      \
+            (done) |= bit__;                                                                                       \
+        }                                                                                                          \
+    } while (0)
+
 static inline int mc_div_up(long long a, long long b) { return (int)((a + b - 1) / b); }
 static inline bool mc_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }

@@ -12,9 +12,13 @@
 
 namespace {
 
+// NaN-propagating max of non-negative values (fmaxf drops a NaN operand: a NaN activation would be quantised to a
+// finite value and the divergence hidden).  A NaN amax has the largest bit pattern, so the integer atomicMax keeps it;
+// with a NaN amax the scale is NaN and every quantised value of the tensor comes out NaN (e4m3 0x7f).
+__device__ __forceinline__ float nmax(float a, float b) { return (a != a || a > b) ? a : b; }
 __device__ __forceinline__ float wave_max_f(float v) {
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    for (int o = 32; o > 0; o >>= 1) v = nmax(v, __shfl_xor(v, o, 64));
     return v;
 }
 
@@ -24,20 +28,20 @@ __global__ __launch_bounds__(256) void amax_bf16_k(const bf16_t* __restrict__ x,
         float f[8];
         unpack8(nt_load16(x + i * 8), f);
 #pragma unroll
-        for (int q = 0; q < 8; ++q) m = fmaxf(m, fabsf(f[q]));
+        for (int q = 0; q < 8; ++q) m = nmax(fabsf(f[q]), m);
     }
     m = wave_max_f(m);
     __shared__ float red[4];
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
     __syncthreads();
-    if (threadIdx.x == 0) atomicMax(amax, __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]))));
+    if (threadIdx.x == 0) atomicMax(amax, __float_as_uint(nmax(nmax(red[0], red[1]), nmax(red[2], red[3]))));
 }
 
 __global__ __launch_bounds__(256) void quant_fp8_bf16_k(const bf16_t* __restrict__ x, long long nv, const float* __restrict__ amax_in,
                                                         unsigned char* __restrict__ y, float* __restrict__ scale_out,
                                                         unsigned* __restrict__ amax_next) {
     const float amax = amax_in[0];
-    const float scale = amax > 0.f ? 448.0f / amax : 1.0f;
+    const float scale = amax != amax ? amax : (amax > 0.f ? 448.0f / amax : 1.0f);
     if (blockIdx.x == 0 && threadIdx.x == 0 && scale_out) scale_out[0] = amax > 0.f ? amax / 448.0f : 1.0f;
     float m = 0.f;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nv; i += (long long)gridDim.x * 256) {
@@ -45,8 +49,9 @@ __global__ __launch_bounds__(256) void quant_fp8_bf16_k(const bf16_t* __restrict
         unpack8(nt_load16(x + i * 8), f);
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            m = fmaxf(m, fabsf(f[q]));
-            f[q] = fminf(fmaxf(f[q] * scale, -448.0f), 448.0f);
+            m = nmax(fabsf(f[q]), m);
+            const float v = f[q] * scale;
+            f[q] = v != v ? v : fminf(fmaxf(v, -448.0f), 448.0f);          // clamp finite values, let NaN through
         }
         int lo = 0, hi = 0;
         lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], lo, false);
@@ -60,7 +65,7 @@ __global__ __launch_bounds__(256) void quant_fp8_bf16_k(const bf16_t* __restrict
         __shared__ float red[4];
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
         __syncthreads();
-        if (threadIdx.x == 0) atomicMax(amax_next, __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]))));
+        if (threadIdx.x == 0) atomicMax(amax_next, __float_as_uint(nmax(nmax(red[0], red[1]), nmax(red[2], red[3]))));
     }
 }
 

@@ -227,12 +227,8 @@ template <int FN, int KC> int launch_rows(const mc_gemm_rows_args& p, int blocks
     constexpr int RG = (FN >= 6 || KC >= 12) ? 1 : 2;   // wide outputs / deep K: 16 rows per iteration (register budget)
     constexpr int PF = KC >= 12 ? 1 : (KC >= 6 ? (RG == 1 ? 2 : 1) : 8 / KC);   // ~8-16 KB of activations in flight per wave
     size_t lds = lds_bytes<FN, KC>();
-    static bool attr_set = false;
-    if (lds > 64 * 1024 && !attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_rows_kernel<FN, KC, PF, RG>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    static unsigned long long attr_done = 0;
+    if (lds > 64 * 1024) MC_SET_MAX_LDS(attr_done, (&gemm_rows_kernel<FN, KC, PF, RG>), lds);
     const int ntiles = (p.N + FN * 16 - 1) / (FN * 16);
     hipLaunchKernelGGL((gemm_rows_kernel<FN, KC, PF, RG>), dim3((blocks + 7) / 8 * 8 * ntiles), dim3(256), lds, st, p, blocks, ntiles);
     MC_LAUNCH_CHECK();

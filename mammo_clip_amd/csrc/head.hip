@@ -110,8 +110,12 @@ __global__ void ce_fwd_bwd_k(float* __restrict__ logits, int rows, int n, const 
     const float lse = mx + __logf(s);
     const int label = (labels ? (int)labels[row] : row) + label_offset;
     const float scale = w / (float)rows;
+    // caller-supplied labels are validated here (the host can only range-check the arange form): an out-of-range label
+    // makes the row's loss -- and with it the step's loss -- NaN instead of reading beside the row
+    const bool ok = label >= 0 && label < n;
     // label smoothing eps: target = (1-eps) * onehot + eps / n   (torch F.cross_entropy semantics)
-    if (lane == 0) row_loss[row] = ((1.f - eps) * (lse - lr[label]) + eps * (lse - sx / (float)n)) * scale;
+    if (lane == 0)
+        row_loss[row] = ok ? ((1.f - eps) * (lse - lr[label]) + eps * (lse - sx / (float)n)) * scale : __uint_as_float(0x7fc00000u);
     const float inv = 1.f / s;
     const float un = eps / (float)n;
     for (int i = lane; i < n; i += 64) {

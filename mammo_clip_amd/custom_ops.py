@@ -1,9 +1,21 @@
 """``torch.library`` registration of the C-ABI kernels ("exposed as custom ops").
 
-The model in ``breastclip/`` drives the kernels through one ``torch.autograd.Function`` per stem / MBConv block / BERT
-layer (ops.py wrappers, many launches per node, hand-derived backward).  The same kernels are ALSO registered here as
-dispatcher-visible operators under the ``mammoclip::`` namespace, so they show up in ``torch.ops``, in the profiler, and
-can be traced / captured like any other operator:
+The model in ``breastclip/`` is one ``torch.autograd.Function`` per stem / MBConv block / BERT layer with a hand-derived
+backward; INSIDE those functions every 1x1-convolution / linear and every depthwise-convolution launch goes through the
+dispatcher-visible operators registered here (``ops.linear_fwd`` / ``linear_dgrad`` / ``linear_wgrad`` / ``dwconv_fwd`` /
+``dwconv_bwd_data`` / ``dwconv_bwd_weight`` are thin wrappers over them):
+
+    torch.ops.mammoclip.conv1x1(x, w, bias?, residual?, pro_scale?, pro_shift?, pro_gate?, rows_per_img, stats, has_pro)
+                                  -> (y, BatchNorm column-statistic partials)      forward, fused BN+SiLU(+SE gate) prologue
+    torch.ops.mammoclip.conv1x1_dgrad(dy, w, residual?, w_t?) -> dx
+    torch.ops.mammoclip.conv1x1_wgrad(dy, x, pro_scale?, pro_shift?, pro_gate?, rows_per_img, has_pro) -> dw (fp32)
+    torch.ops.mammoclip.dwconv_bn(x, w_kkc, n, h, w, k, stride, pad_l, pad_t, oh, ow, pro_scale?, pro_shift?, stats) -> (y, partials)
+    torch.ops.mammoclip.dwconv_dgrad(dy, w_kkc, n, h, w, k, stride, pad_l, pad_t, oh, ow, w_kkc_flipped?) -> dx
+    torch.ops.mammoclip.dwconv_wgrad(x, dy, n, h, w, k, stride, pad_l, pad_t, oh, ow, pro_scale?, pro_shift?) -> dw (fp32)
+
+(registered with ``torch.library.Library.define`` / ``impl``: ~2.5 us of dispatcher per call; they are called under the
+functions' own backward, so they carry no autograd formula of their own).  A second, self-contained set is differentiable
+on its own and usable outside the model:
 
     torch.ops.mammoclip.linear(x, w, bias, residual)          y = x . w^T (+bias)(+residual)    bf16, differentiable
     torch.ops.mammoclip.dwconv(x, w_kkc, n, h, w, k, stride, pad_l, pad_t, oh, ow)   depthwise conv, differentiable
@@ -30,7 +42,7 @@ def _op(name, mutates=()):
 # ------------------------------------------------------------------------------------------------ 1x1 conv / linear
 @_op("linear")
 def linear(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, residual: Optional[Tensor] = None) -> Tensor:
-    return ops.linear_fwd(x, w, bias=bias, residual=residual)
+    return ops._linear_fwd_impl(x, w, bias=bias, residual=residual)
 
 
 @linear.register_fake
@@ -40,7 +52,7 @@ def _(x, w, bias=None, residual=None):
 
 @_op("linear_dgrad")
 def linear_dgrad(dy: Tensor, w: Tensor) -> Tensor:
-    return ops.linear_dgrad(dy, w)
+    return ops._linear_dgrad_impl(dy, w)
 
 
 @linear_dgrad.register_fake
@@ -50,7 +62,7 @@ def _(dy, w):
 
 @_op("linear_wgrad")
 def linear_wgrad(dy: Tensor, x: Tensor) -> Tensor:
-    return ops.linear_wgrad(dy, x)
+    return ops._linear_wgrad_impl(dy, x)
 
 
 @linear_wgrad.register_fake
@@ -80,7 +92,7 @@ linear.register_autograd(_linear_backward, setup_context=_linear_setup)
 @_op("dwconv")
 def dwconv(x: Tensor, w_kkc: Tensor, n: int, h: int, w: int, k: int, stride: int, pad_l: int, pad_t: int, oh: int,
            ow: int) -> Tensor:
-    return ops.dwconv_fwd(x, w_kkc, n, h, w, x.shape[1], k, stride, pad_l, pad_t, oh, ow)
+    return ops._dwconv_fwd_impl(x, w_kkc, n, h, w, x.shape[1], k, stride, pad_l, pad_t, oh, ow)
 
 
 @dwconv.register_fake
@@ -92,7 +104,7 @@ def _(x, w_kkc, n, h, w, k, stride, pad_l, pad_t, oh, ow):
 def dwconv_bwd_data(dy: Tensor, w_kkc: Tensor, n: int, h: int, w: int, k: int, stride: int, pad_l: int, pad_t: int,
                     oh: int, ow: int) -> Tensor:
     flipped = w_kkc.flip(0).contiguous() if stride == 1 else None
-    return ops.dwconv_bwd_data(dy, w_kkc, n, h, w, dy.shape[1], k, stride, pad_l, pad_t, oh, ow, w_kkc_flipped=flipped)
+    return ops._dwconv_bwd_data_impl(dy, w_kkc, n, h, w, dy.shape[1], k, stride, pad_l, pad_t, oh, ow, w_kkc_flipped=flipped)
 
 
 @dwconv_bwd_data.register_fake
@@ -103,7 +115,7 @@ def _(dy, w_kkc, n, h, w, k, stride, pad_l, pad_t, oh, ow):
 @_op("dwconv_bwd_weight")
 def dwconv_bwd_weight(x: Tensor, dy: Tensor, n: int, h: int, w: int, k: int, stride: int, pad_l: int, pad_t: int,
                       oh: int, ow: int) -> Tensor:
-    return ops.dwconv_bwd_weight(x, dy, n, h, w, x.shape[1], k, stride, pad_l, pad_t, oh, ow)
+    return ops._dwconv_bwd_weight_impl(x, dy, n, h, w, x.shape[1], k, stride, pad_l, pad_t, oh, ow)
 
 
 @dwconv_bwd_weight.register_fake
@@ -180,5 +192,75 @@ def cross_entropy_(logits: Tensor, loss: Tensor, label_offset: int, weight: floa
     ops.ce_fwd_bwd(logits, label_offset, weight, loss, smoothing, labels=labels)
 
 
+# ------------------------------------------------------------------------------------------------ the model's operators
+_EMPTY = {}
+
+
+def _empty_f32(like):
+    key = like.device
+    t = _EMPTY.get(key)
+    if t is None:
+        t = _EMPTY[key] = torch.empty(0, dtype=torch.float32, device=like.device)
+    return t
+
+
+def _pro4(ps, pf, pg, rpi, has_pro):
+    return (ps, pf, pg, rpi) if has_pro else None
+
+
+def _conv1x1(x, w, bias, residual, ps, pf, pg, rpi, stats, has_pro):
+    r = ops._linear_fwd_impl(x, w, bias=bias, residual=residual, stats=stats, pro=_pro4(ps, pf, pg, rpi, has_pro))
+    return r if stats else (r, _empty_f32(x))
+
+
+def _conv1x1_meta(x, w, bias, residual, ps, pf, pg, rpi, stats, has_pro):
+    return x.new_empty((x.shape[0], w.shape[0])), x.new_empty((1 if stats else 0, 2, w.shape[0]), dtype=torch.float32)
+
+
+def _conv1x1_dgrad(dy, w, residual, w_t):
+    return ops._linear_dgrad_impl(dy, w, residual=residual, w_t=w_t)
+
+
+def _conv1x1_wgrad(dy, x, ps, pf, pg, rpi, has_pro):
+    return ops._linear_wgrad_impl(dy, x, pro=_pro4(ps, pf, pg, rpi, has_pro))
+
+
+def _dwconv_bn(x, w_kkc, n, h, w, k, stride, pad_l, pad_t, oh, ow, ps, pf, stats):
+    r = ops._dwconv_fwd_impl(x, w_kkc, n, h, w, x.shape[1], k, stride, pad_l, pad_t, oh, ow,
+                             pro=(ps, pf) if ps is not None else None, stats=stats)
+    return r if stats else (r, _empty_f32(x))
+
+
+def _dwconv_dgrad(dy, w_kkc, n, h, w, k, stride, pad_l, pad_t, oh, ow, w_flip):
+    return ops._dwconv_bwd_data_impl(dy, w_kkc, n, h, w, dy.shape[1], k, stride, pad_l, pad_t, oh, ow, w_kkc_flipped=w_flip)
+
+
+def _dwconv_wgrad(x, dy, n, h, w, k, stride, pad_l, pad_t, oh, ow, ps, pf):
+    return ops._dwconv_bwd_weight_impl(x, dy, n, h, w, x.shape[1], k, stride, pad_l, pad_t, oh, ow,
+                                       pro=(ps, pf) if ps is not None else None)
+
+
+_GEO = "int n, int h, int w, int k, int stride, int pad_l, int pad_t, int oh, int ow"
+_MODEL_OPS = {
+    "conv1x1": ("(Tensor x, Tensor w, Tensor? bias, Tensor? residual, Tensor? pro_scale, Tensor? pro_shift, Tensor? pro_gate, "
+                "int rows_per_img, bool stats, bool has_pro) -> (Tensor, Tensor)", _conv1x1, _conv1x1_meta),
+    "conv1x1_dgrad": ("(Tensor dy, Tensor w, Tensor? residual, Tensor? w_t) -> Tensor", _conv1x1_dgrad,
+                      lambda dy, w, residual, w_t: dy.new_empty((dy.shape[0], w.shape[1]))),
+    "conv1x1_wgrad": ("(Tensor dy, Tensor x, Tensor? pro_scale, Tensor? pro_shift, Tensor? pro_gate, int rows_per_img, bool has_pro) "
+                      "-> Tensor", _conv1x1_wgrad,
+                      lambda dy, x, ps, pf, pg, rpi, hp: dy.new_empty((dy.shape[1], x.shape[1]), dtype=torch.float32)),
+    "dwconv_bn": (f"(Tensor x, Tensor w_kkc, {_GEO}, Tensor? pro_scale, Tensor? pro_shift, bool stats) -> (Tensor, Tensor)", _dwconv_bn,
+                  lambda x, wk, n, h, w, k, s, pl, pt, oh, ow, ps, pf, st: (
+                      x.new_empty((n * oh * ow, x.shape[1])), x.new_empty((1 if st else 0, 2, x.shape[1]), dtype=torch.float32))),
+    "dwconv_dgrad": (f"(Tensor dy, Tensor w_kkc, {_GEO}, Tensor? w_kkc_flipped) -> Tensor", _dwconv_dgrad,
+                     lambda dy, wk, n, h, w, k, s, pl, pt, oh, ow, wf: dy.new_empty((n * h * w, dy.shape[1]))),
+    "dwconv_wgrad": (f"(Tensor x, Tensor dy, {_GEO}, Tensor? pro_scale, Tensor? pro_shift) -> Tensor", _dwconv_wgrad,
+                     lambda x, dy, n, h, w, k, s, pl, pt, oh, ow, ps, pf: x.new_empty((k * k, x.shape[1]), dtype=torch.float32)),
+}
+for _name, (_schema, _impl, _meta) in _MODEL_OPS.items():
+    _lib.define(_name + _schema)
+    _lib.impl(_name, _impl, "CUDA")
+    _lib.impl(_name, _meta, "Meta")
+
 OPS = ("linear", "linear_dgrad", "linear_wgrad", "dwconv", "dwconv_bwd_data", "dwconv_bwd_weight", "gelu", "gelu_bwd",
-       "softmax", "l2norm", "cross_entropy_")
+       "softmax", "l2norm", "cross_entropy_") + tuple(_MODEL_OPS)

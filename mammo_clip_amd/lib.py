@@ -197,9 +197,10 @@ class OpTimer:
     """Optional per-call HIP-event timing of C-ABI launches on torch's current stream (used by bench.py for the
     live roofline measurement and for per-op breakdowns).  ``only`` restricts timing to a set of entry points."""
 
-    def __init__(self, only=None, kind_contains=None):
+    def __init__(self, only=None, kind_contains=None, keys=None):
         self.only = set(only) if only else None
         self.kind_contains = dict(kind_contains or {})     # entry point -> substring its ``kind`` tag must contain
+        self.keys = set(keys) if keys is not None else None  # exact record keys ("entry" or "entry:kind") to time
         self.records = []            # (name, start_event, end_event, (bytes, flops))
         self.tag = None              # set by ops.* right before a call: algorithmic (bytes, flops) of that launch
 
@@ -220,6 +221,10 @@ TIMER = None
 def call(name: str, *args, kind=None):
     lib = load()
     t = TIMER
+    if t is not None and t.keys is not None:
+        if (name if kind is None else f"{name}:{kind}") not in t.keys:
+            t.tag = None
+            t = None
     if t is not None and (t.only is None or (name in t.only and t.kind_contains.get(name, "") in (kind or ""))):
         import torch
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -377,3 +377,22 @@ def test_model_under_torch_ddp_find_unused_parameters(tmp_path):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, str(script), ROOT, "29889"], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0 and "DDP-OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+@pytest.mark.gpu
+def test_bench_launches_two_ranks_and_prints_one_json_line():
+    """``python bench.py --gpus 2`` end to end on a 1-GPU box: bench.py re-executes itself under torch.distributed.run on
+    127.0.0.1, both ranks share the GPU over gloo (MC_DIST_BACKEND: RCCL refuses two ranks on one device), parameters are
+    broadcast, the fused embedding gather / reduce-scatter and the bucketed gradient mean run with world size 2, and rank 0
+    prints exactly one JSON line with n_gpus = 2 [ref: trainer_ddp.py:53-63,132-134]."""
+    import json
+    env = dict(os.environ, MC_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "cfg1", "--steps", "1",
+                        "--warmup", "1", "--no-cpu-baseline"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout[-2000:], r.stderr[-3000:])
+    js = json.loads(lines[0])
+    assert js["n_gpus"] == 2 and js["steps"] == 1 and js["value"] > 0 and js["config"]["global_batch"] == 8
+    assert js["scaling"] == "weak" and js["roofline"] is not None and "cpu_baseline" not in js

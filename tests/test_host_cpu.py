@@ -224,6 +224,17 @@ def test_custom_ops_registered_with_torch_library():
                                    torch.empty(9, 8, device="meta"), 2, 6, 6, 3, 2, 0, 0, 3, 3)
     assert d.shape == (2 * 3 * 3, 8)
     assert "Tensor? bias=None" in str(torch.ops.mammoclip.linear.default._schema)
+    # the operators the MODEL's 1x1-convolution / depthwise launches go through (ops.linear_fwd & co. are wrappers over them)
+    y, part = torch.ops.mammoclip.conv1x1(x, w, None, None, None, None, None, 0, True, False)
+    assert y.shape == (10, 24) and part.shape[1:] == (2, 24) and part.dtype == torch.float32
+    assert torch.ops.mammoclip.conv1x1_wgrad(y, x, None, None, None, 0, False).shape == (24, x.shape[1])
+    dd, dpart = torch.ops.mammoclip.dwconv_bn(torch.empty(2 * 6 * 6, 8, dtype=torch.bfloat16, device="meta"),
+                                              torch.empty(9, 8, device="meta"), 2, 6, 6, 3, 2, 0, 0, 3, 3, None, None, False)
+    assert dd.shape == (2 * 3 * 3, 8) and dpart.numel() == 0
+    import inspect
+    from mammo_clip_amd import ops
+    for fn in (ops.linear_fwd, ops.linear_dgrad, ops.linear_wgrad, ops.dwconv_fwd, ops.dwconv_bwd_data, ops.dwconv_bwd_weight):
+        assert "torch.ops.mammoclip." in inspect.getsource(fn), fn.__name__
     with pytest.raises(NotImplementedError):
         torch.ops.mammoclip.linear(torch.zeros(4, 8, dtype=torch.bfloat16), torch.zeros(8, 8, dtype=torch.bfloat16))
 

@@ -355,6 +355,9 @@ def test_evaluator_entry_points(tmp_path):
     np.testing.assert_allclose(np.linalg.norm(img, axis=1), 1.0, atol=1e-5)
     p = Evaluator.zeroshot_scores(img, txt)
     assert p.shape == (b, b) and np.allclose(p.sum(1), 1.0)
+    # the device form (l2norm + fp32 GEMM kernels) gives the same scores as the host form
+    pd_ = Evaluator.zeroshot_scores(3.0 * torch.from_numpy(img).to(DEV), 0.5 * torch.from_numpy(txt).to(DEV))
+    np.testing.assert_allclose(pd_, p, rtol=1e-4, atol=1e-6)
     with pytest.raises(TypeError):
         ev.encode_text(["a report"])
     # built from a reference-layout checkpoint [ref: evaluator.py:24-27,52-58] incl. the optimizer state (row N1/N2)
