@@ -153,6 +153,14 @@ def _rows_ok(M, N, K, bias, act):
     return act == 0 and M >= ROWS_MIN_M and L.load().mc_gemm_rows_supported(N, K)
 
 
+def _prefer_tiles(N, K):
+    """plain-operand problems both kernels take: wide outputs over a short reduction (B5 stages 5 / 6: 128 -> 768,
+    176 -> 1056 and their data gradients) run 20-26 % faster on the 256 x 256 tile kernel than as 6-9 column tiles of the
+    row-streaming kernel (173280 x 1056 x 176: 144 vs 181 us, 173280 x 768 x 128: 80 vs 102 us); narrower outputs
+    (693120 x 384 x 64: 152 vs 139 us) and every problem with a fused prologue stay on the row-streaming kernel"""
+    return N >= 512 and K >= 128
+
+
 # Derived weight images (bf16 casts / transposes of fp32 master parameters) are reused until the parameter changes:
 # within one step both image views, the forward and the backward pass need the same image.  Only (views of) leaf
 # tensors are cached; an entry is tied to the owning tensor OBJECT through a weak reference (addresses and ids are
@@ -223,7 +231,8 @@ def _linear_fwd_impl(x, w, bias=None, act=0, residual=None, stats=False, pro=Non
     M, K = x.shape
     N = w.shape[0]
     y = out if out is not None else empty((M, N), BF16, x)
-    if _rows_ok(M, N, K, bias, act) and (pro is None or pro[0] is not None):
+    if _rows_ok(M, N, K, bias, act) and (pro is None or pro[0] is not None) and not (
+            pro is None and bias is None and not tag and _prefer_tiles(N, K)):
         part = empty((L.load().mc_gemm_rows_blocks(M), 2, N), torch.float32, x) if stats else None
         gemm_rows(x, w, y, residual=residual, pro=pro, stat_partials=part, kind="fwd_rows" + tag, bias=bias)
         return (y, part) if stats else y
@@ -263,7 +272,7 @@ def _linear_dgrad_impl(dy, w, residual=None, w_t=None):
     M, N = dy.shape
     K = w.shape[1]
     dx = empty((M, K), BF16, dy)
-    if w_t is not None and _rows_ok(M, K, N, None, 0):
+    if w_t is not None and _rows_ok(M, K, N, None, 0) and not _prefer_tiles(K, N):
         gemm_rows(dy, w_t, dx, residual=residual, kind="dgrad_rows")
         return dx
     if w_t is not None:       # NT form through the transposed weight: both operands k-contiguous (16-byte LDS stores)

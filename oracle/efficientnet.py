@@ -24,6 +24,17 @@ from .arch import Arch, BN_EPS, BN_MOMENTUM
 # support otherwise).
 ROUND = None
 ROUND_DTYPE = torch.bfloat16
+# BASELINE config #5 emulation: {"expand": {block idx}, "project": {block idx}, "head": bool} -- the 1x1 convolutions whose
+# operands the HIP path quantises to per-tensor-scaled OCP e4m3 (mammo_clip_amd ... set_fp8); None = off.
+FP8 = None
+
+
+def _q8(x):
+    """per-tensor-scaled e4m3 quantise / dequantise (scale 448 / amax), the arithmetic of csrc/fp8.hip"""
+    amax = x.detach().abs().max().clamp_min(1e-30)
+    xb = x.to(torch.bfloat16).float()                      # the HIP path quantises the stored bf16 tensor
+    q = (xb * (448.0 / amax)).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).float() * (amax / 448.0)
+    return x + (q - x).detach()
 
 
 def _q(tag, x):
@@ -62,7 +73,10 @@ def mbconv(sd, p: str, x, blk, train: bool, new_buffers=None, taps: Optional[dic
     """MBConvBlock.forward (efficientnet_custom.py:91-132) with drop_connect disabled."""
     inp = x
     if blk.expand != 1:
-        x = _q("E", F.conv2d(x, _q("W", sd[p + "._expand_conv.weight"])))
+        if FP8 is not None and blk.idx in FP8["expand"]:
+            x = _q("E", F.conv2d(_q8(x), _q8(sd[p + "._expand_conv.weight"])))
+        else:
+            x = _q("E", F.conv2d(x, _q("W", sd[p + "._expand_conv.weight"])))
         if taps is not None:
             taps[p + ".expand_out"] = x
         x = swish(_bn(sd, p + "._bn0", x, train, new_buffers))
@@ -75,8 +89,15 @@ def mbconv(sd, p: str, x, blk, train: bool, new_buffers=None, taps: Optional[dic
     sq = F.conv2d(sq, sd[p + "._se_reduce.weight"], sd[p + "._se_reduce.bias"])
     sq = swish(sq)
     sq = F.conv2d(sq, sd[p + "._se_expand.weight"], sd[p + "._se_expand.bias"])
-    x = _q("A1", torch.sigmoid(sq) * x)
-    x = _q("P", F.conv2d(x, _q("W", sd[p + "._project_conv.weight"])))
+    if FP8 is not None and blk.idx in FP8["project"]:
+        # the HIP path folds the SE gate into per-image copies of the weight and quantises (activation, gated weight)
+        gate = torch.sigmoid(sq)
+        wq = torch.stack([_q8((sd[p + "._project_conv.weight"] * gate[i][None]).to(torch.bfloat16).float()) for i in range(x.shape[0])])
+        xq = _q8(x.to(torch.bfloat16).float())
+        x = _q("P", torch.cat([F.conv2d(xq[i:i + 1], wq[i]) for i in range(x.shape[0])]))
+    else:
+        x = _q("A1", torch.sigmoid(sq) * x)
+        x = _q("P", F.conv2d(x, _q("W", sd[p + "._project_conv.weight"])))
     if taps is not None:
         taps[p + ".project_out"] = x
     x = _bn(sd, p + "._bn2", x, train, new_buffers)
@@ -97,7 +118,10 @@ def extract_features(sd, x, arch: Arch, train: bool, prefix: str = "", new_buffe
         x = mbconv(sd, f"{p}_blocks.{blk.idx}", x, blk, train, new_buffers, taps)
         if taps is not None:
             taps[f"block{blk.idx}"] = x
-    x = _q("H", F.conv2d(x, _q("W", sd[p + "_conv_head.weight"])))
+    if FP8 is not None and FP8["head"]:
+        x = _q("H", F.conv2d(_q8(x), _q8(sd[p + "_conv_head.weight"])))
+    else:
+        x = _q("H", F.conv2d(x, _q("W", sd[p + "_conv_head.weight"])))
     x = swish(_bn(sd, p + "_bn1", x, train, new_buffers))
     return x
 

@@ -82,8 +82,9 @@ int main(int argc, char** argv) {
                                 {5415, 176, 1056, 3, 1}, {2048, 768, 3072, 1, 1}, {4096, 4096, 512, 1, 0}, {44544, 3072, 512, 1, 1}};
     std::vector<Shape> shapes = {{8192, 8192, 8192, 1, 0}, {4096, 4096, 4096, 1, 0}, {44544, 1824, 304, 1, 0}, {44544, 304, 1824, 1, 0}, {44544, 3072, 512, 1, 0},
                                  {44544, 512, 3072, 1, 0}, {173280, 176, 1056, 1, 0}, {16384, 2304, 768, 1, 0}, {16384, 3072, 768, 1, 0}, {16384, 768, 3072, 1, 0},
-                                 {1392, 304, 1824, 32, 0}, {5415, 176, 1056, 32, 0}};
-    size_t maxel = (size_t)173280 * 3072;
+                                 {1392, 304, 1824, 32, 0}, {5415, 176, 1056, 32, 0},
+                                 {173280, 1056, 176, 1, 0}, {173280, 768, 128, 1, 0}, {173280, 176, 768, 1, 0}, {173280, 128, 768, 1, 0}, {693120, 384, 64, 1, 0}, {44544, 304, 1056, 1, 0}};
+    size_t maxel = (size_t)693120 * 1024;
     bf16_t *A, *B, *C, *R; float *bias, *stats, *err;
     HC(hipMalloc(&A, maxel * 2)); HC(hipMalloc(&B, maxel * 2)); HC(hipMalloc(&C, maxel * 2)); HC(hipMalloc(&R, maxel * 2));
     HC(hipMalloc(&bias, 65536 * 4)); HC(hipMalloc(&stats, (size_t)64 << 20)); HC(hipMalloc(&err, (size_t)4 << 20));

@@ -1,0 +1,69 @@
+"""Merge one profile_round3.sh run (gpurun_out/prof_r3/) into profiles/: per-kernel table of GPU-time share, HBM traffic
+(PMC) and MFMA-busy for every kernel of a cfg3 step, plus the per-class traffic JSON bench.py reads for `roofline.traffic`.
+usage: python scripts/pmc_table.py [gpurun_out/prof_r3] [profiles] [r03]"""
+import csv
+import json
+import os
+import re
+import sys
+
+src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof_r3"
+dst = sys.argv[2] if len(sys.argv) > 2 else "profiles"
+tag = sys.argv[3] if len(sys.argv) > 3 else "r03"
+
+
+def short(name):
+    name = re.sub(r"^void ", "", name)
+    name = re.sub(r"\(anonymous namespace\)::", "", name)
+    return re.sub(r"\((mc_|float|unsigned|int|long|void|\(anonymous).*$", "", name).strip()
+
+
+stats = list(csv.DictReader(open(os.path.join(src, "cfg3_kernel_stats.csv"))))
+tot = sum(float(r["TotalDurationNs"]) for r in stats)
+pmc = {}
+for grp in ("FETCH_SIZE", "WRITE_SIZE", "SQ_VALU_MFMA_BUSY_CYCLES"):
+    p = os.path.join(src, f"cfg3_pmc_{grp}.csv")
+    if os.path.exists(p):
+        for r in csv.DictReader(open(p)):
+            pmc.setdefault(r["kernel"], {})[r["counter"]] = float(r["avg"])
+rows = []
+for r in stats:
+    k = r["Name"]
+    c = pmc.get(k, {})
+    avg_us = float(r["AverageNs"]) / 1e3
+    rd = 2 * c.get("FETCH_SIZE", 0.0) * 1024 / 1e6          # gfx950: FETCH_SIZE counts 128-B requests as 64 B (MI355X_MICROARCH.md)
+    wr = c.get("WRITE_SIZE", 0.0) * 1024 / 1e6
+    busy = c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (128 * c["GRBM_GUI_ACTIVE"]) if c.get("GRBM_GUI_ACTIVE") else 0.0
+    rows.append((short(k), 100 * float(r["TotalDurationNs"]) / tot, int(r["Calls"]), avg_us, rd, wr, (rd + wr) / avg_us if avg_us else 0, busy))
+os.makedirs(dst, exist_ok=True)
+with open(os.path.join(dst, f"{tag}_cfg3_pmc_by_kernel.csv"), "w") as f:
+    f.write(f'"# one cfg3 step (+1 survey step) of bench.py: rocprofv3 --kernel-trace --stats, and three separate --pmc passes (FETCH_SIZE | WRITE_SIZE | '
+            f'SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES), scripts/profile_round3.sh all; {tag} state"\n')
+    f.write('"# hbm_read_MB = 2 x FETCH_SIZE KiB x 1024 (gfx950 counts 128-B requests of wide streaming reads as 64 B, MI355X_MICROARCH.md); '
+            'hbm_write_MB = WRITE_SIZE KiB x 1024 (as reported); per launch averages"\n')
+    f.write('"# mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (128 x GRBM_GUI_ACTIVE), the MfmaUtil normalisation (1024 SIMDs, counter summed over 8 XCDs)"\n')
+    w = csv.writer(f)
+    w.writerow(["kernel", "share_of_gpu_time_pct", "launches", "avg_us", "hbm_read_MB_per_launch", "hbm_write_MB_per_launch", "hbm_traffic_TB_per_s", "mfma_busy"])
+    for r in rows:
+        w.writerow([r[0], round(r[1], 2), r[2], round(r[3], 1), round(r[4], 1), round(r[5], 1), round(r[6], 2), round(r[7], 3)])
+# bench.py's timing classes whose launches map onto ONE rocprof kernel name: HBM bytes per launch (read + write)
+cls = {"mc_bnact_bwd_apply": "bnact_bwd_k<true>", "mc_gemm_bf16:|glnt256": "g8::gemm8p_kernel", "mc_gemm_bf16:|tn256": "g8t::gemm256_tn_kernel",
+       "mc_gemm_bf16:|glnt": "gemm_kernel<128, 128, 64, 2, 2, 0, 0, false, true>", "mc_bnact_se_sums": "bnact_se_sums_k",
+       "mc_bnact_pool": "bnact_img_reduce_k",
+       # row-streaming 1x1 convolutions: forward and data-gradient launches are the same template family in rocprof's names,
+       # so the two timing classes share ONE figure (launch-weighted average over all gemm_rows_kernel instances)
+       "mc_gemm_rows_bf16:fwd_rows": "gemm_rows_kernel", "mc_gemm_rows_bf16:dgrad_rows": "gemm_rows_kernel",
+       "mc_wgrad_rows_bf16:wgrad_rows": "wgrad_rows_kernel"}
+traffic = {}
+for key, kn in cls.items():
+    sel = [r for r in rows if r[0].startswith(kn)]
+    n = sum(r[2] for r in sel)
+    if n:
+        traffic[key] = int(sum((r[4] + r[5]) * 1e6 * r[2] for r in sel) / n)
+traffic["_note"] = ("HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, rocprofv3 --pmc, separate passes) averaged over the launches of one cfg3 step; "
+                    "source: " + f"profiles/{tag}_cfg3_pmc_by_kernel.csv")
+json.dump(traffic, open(os.path.join(dst, f"{tag}_roofline_traffic.json"), "w"), indent=1)
+for f_ in ("cfg3_kernel_stats.csv", "cfg4_kernel_stats.csv", "agent_info.csv"):
+    if os.path.exists(os.path.join(src, f_)):
+        open(os.path.join(dst, f"{tag}_{f_}"), "w").write(open(os.path.join(src, f_)).read())
+print(open(os.path.join(dst, f"{tag}_cfg3_pmc_by_kernel.csv")).read()[:6000])

@@ -505,7 +505,8 @@ def test_recompute_modes_same_gradients_less_memory():
         for n, g in res[0][2].items():
             assert relerr(res[mode][2][n], g) < 5e-3, (mode, n, relerr(res[mode][2][n], g))
     print("graph bytes held after forward by mode:", {m: res[m][3] for m in res})
-    assert res[1][3] < 0.8 * res[0][3] and res[2][3] < 0.6 * res[0][3] and res[2][3] < res[3][3] < res[1][3], \
+    # (the text encoder's share of the graph is the same in every mode; since round 3 it includes the kept GELU outputs)
+    assert res[1][3] < 0.85 * res[0][3] and res[2][3] < 0.6 * res[0][3] and res[2][3] < res[3][3] < res[1][3], \
         {m: res[m][3] for m in res}
 
 
