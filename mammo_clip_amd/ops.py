@@ -933,7 +933,12 @@ class GradSink:
     def deliver(self, params, grads):
         for p_, g in zip(params, grads):
             if g is not None and p_.requires_grad:
-                self.pending.append((p_, g))
+                # contiguous fp32 storage, kept as a FLAT view: every list handed to _foreach_add_ then has identical
+                # (1-D, unit) strides and one dtype, which is what its multi-tensor fast path requires -- a single
+                # 4-D view with a different size-1 stride sends the whole call down the one-launch-per-tensor path
+                if g.dtype != p_.dtype:
+                    g = g.to(p_.dtype)
+                self.pending.append((p_, g.contiguous().view(-1)))
 
     @torch.no_grad()
     def flush(self):
@@ -943,7 +948,7 @@ class GradSink:
             return
         groups = {}
         for p_, g in self.pending:
-            groups.setdefault(p_, []).append(g if g.dtype == p_.dtype else g.to(p_.dtype))
+            groups.setdefault(p_, []).append(g)
         self.pending = []
         level = 1
         while True:
@@ -967,7 +972,7 @@ class GradSink:
     def finish(self):
         self.flush()
         for p_, a in self.acc.items():
-            a = a.view_as(p_) if a.shape != p_.shape else a
+            a = a.view_as(p_)
             if p_.grad is None:
                 p_.grad = a
             else:
