@@ -169,6 +169,7 @@ def main():
                          "0 = 2 for the global-batch workloads at <= 512 pairs per GPU (2 x 32 pairs = 232 GB of the 288 GB), 1 otherwise")
     ap.add_argument("--recompute", type=int, default=-1, choices=(-1, 0, 1, 2, 3),
                     help="MBConv activation recompute mode (EfficientNet.set_recompute); -1 = chosen with --keep-graphs")
+    ap.add_argument("--keep-kept", type=int, default=6, help="kept mode-2 graphs of the N = 1 / 2 global-batch runs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-n8-load", action="store_true", help="skip the n8_load block of the default N = 1 run")
     ap.add_argument("--fp8", action="store_true", help="fp8 (e4m3) operands for the late-stage 1x1 convolutions (config #5 arithmetic on any workload)")
@@ -219,8 +220,13 @@ def main():
     #   512 pairs/GPU (N = 2): two full graphs (mode 2 with five kept graphs: 6394 ms -- every backward pays the recompute,
     #     eleven micro-batches are still forwarded twice);
     #   1024 pairs/GPU (N = 1): the fp32 input batch itself occupies 34 GB: one kept graph.
+    keep_recompute = None
     if args.keep_graphs <= 0 and args.recompute < 0 and strong and b <= 256:
         args.keep_graphs, args.recompute = args.micro_batches, (3 if b <= 128 else 2)
+    elif args.keep_graphs <= 0 and args.recompute < 0 and strong:
+        # N = 1 / 2 (round 3): SIX kept graphs in recompute mode 2 (28 GB each; their backward pays the rebuild of e and d,
+        # ~32 ms, and saves a ~90 ms forward), the re-forwarded micro-batches stay in mode 0 (Trainer.keep_recompute)
+        args.keep_graphs, keep_recompute = args.keep_kept, 2
     if args.keep_graphs <= 0:
         args.keep_graphs = 2 if (strong and b <= 512) else 1
     util.GlobalEnv.reset()
@@ -231,7 +237,7 @@ def main():
     loss_func = build_loss(LOSS_CFG)
     opt = build_optimizer(model, {"name": "adamw", "config": {"lr": 5e-5, "weight_decay": 1e-4}})
     sched = LinearWarmupCosineAnnealingLR(opt, total_steps=10000, warmup_steps=100)
-    trainer = engine.Trainer(model, loss_func, opt, sched, device, keep_graphs=args.keep_graphs)
+    trainer = engine.Trainer(model, loss_func, opt, sched, device, keep_graphs=args.keep_graphs, keep_recompute=keep_recompute)
     batch = synth_batch_gpu(b, H, W, T, device, seed=10 + rank)
 
     def sync():
@@ -279,7 +285,7 @@ def main():
         trainer.optimizer.zero_grad(set_to_none=True)
         torch.cuda.empty_cache()
         model.image_encoder.set_recompute(3)
-        trainer.keep_graphs = 4
+        trainer.keep_graphs, trainer.keep_recompute = 4, None
         b8 = synth_batch_gpu(128, H, W, T, device, seed=99)
         trainer.step(b8, 4)
         torch.cuda.synchronize()
@@ -328,7 +334,7 @@ def main():
                                    f"AdamW; fwd+loss+bwd+optimizer; dropout/drop-connect on",
                        "global_batch": b * world, "parallelism": f"dp{world}" + (f" x {args.micro_batches} micro-batches" if args.micro_batches > 1 else ""),
                        "loss": round(loss_val, 5), "peak_hbm_gb": round(peak_gb, 1),
-                       "keep_graphs": args.keep_graphs, "recompute": args.recompute},
+                       "keep_graphs": args.keep_graphs, "recompute": args.recompute, "keep_recompute": keep_recompute},
             "roofline": first, "roofline_runner_up": second, "roofline_third": third,
         }
         if n8 is not None:

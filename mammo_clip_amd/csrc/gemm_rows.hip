@@ -29,6 +29,8 @@ __global__ __launch_bounds__(256, 2) void gemm_rows_kernel(const mc_gemm_rows_ar
     float* sScale = reinterpret_cast<float*>(sW + KC * FN * 1024);  // [KC*32]
     float* sShift = sScale + KC * 32;
     unsigned char* sC = reinterpret_cast<unsigned char*>(sShift + KC * 32);   // [4 waves][16][CROW]
+    constexpr int SC_BYTES = (4 * 16 * CROW > 4 * 64 * 16 * 4) ? 4 * 16 * CROW : 4 * 64 * 16 * 4;
+    float* sGate = reinterpret_cast<float*>(sC + SC_BYTES);                   // [4 waves][2 images][KC*32]: SE gate rows
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // Wide outputs (N > 256, K small) are split into column tiles of FN*16: every tile's workgroup keeps ITS slice of
     // the weights in LDS and streams the same rows.  The column tiles of one row-block index get consecutive slots on
@@ -59,7 +61,33 @@ __global__ __launch_bounds__(256, 2) void gemm_rows_kernel(const mc_gemm_rows_ar
     unsigned char* myC = sC + wave * 16 * CROW;
     const int mrow = lane & 15, kg = lane >> 4;
     const long long ngroups = (p.M + RG * 16 - 1) / (RG * 16);
-    const long long gstride = (long long)nblocks * 4;
+    // Work assignment.  Plain / BN+SiLU forms: cyclic by single 32-row groups -- the chip sweeps the tensor as one moving
+    // window (best HBM rate: 8192 independent contiguous streams cost the plain form 8-16 %).  Gated form (per-image SE
+    // gate in the prologue, round 3): every wave takes ONE contiguous range, so the image it works in changes once per
+    // rows_per_img rows and the gate row lives in a small per-wave LDS cache (this image + the next) instead of being
+    // fetched from global memory for every 16-byte chunk of every row -- those two extra vector-memory instructions per
+    // activation load were the whole cost of the gated form (2.77 M x 40 x 240: 0.50 -> 0.40 ms, block-cyclic by 4: 0.44).
+    const long long nwaves = (long long)nblocks * 4;
+    const bool cyc = p.pro_gate == nullptr;
+    const long long wid = (long long)bxr * 4 + wave;
+    const long long gpw = (ngroups + nwaves - 1) / nwaves;
+    const long long my_end = (wid + 1) * gpw < ngroups ? (wid + 1) * gpw : ngroups;       // contiguous form: this wave's range end
+    auto gnext = [&](long long g) { return cyc ? g + nwaves : (g + 1 < my_end ? g + 1 : ngroups); };
+    float* myG = sGate + wave * 2 * KC * 32;
+    long long g_img = -1, g_end = 0;                        // image whose gate row sits in slot 0, first row of the next image
+    auto gate_cache = [&](long long mbase) {
+        if (mbase < g_end && g_img >= 0) return;
+        g_img = mbase / p.pro_rows_per_img;
+        g_end = (g_img + 1) * p.pro_rows_per_img;
+        const long long last = (p.M - 1) / p.pro_rows_per_img;
+        __builtin_amdgcn_wave_barrier();
+        for (int k = lane; k < 2 * KC * 32; k += 64) {
+            const int sl = k >= KC * 32, kk = k - sl * KC * 32;
+            const long long im = g_img + sl <= last ? g_img + sl : last;
+            myG[k] = kk < p.K ? p.pro_gate[im * p.K + kk] : 0.f;
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
     // epilogue mapping: lane = (row slot, 16-byte column chunk); a lane always handles the same 8 output columns, so
     // the BatchNorm statistics of the stored tensor accumulate in 16 registers inside the store loop
     const int cpr = nw >> 3;                        // 16-byte chunks per output row of this tile (<= 32)
@@ -93,7 +121,11 @@ __global__ __launch_bounds__(256, 2) void gemm_rows_kernel(const mc_gemm_rows_ar
             for (int rg = 0; rg < RG; ++rg) {
                 long long m = (g * RG + rg) * 16 + mrow;
                 if (m >= p.M) m = p.M - 1;
-                const float* gate = p.pro_gate ? p.pro_gate + (m / p.pro_rows_per_img) * p.K : nullptr;
+                const float* gate = nullptr;
+                if (p.pro_gate) {
+                    gate_cache((g * RG + rg) * 16 < p.M ? (g * RG + rg) * 16 : p.M - 1);
+                    gate = myG + (m >= g_end ? KC * 32 : 0);
+                }
 #pragma unroll
                 for (int kc = 0; kc < KC; ++kc) {
                     int k = kc * 32 + kg * 8;
@@ -174,21 +206,28 @@ __global__ __launch_bounds__(256, 2) void gemm_rows_kernel(const mc_gemm_rows_ar
         }
     };
 
-    const long long g0 = (long long)bxr * 4 + wave;
+    long long gq[PF];                                       // the groups in flight, oldest first (static indices)
+    gq[0] = cyc ? wid : (wid * gpw < ngroups ? wid * gpw : ngroups);
+#pragma unroll
+    for (int u = 1; u < PF; ++u) gq[u] = gnext(gq[u - 1]);
 #pragma unroll
     for (int u = 0; u < PF; ++u)
-        if (g0 + u * gstride < ngroups) load_group(xn[u], g0 + u * gstride);
-    for (long long g = g0; g < ngroups; g += PF * gstride) {
+        if (gq[u] < ngroups) load_group(xn[u], gq[u]);
+    while (gq[0] < ngroups) {
 #pragma unroll
         for (int u = 0; u < PF; ++u) {
-            const long long gg = g + u * gstride;
+            const long long gg = gq[u];
             if (gg < ngroups) {
                 uint4 xf[RG][KC];
 #pragma unroll
                 for (int rg = 0; rg < RG; ++rg)
 #pragma unroll
                     for (int kc = 0; kc < KC; ++kc) xf[rg][kc] = xn[u][rg][kc];
-                if (gg + PF * gstride < ngroups) load_group(xn[u], gg + PF * gstride);   // in flight during PF groups of work
+                long long gn = gg;
+#pragma unroll
+                for (int t = 0; t < PF; ++t) gn = gnext(gn);
+                gq[u] = gn;
+                if (gn < ngroups) load_group(xn[u], gn);   // in flight during PF groups of work
                 process(gg, xf);
             }
         }
@@ -226,9 +265,11 @@ template <int FN, int KC> size_t lds_bytes() {
 template <int FN, int KC> int launch_rows(const mc_gemm_rows_args& p, int blocks, hipStream_t st) {
     constexpr int RG = (FN >= 6 || KC >= 12) ? 1 : 2;   // wide outputs / deep K: 16 rows per iteration (register budget)
     constexpr int PF = KC >= 12 ? 1 : (KC >= 6 ? (RG == 1 ? 2 : 1) : 8 / KC);   // ~8-16 KB of activations in flight per wave
-    size_t lds = lds_bytes<FN, KC>();
+    size_t lds = lds_bytes<FN, KC>() + (p.pro_gate ? (size_t)4 * 2 * KC * 32 * 4 : 0);     // + per-wave SE gate cache
     static unsigned long long attr_done = 0;
-    if (lds > 64 * 1024) MC_SET_MAX_LDS(attr_done, (&gemm_rows_kernel<FN, KC, PF, RG>), lds);
+    const void* kfn = reinterpret_cast<const void*>(&gemm_rows_kernel<FN, KC, PF, RG>);
+    const size_t lds_max = lds_bytes<FN, KC>() + (size_t)4 * 2 * KC * 32 * 4;
+    if (lds > 64 * 1024) MC_SET_MAX_LDS(attr_done, kfn, lds_max);
     const int ntiles = (p.N + FN * 16 - 1) / (FN * 16);
     hipLaunchKernelGGL((gemm_rows_kernel<FN, KC, PF, RG>), dim3((blocks + 7) / 8 * 8 * ntiles), dim3(256), lds, st, p, blocks, ntiles);
     MC_LAUNCH_CHECK();
@@ -278,7 +319,7 @@ extern "C" int mc_gemm_rows_bf16(const mc_gemm_rows_args* a, void* stream) {
     MC_CHECK(mc_aligned16(p.X) && mc_aligned16(p.W) && mc_aligned16(p.C), "gemm_rows: operands must be 16-byte aligned");
     MC_CHECK(!p.R || (p.ldr % 8 == 0 && mc_aligned16(p.R)), "gemm_rows: bad residual");
     MC_CHECK((p.pro_scale == nullptr) == (p.pro_shift == nullptr), "gemm_rows: prologue needs scale and shift");
-    MC_CHECK(!p.pro_gate || (p.pro_scale && p.pro_rows_per_img > 0), "gemm_rows: gate needs the BN prologue");
+    MC_CHECK(!p.pro_gate || (p.pro_scale && p.pro_rows_per_img >= 16), "gemm_rows: gate needs the BN prologue and >= 16 rows per image");
     hipStream_t st = (hipStream_t)stream;
     int blocks = mc_gemm_rows_blocks(p.M);
     if (p.N > 256) return dispatch_kc<8>(p, blocks, st);   // wide output: 128-column tiles

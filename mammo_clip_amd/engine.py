@@ -116,7 +116,7 @@ class GradBuckets:
 
 class Trainer:
     def __init__(self, model, loss_func, optimizer, scheduler=None, device=None, bucket_mb: int = 256,
-                 overlap_micro: bool = False, keep_graphs: int = 1, grad_sink: bool = True):
+                 overlap_micro: bool = False, keep_graphs: int = 1, grad_sink: bool = True, keep_recompute: Optional[int] = None):
         self.model, self.loss_func, self.optimizer, self.scheduler = model, loss_func, optimizer, scheduler
         self.device = device
         # Gradient reduction: by default the flat buckets are all-reduced AFTER the last backward (reduce_all) -- the whole
@@ -126,6 +126,10 @@ class Trainer:
         self.grad_sink = bool(grad_sink)        # parameter gradients combined by multi-tensor adds (ops.GradSink)
         self.overlap_micro = bool(overlap_micro) and not self.grad_sink
         self.keep_graphs = max(1, int(keep_graphs))   # micro-batched step: micro-batches forwarded once, graph kept
+        # MBConv recompute mode for the KEPT graphs only (EfficientNet.set_recompute): a kept graph in mode 2 is 28 GB instead
+        # of 100 GB, so more of them fit; the re-forwarded micro-batches (graph alive for one forward + backward only) keep
+        # the model's own mode.  None = the model's mode everywhere.
+        self.keep_recompute = keep_recompute
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self.buckets = GradBuckets(list(model.parameters()), bucket_mb << 20) if self.world > 1 else None
         if self.world > 1:
@@ -234,9 +238,19 @@ def _step_micro(self, batch: Dict, k: int) -> Dict[str, torch.Tensor]:
     # and never forwarded again (k - keep extra forwards per step instead of k: at 4 micro-batches per GPU and keep = 1
     # that is 6 % of the step; keep = 2 needs the activations of two micro-batches, ~230 GB at 32 pairs each)
     lives = []
-    for mb in mbs[k - keep:]:
-        out = model(mb, self.device)
-        lives.append({kk: out[kk] for kk in keys if kk in out})
+    enc = getattr(model, "image_encoder", None)
+    base_modes = None
+    if self.keep_recompute is not None and parts and hasattr(enc, "set_recompute"):
+        base_modes = [blk.recompute for blk in enc._blocks]
+        enc.set_recompute(self.keep_recompute)
+    try:
+        for mb in mbs[k - keep:]:
+            out = model(mb, self.device)
+            lives.append({kk: out[kk] for kk in keys if kk in out})
+    finally:
+        if base_modes is not None:                 # (the mode is read at forward time and travels with each graph)
+            for blk, m_ in zip(enc._blocks, base_modes):
+                blk.recompute = m_
     after = (irng.calls, trng._calls)
     leaf = {kk: torch.cat([p_[kk] for p_ in parts]).detach().requires_grad_(True) for kk in lives[0]} if parts else {}
     full = {kk: torch.cat(([leaf[kk]] if parts else []) + [lv[kk] for lv in lives]) for kk in lives[0]}
