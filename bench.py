@@ -82,10 +82,12 @@ KERNEL_NAMES = {
 def kernel_name(key):
     """entry point ':' class tags -> kernel description; for the plain-operand GEMM entry point the class tag names the
     kernel, and forward / data-gradient calls of one kernel are one class (class_key)"""
+    side = {"mfma": " -- launches whose shape is MFMA-bound (flop/byte >= 312)", "hbm": " -- launches whose shape is HBM-bound (flop/byte < 312)"}
     for k, v in KERNEL_NAMES.items():
         ep, _, tag = k.partition("|")
-        if key.split(":")[0] == ep and (not tag or key.endswith("|" + tag)):
-            return v + (" [" + key + "]" if ":" in key else "")
+        base = key[:-5] if key.endswith("|mfma") else (key[:-4] if key.endswith("|hbm") else key)
+        if key.split(":")[0] == ep and (not tag or base.endswith("|" + tag)):
+            return v + side.get(key.rsplit("|", 1)[-1], "") + (" [" + key + "]" if ":" in key else "")
     return key
 
 
@@ -93,8 +95,9 @@ def class_key(key):
     """merge the timer's record keys into kernel classes: 'mc_gemm_bf16:fwd|glnt256' and ':dgrad|glnt256' -> one class"""
     ep, _, kind = key.partition(":")
     for tag in ("glnt256", "glnt", "tn256"):
-        if ep == "mc_gemm_bf16" and kind.endswith("|" + tag):
-            return f"{ep}:|{tag}"
+        for side in ("mfma", "hbm"):
+            if ep == "mc_gemm_bf16" and kind.endswith(f"|{tag}|{side}"):
+                return f"{ep}:|{tag}|{side}"
     return key
 
 
@@ -309,15 +312,16 @@ def main():
 
         def entry(key):
             cnt, t_ms, by, fl = summ.get(key, (0, 0.0, 0, 0))
-            # the MFMA tile kernels are priced against the MFMA peak whatever their shape mix (north_star's target is stated
-            # for them; their aggregate intensity sits right at the ridge, 300 vs 312 flop/byte); the rest by intensity
-            mfma = any(key.endswith("|" + t) for t in ("glnt256", "glnt", "tn256")) or (by > 0 and fl / by >= RIDGE)
+            # the tile-GEMM classes are split per launch by the roofline that bounds the launch's shape (ops.gemm tags them);
+            # every other class by its aggregate intensity
+            mfma = key.endswith("|mfma") or (not key.endswith("|hbm") and by > 0 and fl / by >= RIDGE)
             if mfma:
                 ach, peak, unit = (fl / (t_ms * 1e-3) / 1e12 if t_ms > 0 else 0.0), MFMA_PEAK_TFS, "TFLOP/s"
             else:
                 ach, peak, unit = (by / (t_ms * 1e-3) / 1e9 if t_ms > 0 else 0.0), HBM_PEAK_GBS, "GB/s"
+            tkey = key[:-5] if key.endswith("|mfma") else (key[:-4] if key.endswith("|hbm") else key)
             return {"bound": "mfma" if mfma else "hbm", "achieved": round(ach, 1), "peak": peak, "unit": unit,
-                    "frac": round(ach / peak, 4), "traffic": tj.get(key), "kernel": kernel_name(key), "launches": cnt,
+                    "frac": round(ach / peak, 4), "traffic": tj.get(key, tj.get(tkey)), "kernel": kernel_name(key), "launches": cnt,
                     "avg_launch_us": round(t_ms / max(cnt, 1) * 1e3, 1), "algorithmic_bytes_per_launch": int(by / max(cnt, 1)),
                     "algorithmic_flops_per_launch": int(fl / max(cnt, 1)), "gpu_ms_in_timed_steps": round(t_ms, 1),
                     "share_of_gpu_time_in_survey_step": round(ssum[key][1] / max(sum(v[1] for v in ssum.values()), 1e-9), 4),

@@ -74,11 +74,15 @@ def gemm(A, B, C_out, M, N, K, lda, ldb, ldc, a_kmajor=0, b_kmajor=0, c_f32=0, c
           2 * batch * M * N * K)
     if L.TIMER is not None and pro is None:
         # timing classes = the kernel that serves the launch: plain NT tiles (256 x 256 gemm8p_kernel or the 128 x 128
-        # direct-to-LDS gemm_kernel), TN weight-gradient tiles (gemm256_tn_kernel)
+        # direct-to-LDS gemm_kernel), TN weight-gradient tiles (gemm256_tn_kernel) -- each split by the roofline that bounds
+        # THIS launch's shape: arithmetic intensity against the 2.5 PFLOP/s : 8 TB/s ridge (SURVEY.md section 8d asks for the
+        # MFMA fraction of the MFMA-bound GEMMs and the HBM fraction of the bandwidth-bound ones separately)
+        nbytes = batch * (es * M * K + es * N * K + (4 if c_f32 else 2) * M * N + (2 * M * N if R is not None else 0))
+        side = "mfma" if 2.0 * batch * M * N * K >= 312.5 * nbytes else "hbm"
         if not a_kmajor and not b_kmajor and N > 64 and K > 48 and not c_f32:
-            kind = (kind or "") + ("|glnt256" if L.load().mc_gemm_tile_config(C.byref(a)) == 256 else "|glnt")
+            kind = (kind or "") + ("|glnt256" if L.load().mc_gemm_tile_config(C.byref(a)) == 256 else "|glnt") + "|" + side
         elif a_kmajor and b_kmajor and c_f32 and L.load().mc_gemm256_tn_eligible(C.byref(a)):
-            kind = "wgrad|tn256"
+            kind = "wgrad|tn256|" + side
     L.call("mc_gemm_bf16", C.byref(a), _st(), kind=kind)
     return stat_partials
 
