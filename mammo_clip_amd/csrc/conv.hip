@@ -946,8 +946,9 @@ template <int K, int CPL, int LP, int NJ> int launch_march_bwd_s2(const mc_dwcon
     const int seg_rows = mc_div_up(mc_div_up(ohv, segs), C::RB) * C::RB;
     segs = mc_div_up(ohv, seg_rows);
     long long nitems = (long long)p.n * strips * segs;
-    long long cap = 512 / ctiles;
-    if (cap < 8) cap = 8;
+    long long per_xcd = 64 / ctiles;                            // 2 workgroups per CU, capped per XCD (see march_plan)
+    if (per_xcd < 1) per_xcd = 1;
+    long long cap = 8 * per_xcd;
     long long per = (nitems + cap - 1) / cap;
     const int gy = (int)((nitems + per - 1) / per);
     const int gy8 = (gy + 7) / 8 * 8;
@@ -971,8 +972,14 @@ template <typename C> MarchPlan march_plan(const mc_dwconv_args& p) {
     m.segs = mc_div_up(p.oh, m.seg_rows);
     // persistent workgroups: as many as are resident at once, every one with the same item count
     long long nitems = (long long)p.n * m.strips * m.segs;
-    long long cap = 256 * (p.epi_x ? 2 : C::OCC) / m.ctiles;      // (the epilogue variant is built for 2 workgroups per CU)
-    if (cap < 8) cap = 8;
+    // Block b runs on XCD b % 8 and the kernel maps (b >> 3) -> (channel tile, y / 8): an XCD receives ceil(gy / 8) * ctiles
+    // workgroups and holds 32 CUs x OCC of them.  The y count is capped PER XCD (round 3): the chip-wide cap 256 * OCC /
+    // ctiles put 68 workgroups on the 64 slots of XCDs 0-3 at c = 1056 (17 channel tiles, gy = 28): four stragglers ran a
+    // second round and the launch took 1.9x the time of the c = 768 launch for 1.4x the work.
+    const long long occ = p.epi_x ? 2 : C::OCC;                   // (the epilogue variant is built for 2 workgroups per CU)
+    long long per_xcd = 32 * occ / m.ctiles;
+    if (per_xcd < 1) per_xcd = 1;
+    long long cap = 8 * per_xcd;
     long long per = (nitems + cap - 1) / cap;
     m.gy = (int)((nitems + per - 1) / per);
     return m;
@@ -1011,9 +1018,10 @@ template <int K, int S> int launch_march_cp(const mc_dwconv_args& p, hipStream_t
 }
 template <int K, int S, typename C> int launch_march_bww(const mc_dwconv_args& p, hipStream_t st) {
     MarchPlan m = march_plan<C>(p);
-    long long nitems = (long long)p.n * m.strips * m.segs;      // 2 workgroups per CU here
-    long long cap = 512 / m.ctiles;
-    if (cap < 8) cap = 8;
+    long long nitems = (long long)p.n * m.strips * m.segs;      // 2 workgroups per CU here; capped per XCD (see march_plan)
+    long long per_xcd = 64 / m.ctiles;
+    if (per_xcd < 1) per_xcd = 1;
+    long long cap = 8 * per_xcd;
     long long per = (nitems + cap - 1) / cap;
     m.gy = (int)((nitems + per - 1) / per);
     int gy8 = (m.gy + 7) / 8 * 8;

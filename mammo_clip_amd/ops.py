@@ -876,14 +876,14 @@ def linear_fwd(x, w, bias=None, act=0, residual=None, stats=False, pro=None, out
         _chk_dev(x, w)
         return _linear_fwd_impl(x, w, bias, act, residual, stats, pro, out, tag)
     ps, pf, pg, rpi = pro if pro is not None else (None, None, None, 0)
-    y, part = torch.ops.mammoclip.conv1x1(x, w, bias, residual, ps, pf, pg, int(rpi), bool(stats), pro is not None)
+    y, part = _OP_CONV1X1(x, w, bias, residual, ps, pf, pg, int(rpi), bool(stats), pro is not None)
     return (y, part) if stats else y
 
 
 def linear_dgrad(dy, w, residual=None, w_t=None):
     if not dy.is_cuda:
         _chk_dev(dy, w)
-    return torch.ops.mammoclip.conv1x1_dgrad(dy, w, residual, w_t)
+    return _OP_CONV1X1_DGRAD(dy, w, residual, w_t)
 
 
 def linear_wgrad(dy, x, pro=None, out=None, tag=""):
@@ -891,7 +891,7 @@ def linear_wgrad(dy, x, pro=None, out=None, tag=""):
         _chk_dev(dy, x)
         return _linear_wgrad_impl(dy, x, pro, out, tag)
     ps, pf, pg, rpi = pro if pro is not None else (None, None, None, 0)
-    return torch.ops.mammoclip.conv1x1_wgrad(dy, x, ps, pf, pg, int(rpi), pro is not None)
+    return _OP_CONV1X1_WGRAD(dy, x, ps, pf, pg, int(rpi), pro is not None)
 
 
 def dwconv_fwd(x, w_kkc, n, h, w, c, k, stride, pad_l, pad_t, oh, ow, pro=None, stats=False, epi=None):
@@ -899,7 +899,7 @@ def dwconv_fwd(x, w_kkc, n, h, w, c, k, stride, pad_l, pad_t, oh, ow, pro=None, 
         _chk_dev(x, w_kkc)
         return _dwconv_fwd_impl(x, w_kkc, n, h, w, c, k, stride, pad_l, pad_t, oh, ow, pro, stats, epi)
     ps, pf = pro if pro is not None else (None, None)
-    y, part = torch.ops.mammoclip.dwconv_bn(x, w_kkc, n, h, w, k, stride, pad_l, pad_t, oh, ow, ps, pf, bool(stats))
+    y, part = _OP_DWCONV_BN(x, w_kkc, n, h, w, k, stride, pad_l, pad_t, oh, ow, ps, pf, bool(stats))
     return (y, part) if stats else y
 
 
@@ -907,14 +907,14 @@ def dwconv_bwd_data(dy, w_kkc, n, h, w, c, k, stride, pad_l, pad_t, oh, ow, w_kk
     if epi is not None or not dy.is_cuda:
         _chk_dev(dy, w_kkc)
         return _dwconv_bwd_data_impl(dy, w_kkc, n, h, w, c, k, stride, pad_l, pad_t, oh, ow, w_kkc_flipped, epi)
-    return torch.ops.mammoclip.dwconv_dgrad(dy, w_kkc, n, h, w, k, stride, pad_l, pad_t, oh, ow, w_kkc_flipped)
+    return _OP_DWCONV_DGRAD(dy, w_kkc, n, h, w, k, stride, pad_l, pad_t, oh, ow, w_kkc_flipped)
 
 
 def dwconv_bwd_weight(x, dy, n, h, w, c, k, stride, pad_l, pad_t, oh, ow, pro=None):
     if not x.is_cuda:
         _chk_dev(x, dy)
     ps, pf = pro if pro is not None else (None, None)
-    return torch.ops.mammoclip.dwconv_wgrad(x, dy, n, h, w, k, stride, pad_l, pad_t, oh, ow, ps, pf)
+    return _OP_DWCONV_WGRAD(x, dy, n, h, w, k, stride, pad_l, pad_t, oh, ow, ps, pf)
 
 
 # ------------------------------------------------------------------------------------------- gradient sink
@@ -997,3 +997,12 @@ def deliver_param_grads(params, grads):
 
 
 from . import custom_ops  # noqa: E402,F401  (registers torch.ops.mammoclip.*; imported last: it binds the implementations above)
+
+# the overloads the wrappers above call (torch.ops.mammoclip.<name>.default, resolved once: two attribute look-ups and the
+# overload resolution per call are host time the launch-bound configurations notice)
+_OP_CONV1X1 = torch.ops.mammoclip.conv1x1.default
+_OP_CONV1X1_DGRAD = torch.ops.mammoclip.conv1x1_dgrad.default
+_OP_CONV1X1_WGRAD = torch.ops.mammoclip.conv1x1_wgrad.default
+_OP_DWCONV_BN = torch.ops.mammoclip.dwconv_bn.default
+_OP_DWCONV_DGRAD = torch.ops.mammoclip.dwconv_dgrad.default
+_OP_DWCONV_WGRAD = torch.ops.mammoclip.dwconv_wgrad.default

@@ -234,7 +234,8 @@ def test_custom_ops_registered_with_torch_library():
     import inspect
     from mammo_clip_amd import ops
     for fn in (ops.linear_fwd, ops.linear_dgrad, ops.linear_wgrad, ops.dwconv_fwd, ops.dwconv_bwd_data, ops.dwconv_bwd_weight):
-        assert "torch.ops.mammoclip." in inspect.getsource(fn), fn.__name__
+        assert "_OP_" in inspect.getsource(fn), fn.__name__          # = torch.ops.mammoclip.<name>.default, bound at import
+    assert ops._OP_CONV1X1 is torch.ops.mammoclip.conv1x1.default and ops._OP_DWCONV_BN is torch.ops.mammoclip.dwconv_bn.default
     with pytest.raises(NotImplementedError):
         torch.ops.mammoclip.linear(torch.zeros(4, 8, dtype=torch.bfloat16), torch.zeros(8, 8, dtype=torch.bfloat16))
 
