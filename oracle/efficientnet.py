@@ -37,9 +37,18 @@ def _q8(x):
     return x + (q - x).detach()
 
 
+ROUND_SR = None     # torch.Generator: STOCHASTIC rounding to bf16 instead of round-to-nearest (independent draws of the same noise)
+
+
 def _q(tag, x):
     if ROUND is None or tag not in ROUND:
         return x
+    if ROUND_SR is not None and ROUND_DTYPE == torch.bfloat16 and x.dtype == torch.float32:
+        # unbiased random rounding: add uniform noise below the bf16 ulp, truncate the low 16 bits
+        bits = x.detach().contiguous().view(torch.int32)
+        noise = torch.randint(0, 1 << 16, bits.shape, generator=ROUND_SR, device=bits.device, dtype=torch.int32)
+        r = ((bits + noise) & -65536).view(torch.float32)
+        return x + (r - x).detach()
     return x + (x.to(ROUND_DTYPE).to(x.dtype) - x).detach()
 
 
