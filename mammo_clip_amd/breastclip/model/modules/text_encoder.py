@@ -13,6 +13,7 @@ from typing import Dict
 
 import torch
 from torch import nn
+import torch.nn.functional as F
 
 from .... import ops
 
@@ -271,7 +272,17 @@ class BertModelHIP(nn.Module):
     def forward(self, input_ids=None, attention_mask=None, token_type_ids=None, **_):
         if not input_ids.is_cuda:
             raise RuntimeError("mammo_clip_amd.BertModelHIP runs only on a HIP device (no CPU fallback)")
-        b, t = input_ids.shape
+        b, t0 = input_ids.shape
+        t = t0
+        if t % 8:
+            # the GEMM / softmax kernels want rows of 16 bytes: pad the sequences with masked [PAD] tokens (they are never
+            # attended to, their own outputs are dropped below and carry no gradient) -- any report length is accepted,
+            # like the reference's BertModel [ref: text_encoder.py:47-49]
+            padn = 8 - t % 8
+            input_ids = F.pad(input_ids, (0, padn))
+            attention_mask = F.pad(attention_mask if attention_mask is not None else torch.ones((b, t0), dtype=input_ids.dtype, device=input_ids.device), (0, padn))
+            token_type_ids = F.pad(token_type_ids, (0, padn)) if token_type_ids is not None else None
+            t += padn
         self._calls += 1
         seed = self.rng_seed * 1000003 + self._calls
         cfg = self.config
@@ -285,7 +296,8 @@ class BertModelHIP(nn.Module):
         maskb = ops.mask_bias(mask)
         for lyr in self.encoder.layer:
             x = lyr(x, maskb, b, t, seed)
-        return {"last_hidden_state": x.view(b, t, cfg.hidden_size)}
+        x = x.view(b, t, cfg.hidden_size)
+        return {"last_hidden_state": x if t == t0 else x[:, :t0].contiguous()}
 
 
 class HuggingfaceTextEncoder(nn.Module):

@@ -14,6 +14,18 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, float seed) {
             if (MODE == 0) a[i] = __builtin_fmaf(a[i], seed, 1.0f);
             if (MODE == 1) a2[i] = __builtin_elementwise_fma(a2[i], b2, b2);
             if (MODE == 2) asm volatile("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(a[i]) : "v"(w), "v"(w + i));
+            if (MODE == 4) asm volatile("v_exp_f32 %0, %0" : "+v"(a[i]));
+            if (MODE == 5) asm volatile("v_rcp_f32 %0, %0" : "+v"(a[i]));
+            if (MODE == 6) asm volatile("v_lshlrev_b32 %0, 16, %0" : "+v"(a[i]));
+            if (MODE == 7) asm volatile("v_and_b32 %0, 0xffff0000, %0" : "+v"(a[i]));
+            if (MODE == 8) asm volatile("v_cvt_pk_bf16_f32 %0, %0, %1" : "+v"(a[i]) : "v"(seed));
+            if (MODE == 9) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a[i]) : "v"(seed));
+            if (MODE == 10) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(a2[i]) : "v"(b2));
+            if (MODE == 11) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(a2[i]) : "v"(b2));
+            if (MODE == 12) asm volatile("v_add_f32 %0, %0, %1" : "+v"(a[i]) : "v"(seed));
+            if (MODE == 13) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(a2[i]) : "v"(a2[(i + 5) & 15]), "v"(b2));
+            if (MODE == 14) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(a[i]) : "v"(a[(i + 5) & 15]), "v"(seed));
+            if (MODE == 15) asm volatile("v_mov_b32 %0, %1" : "+v"(a[i]) : "v"(a[(i + 5) & 15]));
 #if defined(TRY_DOT2)
             if (MODE == 3) a[i] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, w), __builtin_bit_cast(bf2, w + i), a[i], false);
 #endif
@@ -37,6 +49,9 @@ template <int MODE> void run(const char* name, float* d, int perinst) {
 int main() {
     float* d; hipMalloc(&d, 256 * 8 * 256 * 4);
     run<0>("v_fma_f32", d, 1); run<1>("v_pk_fma_f32", d, 2); run<2>("v_dot2c_f32_bf16", d, 2);
+    run<4>("v_exp_f32", d, 1); run<5>("v_rcp_f32", d, 1); run<6>("v_lshlrev_b32", d, 1); run<7>("v_and_b32 lit", d, 1);
+    run<8>("v_cvt_pk_bf16_f32", d, 1); run<9>("v_mul_f32", d, 1); run<10>("v_pk_mul_f32", d, 2); run<11>("v_pk_add_f32", d, 2);
+    run<12>("v_add_f32", d, 1); run<13>("v_pk_fma 3 distinct", d, 2); run<14>("v_fma 3 distinct", d, 1); run<15>("v_mov_b32", d, 1);
 #if defined(TRY_DOT2)
     run<3>("v_dot2_f32_bf16", d, 2);
 #endif
