@@ -41,6 +41,24 @@ struct RowMap {
     }
 };
 
+// Column sums of the [rpb][O = cvp*8] matrix the row-lanes of a workgroup left in red[] (red[thread*8 + q], thread =
+// rl*cvp + cl).  Narrow tensors have many row-lanes (24 channels: 85) and the single-thread loop over them was 15-30 % of
+// the kernel: here thread t < O*P sums the rows part, part+P, ... of column o = t % O (P = 256 / O) and the P partials are
+// combined in part order -- deterministic.  Used when rpb >= 8 (then O <= 256).  Returns column t's sum for t < O.
+__device__ inline float rowlane_colsum(const float* red, float* tmp, int cvp, int rpb) {
+    const int O = cvp * 8, P = 256 / O, t = threadIdx.x;
+    const int o = t % O, part = t / O;
+    float s = 0.f;
+    if (part < P)
+        for (int r = part; r < rpb; r += P) s += red[r * O + o];
+    tmp[t] = s;
+    __syncthreads();
+    float tot = 0.f;
+    if (t < O)
+        for (int k = 0; k < P; ++k) tot += tmp[k * O + t];
+    return tot;
+}
+
 __global__ void bn_finalize_k(const float* __restrict__ partials, int rows, int c, double count,
                               const float* __restrict__ gamma, const float* __restrict__ beta,
                               float* __restrict__ rmean, float* __restrict__ rvar, float momentum, float eps,
@@ -129,6 +147,7 @@ template <int MODE>
 __global__ __launch_bounds__(256) void bnact_img_reduce_k(const mc_bnact_args p) {
     RowMap rm(p.c, MODE == 0);
     __shared__ float red[256 * 8];
+    __shared__ float tmp[256];
     const long long img = blockIdx.x;
     const bf16_t* xb = p.x + img * p.hw * p.c;
     const bf16_t* gb = (MODE == 1) ? p.g + img * p.hw * p.c : nullptr;
@@ -191,7 +210,14 @@ __global__ __launch_bounds__(256) void bnact_img_reduce_k(const mc_bnact_args p)
 #pragma unroll
         for (int q = 0; q < 8; ++q) red[threadIdx.x * 8 + q] = acc[q];
         __syncthreads();
-        if (rm.rl == 0 && v < rm.cv) {
+        if (rm.rpb >= 8) {
+            const float s = rowlane_colsum(red, tmp, rm.cvp, rm.rpb);
+            const int vo = cbase + (int)threadIdx.x / 8, q = threadIdx.x & 7;
+            if ((int)threadIdx.x < rm.cvp * 8 && vo < rm.cv) {
+                if (gridDim.y == 1) dst[vo * 8 + q] = s * post;
+                else p.split_ws[((long long)blockIdx.y * p.n_img + img) * p.c + vo * 8 + q] = s * post;
+            }
+        } else if (rm.rl == 0 && v < rm.cv) {
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 float s = 0.f;
@@ -214,6 +240,7 @@ __global__ __launch_bounds__(256) void bnact_img_reduce_k(const mc_bnact_args p)
 __global__ __launch_bounds__(256) void bnact_se_sums_k(const mc_bnact_args p) {
     RowMap rm(p.c);
     __shared__ float red[256 * 8];
+    __shared__ float tmp[256];
     const long long img = blockIdx.x;
     const bf16_t* xb = p.x + img * p.hw * p.c;
     const bf16_t* gb = p.g + img * p.hw * p.c;
@@ -252,11 +279,24 @@ __global__ __launch_bounds__(256) void bnact_se_sums_k(const mc_bnact_args p) {
             };
             const long long rstride = (long long)gridDim.y * rm.rpb;
             long long r = (long long)blockIdx.y * rm.rpb + rm.rl;
-            for (; r + rstride < p.hw; r += 2 * rstride) {             // two independent rows in flight
+            if (r + rstride < p.hw) {
+                // two rows per step, the NEXT step's four loads issued before this step's arithmetic (the body is ~900
+                // VALU instructions per pair of rows: without the prefetch a wave has nothing in flight while it computes)
                 uint4 x0 = *reinterpret_cast<const uint4*>(xb + r * p.c + v * 8);
                 uint4 x1 = *reinterpret_cast<const uint4*>(xb + (r + rstride) * p.c + v * 8);
                 uint4 g0 = *reinterpret_cast<const uint4*>(gb + r * p.c + v * 8);
                 uint4 g1 = *reinterpret_cast<const uint4*>(gb + (r + rstride) * p.c + v * 8);
+                r += 2 * rstride;
+                for (; r + rstride < p.hw; r += 2 * rstride) {
+                    const uint4 nx0 = *reinterpret_cast<const uint4*>(xb + r * p.c + v * 8);
+                    const uint4 nx1 = *reinterpret_cast<const uint4*>(xb + (r + rstride) * p.c + v * 8);
+                    const uint4 ng0 = *reinterpret_cast<const uint4*>(gb + r * p.c + v * 8);
+                    const uint4 ng1 = *reinterpret_cast<const uint4*>(gb + (r + rstride) * p.c + v * 8);
+                    __builtin_amdgcn_sched_barrier(0);          // keep the four loads in front of the arithmetic
+                    body(x0, g0);
+                    body(x1, g1);
+                    x0 = nx0; x1 = nx1; g0 = ng0; g1 = ng1;
+                }
                 body(x0, g0);
                 body(x1, g1);
             }
@@ -267,7 +307,14 @@ __global__ __launch_bounds__(256) void bnact_se_sums_k(const mc_bnact_args p) {
 #pragma unroll
             for (int q = 0; q < 8; ++q) red[threadIdx.x * 8 + q] = acc[k][q];
             __syncthreads();
-            if (rm.rl == 0 && v < rm.cv) {
+            if (rm.rpb >= 8) {
+                const float sm = rowlane_colsum(red, tmp, rm.cvp, rm.rpb);
+                const int vo = cbase + (int)threadIdx.x / 8, q = threadIdx.x & 7;
+                if ((int)threadIdx.x < rm.cvp * 8 && vo < rm.cv) {
+                    if (gridDim.y == 1) p.dgate[k * plane + img * p.c + vo * 8 + q] = sm;
+                    else p.split_ws[((long long)blockIdx.y * 5 + k) * plane + img * p.c + vo * 8 + q] = sm;
+                }
+            } else if (rm.rl == 0 && v < rm.cv) {
                 float* dst = p.dgate + k * plane + img * p.c;
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
@@ -303,7 +350,10 @@ __global__ void bn_partials_from_se_sums_k(const float* __restrict__ sums, const
 // once; a thread owns one 8-channel vector and walks down the rows, so the per-channel parameters live in registers
 // and the loop body is two 16-byte loads, the activation derivative and (APPLY) one 16-byte store, two rows in
 // flight per iteration.
-template <bool APPLY>
+// ACT: SiLU in front of the BatchNorm output (p.act == 1); MA: per-(image, channel) factor / addend on the upstream gradient
+// (p.mul / p.add).  Compile-time so that the plain form (BatchNorm2 of the projection: no activation, no factors) carries
+// 24 instead of 56 parameter registers and keeps four rows in flight in the reduce pass too.
+template <bool APPLY, bool ACT, bool MA>
 __global__ __launch_bounds__(256) void bnact_bwd_k(const mc_bnact_args p) {
     RowMap rm(p.c);
     __shared__ float red[APPLY ? 1 : 256 * 16];
@@ -323,19 +373,18 @@ __global__ __launch_bounds__(256) void bnact_bwd_k(const mc_bnact_args p) {
         for (int q = 0; q < 8; ++q) { a0[q] = 0.f; a1[q] = 0.f; }
         if (active) {
             float s[8], t[8], k0[8], k1[8], k2[8], mulv[8], addv[8];
-            load8f(p.scale + v * 8, s);
-            load8f(p.shift + v * 8, t);
+            if (ACT) { load8f(p.scale + v * 8, s); load8f(p.shift + v * 8, t); }
             if (APPLY) { load8f(p.coef + v * 8, k0); load8f(p.coef + p.c + v * 8, k1); load8f(p.coef + 2 * p.c + v * 8, k2); }
             else { load8f(p.mean + v * 8, k0); load8f(p.invstd + v * 8, k1); }
 #pragma unroll
             for (int q = 0; q < 8; ++q) { mulv[q] = rs; addv[q] = 0.f; }
-            if (p.mul) {
+            if (MA && p.mul) {
                 float m[8];
                 load8f(p.mul + img * p.c + v * 8, m);
 #pragma unroll
                 for (int q = 0; q < 8; ++q) mulv[q] = m[q] * rs;
             }
-            if (p.add) {
+            if (MA && p.add) {
                 float m[8];
                 load8f(p.add + img * p.c + v * 8, m);
 #pragma unroll
@@ -347,8 +396,8 @@ __global__ __launch_bounds__(256) void bnact_bwd_k(const mc_bnact_args p) {
                 unpack8(gv, g);
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
-                    float d = g[q] * mulv[q] + addv[q];
-                    if (p.act == 1) d *= silu_grad_f(x[q] * s[q] + t[q]);
+                    float d = MA ? g[q] * mulv[q] + addv[q] : g[q] * rs;
+                    if (ACT) d *= silu_grad_f(x[q] * s[q] + t[q]);
                     dz[q] = d;
                 }
                 if (APPLY) {
@@ -363,7 +412,7 @@ __global__ __launch_bounds__(256) void bnact_bwd_k(const mc_bnact_args p) {
             };
             const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
             long long r = (long long)blockIdx.x * rm.rpb + rm.rl;
-            if constexpr (APPLY)                                     // (the reduce variant has no registers to spare for this)
+            if constexpr (APPLY || !(ACT && MA))                     // (the full reduce variant has no registers to spare for this)
             for (; r + 3 * rstride < p.hw; r += 4 * rstride) {      // four independent rows (8 loads) in flight
                 uint4 xv[4], gv[4];
 #pragma unroll
@@ -389,7 +438,20 @@ __global__ __launch_bounds__(256) void bnact_bwd_k(const mc_bnact_args p) {
                 body(r, x0, g0);
             }
         }
-        if (!APPLY) {
+        if (!APPLY && rm.rpb >= 8) {
+            const long long prow = img * gridDim.x + blockIdx.x;
+            float* const tmp = red + 256 * 8;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) red[threadIdx.x * 8 + q] = h == 0 ? a0[q] : a1[q];
+                __syncthreads();
+                const float sm = rowlane_colsum(red, tmp, rm.cvp, rm.rpb);
+                const int vo = cbase + (int)threadIdx.x / 8;
+                if ((int)threadIdx.x < rm.cvp * 8 && vo < rm.cv) p.partials[(prow * 2 + h) * p.c + vo * 8 + (threadIdx.x & 7)] = sm;
+                __syncthreads();
+            }
+        } else if (!APPLY) {
 #pragma unroll
             for (int q = 0; q < 8; ++q) { red[threadIdx.x * 16 + q] = a0[q]; red[threadIdx.x * 16 + 8 + q] = a1[q]; }
             __syncthreads();
@@ -681,11 +743,21 @@ extern "C" int mc_bn_partials_from_se_sums(const float* sums, const float* gate,
     MC_LAUNCH_CHECK();
     return MC_OK;
 }
+template <bool APPLY>
+static void launch_bwd(const mc_bnact_args& p, void* stream) {
+    const dim3 grid(bwd_grid_x(p), (unsigned)p.n_img), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    const bool act = p.act == 1, ma = p.mul || p.add;
+    if (act && ma) hipLaunchKernelGGL((bnact_bwd_k<APPLY, true, true>), grid, block, 0, st, p);
+    else if (act) hipLaunchKernelGGL((bnact_bwd_k<APPLY, true, false>), grid, block, 0, st, p);
+    else if (ma) hipLaunchKernelGGL((bnact_bwd_k<APPLY, false, true>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((bnact_bwd_k<APPLY, false, false>), grid, block, 0, st, p);
+}
 extern "C" int mc_bnact_bwd_reduce(const mc_bnact_args* a, void* stream) {
     const mc_bnact_args& p = *a;
     if (int e = check_bnact(p)) return e;
     MC_CHECK(p.partials && p.mean && p.invstd, "bnact_bwd_reduce: null partials/mean/invstd");
-    hipLaunchKernelGGL((bnact_bwd_k<false>), dim3(bwd_grid_x(p), (unsigned)p.n_img), dim3(256), 0, (hipStream_t)stream, p);
+    launch_bwd<false>(p, stream);
     MC_LAUNCH_CHECK();
     return MC_OK;
 }
@@ -693,7 +765,7 @@ extern "C" int mc_bnact_bwd_apply(const mc_bnact_args* a, void* stream) {
     const mc_bnact_args& p = *a;
     if (int e = check_bnact(p)) return e;
     MC_CHECK(p.coef && p.dx, "bnact_bwd_apply: null coef/dx");
-    hipLaunchKernelGGL((bnact_bwd_k<true>), dim3(bwd_grid_x(p), (unsigned)p.n_img), dim3(256), 0, (hipStream_t)stream, p);
+    launch_bwd<true>(p, stream);
     MC_LAUNCH_CHECK();
     return MC_OK;
 }
