@@ -206,8 +206,9 @@ typedef struct mc_dwconv_args {
     const float* pro_scale;
     const float* pro_shift;
     float* stat_partials;
-    /* mc_dwconv_fwd only, stride 1: BatchNorm(+SiLU)-backward epilogue for the launch that computes the DATA GRADIENT of
-     * a stride-1 depthwise conv as a forward conv on flipped taps.  epi_x = the conv output e [n,oh,ow,c] that fed
+    /* BatchNorm(+SiLU)-backward epilogue of the DATA GRADIENT launch: mc_dwconv_fwd on flipped taps for a stride-1 conv,
+     * mc_dwconv_bwd_data for a stride-2 conv (stat_partials then has mc_dwconv_bwd_data_stat_rows() rows and epi_x is
+     * [n,h,w,c], the shape of the gradient).  epi_x = the conv output e [n,oh,ow,c] that fed
      * silu(bn(e)); the kernel then writes dZ = y * silu'(e*epi_scale + epi_shift) instead of y and stat_partials receives
      * [rows][2][c] = (sum dZ, sum dZ * (e - epi_mean) * epi_invstd), the input of mc_bn_bwd_finalize.  NULL = plain conv. */
     const mc_bf16* epi_x;
@@ -217,6 +218,7 @@ typedef struct mc_dwconv_args {
     const float* epi_invstd;
 } mc_dwconv_args;
 int mc_dwconv_stat_rows(const mc_dwconv_args* args);
+int mc_dwconv_bwd_data_stat_rows(const mc_dwconv_args* args);
 int mc_dwconv_fwd(const mc_dwconv_args* args, void* stream);
 int mc_dwconv_bwd_data(const mc_dwconv_args* args, void* stream);
 int mc_dwconv_bwd_weight(const mc_dwconv_args* args, void* stream);

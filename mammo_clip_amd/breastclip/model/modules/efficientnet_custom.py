@@ -270,14 +270,16 @@ class _MBConvFn(torch.autograd.Function):
         dwdw = ops.dwconv_bwd_weight(dw_in, dd, n, h, w, a.cexp, k, s, l, t, oh, ow, pro=pro0)
         wflip = ops.flipped_taps_f32(blk._depthwise_conv.weight.view(a.cexp, k * k)) if s == 1 else None   # 180 degree rotation
         grads = {}
-        if a.expand != 1 and s == 1:
-            # stride 1: the data-gradient kernel finishes the bn0 + swish backward in its epilogue -- it reads e at the
-            # output position, writes dZ0 = dA0 * silu'(bn0(e)) and leaves the BatchNorm-backward reductions behind, so
-            # the separate reduce pass over (e, dA0) is gone and the apply pass is a plain linear combination
+        if a.expand != 1:
+            # the data-gradient kernel finishes the bn0 + swish backward in its epilogue -- it reads e at the output
+            # position, writes dZ0 = dA0 * silu'(bn0(e)) and leaves the BatchNorm-backward reductions behind, so the
+            # separate reduce pass over (e, dA0) is gone and the apply pass is a plain linear combination (stride 1: the
+            # forward kernel on flipped taps; stride 2, round 3: the marching super-pixel kernel -- dA0 of the stride-2
+            # blocks, the largest tensors of the network, is never written)
             dz0, part0 = ops.dwconv_bwd_data(dd, sv["wkkc"], n, h, w, a.cexp, k, s, l, t, oh, ow, w_kkc_flipped=wflip,
                                              epi=(e, st0))
             del dd
-            if 2 * n * hw * a.cexp >= BN_FOLD_MIN_BYTES:
+            if 2 * n * hw * a.cexp >= (BN_FOLD_MIN_BYTES if s == 1 else max(BN_FOLD_MIN_BYTES, BN_FOLD_S2_MIN_BYTES)):
                 # bn0 backward is linear in (dZ0, e) and e = x We^T: it is folded into the operands of the expand conv's
                 # two gradient GEMMs (ops.bn_fold_expand_bwd) -- de is never formed, e is not read again.  Three passes
                 # over the expanded tensor against ~10 small launches and 6 passes over the (6x smaller) block input:
@@ -294,19 +296,6 @@ class _MBConvFn(torch.autograd.Function):
         else:
             da0 = ops.dwconv_bwd_data(dd, sv["wkkc"], n, h, w, a.cexp, k, s, l, t, oh, ow, w_kkc_flipped=wflip)
             del dd
-            if a.expand != 1 and 2 * n * hw * a.cexp >= max(BN_FOLD_MIN_BYTES, BN_FOLD_S2_MIN_BYTES):
-                # stride 2: one pass writes dZ0 = dA0 * silu'(bn0(e)) and the BatchNorm-backward reductions, then the
-                # folded expand-conv gradients as above (no separate reduce pass, no apply pass)
-                dz0, part0 = ops.bnact_bwd_reduce_dz(e, n, hw, a.cexp, st0, 1, da0)
-                del da0, e, dw_in
-                coef0, dg0, db0 = ops.bn_bwd_coefs(part0, n * hw, st0, blk._bn0.weight)
-                dx, dwe = ops.bn_fold_expand_bwd(dz0, x, blk._expand_conv.weight.view(a.cexp, a.cin), sv["we"], coef0,
-                                                 db0, n * hw, residual=dy if a.skip else None)
-                del dz0
-                de = None
-            elif a.expand != 1:
-                de, dg0, db0 = ops.bnact_bwd(e, n, hw, a.cexp, st0, blk._bn0.weight, 1, g=da0)
-                del da0, e, dw_in
         if a.expand != 1:
             if de is not None:
                 we_t = ops.cast_transpose_bf16(blk._expand_conv.weight.view(a.cexp, a.cin))     # [cin, cexp]

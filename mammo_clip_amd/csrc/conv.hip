@@ -709,7 +709,7 @@ __global__ __launch_bounds__(256, 2) void dwconv_march_bww_kernel(const mc_dwcon
 // touches (all K*K taps of the lane's channels, held in registers, are used once per dy row), and super-row o' is
 // complete - four output pixels per super-column - as soon as dy row o' has been processed.  The kernel is bound by
 // the 4x larger dx write stream.
-template <int K, int CPL, int LP, int NJ> struct MarchBwdCfg {
+template <int K, int CPL, int LP, int NJ, bool EPI = false> struct MarchBwdCfg {
     static constexpr int H2 = CPL / 2;
     static constexpr int PXW = 64 / LP;
     static constexpr int D = (K + 1) / 2;                  // super-taps per dimension = live super-rows
@@ -721,19 +721,27 @@ template <int K, int CPL, int LP, int NJ> struct MarchBwdCfg {
     static constexpr int VPP = PXB / 16;
     static constexpr int PSB = (CPL == 2 && LP == 32 && NJ == 2) ? 192 : PXB;      // conflict-free 4-byte reads
     static constexpr int NR_ = (16384 + D * IW_T * PXB / 2) / (D * IW_T * PXB);
-    static constexpr int NR = NR_ < 1 ? 1 : NR_;
+    static constexpr int NR0 = NR_ < 1 ? 1 : NR_;
+    // epilogue variant: the e values of a block's output pixels are prefetched into REGISTERS beside the dy block (two
+    // generations live: 2 * RB * 4 * NJ * CPL/2 registers), so its blocks are shorter
+    static constexpr int NR = EPI ? (K == 3 ? (NR0 < 2 ? NR0 : 2) : 1) : NR0;
     static constexpr int RB = D * NR;                      // dy rows per staged block
     static constexpr int TS = 256 - 256 % VPP;
     static constexpr int NV = (RB * IW_T * VPP + TS - 1) / TS;
     static constexpr int BUF_BYTES = RB * IW_T * PSB;
 };
 
-template <int K, int CPL, int LP, int NJ>
+// EPI: the launch also finishes the BatchNorm0 + SiLU backward of the expand conv output e = p.epi_x [n,h,w,c] (see the
+// stride-1 form above): it writes dZ0 = dA0 * silu'(e*scale + shift) and leaves (sum dZ0, sum dZ0 * xhat0) in stat_partials.
+// The e values of the pixels a block completes are loaded straight into registers with the block's dy prefetch (every
+// lane reads exactly the pixels it writes).
+template <int K, int CPL, int LP, int NJ, bool EPI = false>
 __global__ __launch_bounds__(256, 2) void dwconv_march_bwd_s2_kernel(const mc_dwconv_args p, int strips, int segs, int seg_rows,
                                                                      int ctiles, int gy) {
-    using C = MarchBwdCfg<K, CPL, LP, NJ>;
+    using C = MarchBwdCfg<K, CPL, LP, NJ, EPI>;
     typedef typename std::conditional<CPL == 4, uint2, uint32_t>::type ldsv_t;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[C::BUF_BYTES];
+    constexpr int SM_BYTES = (EPI && C::BUF_BYTES < 256 * 2 * CPL * 4) ? 256 * 2 * CPL * 4 : C::BUF_BYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[SM_BYTES];
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int ct = slot % ctiles, y = (slot / ctiles) * 8 + xcd;
     if (y >= gy) return;
@@ -769,6 +777,17 @@ __global__ __launch_bounds__(256, 2) void dwconv_march_bwd_s2_kernel(const mc_dw
         if (v >= C::RB * C::IW_T * C::VPP) meta[i] = 0xffu;
     }
     f32x2_t acc[C::D][NJ][4][C::H2];                       // [super-row slot][super-column][f*2+e][channel pair]
+    constexpr int NE = EPI ? C::RB * 4 * NJ : 1;           // e pixels a lane completes per block: [dy row][f][i][e]
+    ldsv_t enext[NE], ecur[NE];
+    f32x2_t e_sc[C::H2], e_sh[C::H2], ssum[C::H2], ssq[C::H2];
+#pragma unroll
+    for (int h = 0; h < C::H2; ++h) {
+        e_sc[h] = e_sh[h] = ssum[h] = ssq[h] = f32x2_t{0.f, 0.f};
+        if (EPI && ch_ok) {
+            e_sc[h] = *reinterpret_cast<const f32x2_t*>(p.epi_scale + cl + 2 * h);
+            e_sh[h] = *reinterpret_cast<const f32x2_t*>(p.epi_shift + cl + 2 * h);
+        }
+    }
 
     const int nitems = p.n * strips * segs;
     auto item_geom = [&](int it, int& img, int& j0, int& s0, int& nrows, int& nblk) {
@@ -782,6 +801,28 @@ __global__ __launch_bounds__(256, 2) void dwconv_march_bwd_s2_kernel(const mc_dw
     };
     uint4 vals[C::NV];
     unsigned inb = 0, colmask = 0;
+    // EPI: e of the pixels the dy rows of block b complete (dy row k of the block completes super-row b*RB + k - (D-1))
+    auto epi_load = [&](int img, int j0, int s0, int nrows_i, int b) {
+        if constexpr (EPI) {
+            const long long ix = 2LL * (j0 + jl0) - p.pad_l;
+#pragma unroll
+            for (int k = 0; k < C::RB; ++k) {
+                const int sr = b * C::RB + k - (C::D - 1);
+                const long long iy0 = 2LL * (s0 + sr) - p.pad_t;
+#pragma unroll
+                for (int f = 0; f < 2; ++f)
+#pragma unroll
+                    for (int i = 0; i < NJ; ++i)
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            const long long x = ix + 2 * i + e, yy = iy0 + f;
+                            const bool ok = ch_ok && sr >= 0 && sr < nrows_i && yy >= 0 && yy < p.h && x >= 0 && x < p.w;
+                            const bf16_t* a = ok ? p.epi_x + (((long long)img * p.h + yy) * p.w + x) * p.c + cl : p.epi_x;
+                            enext[((k * 2 + f) * NJ + i) * 2 + e] = *reinterpret_cast<const ldsv_t*>(a);   // unconditional (see stage_load)
+                        }
+            }
+        }
+    };
     auto stage_load = [&](int img, int j0, int s0, int b, bool new_item) {
         const int oy0 = s0 - (C::D - 1) + b * C::RB, ox0 = j0 - (C::D - 1);
         if (new_item) {
@@ -814,12 +855,17 @@ __global__ __launch_bounds__(256, 2) void dwconv_march_bwd_s2_kernel(const mc_dw
                 *reinterpret_cast<uint4*>(smem + ((meta[i] >> 16) << 4)) = val;
             }
         }
+        if constexpr (EPI) {
+#pragma unroll
+            for (int i = 0; i < NE; ++i) ecur[i] = enext[i];
+        }
     };
 
     int it = y, img = 0, j0 = 0, s0 = 0, nrows = 0, nblk = 0, b = 0;
     if (it >= nitems) return;
     item_geom(it, img, j0, s0, nrows, nblk);
     stage_load(img, j0, s0, 0, true);
+    epi_load(img, j0, s0, nrows, 0);
     int sr_next = 0;                                       // super-row (item-relative) completed by the next dy row
     bf16_t* optr = nullptr;                                // lane's pixel (f = 0, e = 0 of its first super-column) in that super-row
     unsigned ok_mask = 0;                                  // bit (i*2+e): output column exists
@@ -834,7 +880,7 @@ __global__ __launch_bounds__(256, 2) void dwconv_march_bwd_s2_kernel(const mc_dw
             if (it2 < nitems) item_geom(it2, img2, j2, s2, nrows2, nblk2);
         }
         const bool more = it2 < nitems;
-        if (more) stage_load(img2, j2, s2, b2, b2 == 0);
+        if (more) { stage_load(img2, j2, s2, b2, b2 == 0); epi_load(img2, j2, s2, nrows2, b2); }
 
         if (b == 0) {
 #pragma unroll
@@ -857,7 +903,7 @@ __global__ __launch_bounds__(256, 2) void dwconv_march_bwd_s2_kernel(const mc_dw
                     if (ch_ok && x >= 0 && x < p.w) ok_mask |= 1u << (i * 2 + e);
                 }
         }
-#pragma unroll 1
+#pragma unroll (EPI ? C::NR : 1)
         for (int sb = 0; sb < C::NR; ++sb) {
             const unsigned char* lp = smem + lbase + sb * (C::D * C::IW_T * C::PSB);
 #pragma unroll
@@ -907,12 +953,26 @@ __global__ __launch_bounds__(256, 2) void dwconv_march_bwd_s2_kernel(const mc_dw
                                     for (int e = 0; e < 2; ++e) {
                                         if ((ok_mask >> (i * 2 + e)) & 1u) {
                                             bf16_t* o = optr + f * row_pitch + (long long)(2 * i + e) * p.c;
-                                            if constexpr (CPL == 4)
-                                                *reinterpret_cast<uint2*>(o) =
-                                                    make_uint2(pack_bf2(acc[sl][i][f * 2 + e][0].x, acc[sl][i][f * 2 + e][0].y),
-                                                               pack_bf2(acc[sl][i][f * 2 + e][1].x, acc[sl][i][f * 2 + e][1].y));
-                                            else
-                                                *reinterpret_cast<uint32_t*>(o) = pack_bf2(acc[sl][i][f * 2 + e][0].x, acc[sl][i][f * 2 + e][0].y);
+                                            uint32_t o2[C::H2];
+#pragma unroll
+                                            for (int h = 0; h < C::H2; ++h) {
+                                                if constexpr (EPI) {
+                                                    const ldsv_t evv = ecur[(((sb * C::D + jr) * 2 + f) * NJ + i) * 2 + e];
+                                                    uint32_t ew;
+                                                    if constexpr (CPL == 4) ew = h == 0 ? evv.x : evv.y; else ew = evv;
+                                                    const f32x2_t e2 = {bf_lo(ew), bf_hi(ew)};
+                                                    const f32x2_t z = __builtin_elementwise_fma(e2, e_sc[h], e_sh[h]);
+                                                    const f32x2_t a2 = acc[sl][i][f * 2 + e][h];
+                                                    o2[h] = pack_bf2(a2.x * silu_grad_f(z.x), a2.y * silu_grad_f(z.y));
+                                                    const f32x2_t r = {bf_lo(o2[h]), bf_hi(o2[h])};     // reductions of the stored (rounded) dZ0
+                                                    ssum[h] += r;
+                                                    ssq[h] = __builtin_elementwise_fma(r, e2, ssq[h]);
+                                                } else {
+                                                    o2[h] = pack_bf2(acc[sl][i][f * 2 + e][h].x, acc[sl][i][f * 2 + e][h].y);
+                                                }
+                                            }
+                                            if constexpr (CPL == 4) *reinterpret_cast<uint2*>(o) = make_uint2(o2[0], o2[1]);
+                                            else *reinterpret_cast<uint32_t*>(o) = o2[0];
                                         }
                                     }
                             }
@@ -932,6 +992,59 @@ __global__ __launch_bounds__(256, 2) void dwconv_march_bwd_s2_kernel(const mc_dw
         if (!more) break;
         it = it2; img = img2; j0 = j2; s0 = s2; nrows = nrows2; nblk = nblk2; b = b2;
     }
+    if constexpr (EPI) {
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem);          // [256 threads][2][CPL]
+#pragma unroll
+        for (int h = 0; h < C::H2; ++h) {
+            red[tid * 2 * CPL + 2 * h] = ssum[h].x; red[tid * 2 * CPL + 2 * h + 1] = ssum[h].y;
+            red[tid * 2 * CPL + CPL + 2 * h] = ssq[h].x; red[tid * 2 * CPL + CPL + 2 * h + 1] = ssq[h].y;
+        }
+        __syncthreads();
+        if (tid < 2 * C::TCH) {
+            const int ch = tid % C::TCH, which = tid / C::TCH;          // 0 = sum dZ, 1 = sum dZ * e
+            float sv = 0.f, s0v = 0.f;
+            for (int wv = 0; wv < 4; ++wv)
+                for (int q = 0; q < C::PXW; ++q) {
+                    sv += red[(wv * 64 + q * LP + ch / CPL) * 2 * CPL + which * CPL + ch % CPL];
+                    s0v += red[(wv * 64 + q * LP + ch / CPL) * 2 * CPL + ch % CPL];
+                }
+            if (c0 + ch < p.c) {
+                // sum dZ * xhat = invstd * (sum dZ * e - mean * sum dZ)
+                if (which == 1) sv = p.epi_invstd[c0 + ch] * (sv - p.epi_mean[c0 + ch] * s0v);
+                p.stat_partials[((long long)y * 2 + which) * p.c + c0 + ch] = sv;
+            }
+        }
+    }
+}
+
+template <int K, int CPL, int LP, int NJ, bool EPI = false> int march_bwd_s2_plan(const mc_dwconv_args& p, int* strips_, int* segs_, int* seg_rows_, int* ctiles_) {
+    using C = MarchBwdCfg<K, CPL, LP, NJ, EPI>;
+    const int ohv = (p.h + p.pad_t + 1) >> 1, owv = (p.w + p.pad_l + 1) >> 1;
+    const int strips = mc_div_up(owv, C::TOWJ), ctiles = mc_div_up(p.c, C::TCH);
+    long long base = (long long)p.n * strips * ctiles;
+    int segs = (int)((2048 + base - 1) / base);
+    int max_segs = ohv / 16 > 0 ? ohv / 16 : 1;
+    if (segs > max_segs) segs = max_segs;
+    if (segs < 1) segs = 1;
+    const int seg_rows = mc_div_up(mc_div_up(ohv, segs), C::RB) * C::RB;
+    segs = mc_div_up(ohv, seg_rows);
+    long long nitems = (long long)p.n * strips * segs;
+    long long per_xcd = 64 / ctiles;                            // 2 workgroups per CU, capped per XCD (see march_plan)
+    if (per_xcd < 1) per_xcd = 1;
+    long long cap = 8 * per_xcd;
+    long long per = (nitems + cap - 1) / cap;
+    *strips_ = strips; *segs_ = segs; *seg_rows_ = seg_rows; *ctiles_ = ctiles;
+    return (int)((nitems + per - 1) / per);
+}
+template <int K, int CPL, int LP, int NJ> int launch_march_bwd_s2_epi(const mc_dwconv_args& p, hipStream_t st) {
+    int strips, segs, seg_rows, ctiles;
+    const int gy = march_bwd_s2_plan<K, CPL, LP, NJ, true>(p, &strips, &segs, &seg_rows, &ctiles);
+    const int gy8 = (gy + 7) / 8 * 8;
+    hipLaunchKernelGGL((dwconv_march_bwd_s2_kernel<K, CPL, LP, NJ, true>), dim3(gy8 * ctiles), dim3(256), 0, st, p, strips, segs,
+                       seg_rows, ctiles, gy);
+    MC_LAUNCH_CHECK();
+    return MC_OK;
 }
 
 template <int K, int CPL, int LP, int NJ> int launch_march_bwd_s2(const mc_dwconv_args& p, hipStream_t st) {
@@ -1054,6 +1167,18 @@ extern "C" int mc_dwconv_stat_rows(const mc_dwconv_args* a) {
     return a->stride == 1 ? march_rows<5, 1>(*a) : march_rows<5, 2>(*a);
 }
 
+// rows of stat_partials written by mc_dwconv_bwd_data with the stride-2 BatchNorm-backward epilogue (epi_x set)
+extern "C" int mc_dwconv_bwd_data_stat_rows(const mc_dwconv_args* a) {
+    const mc_dwconv_args& p = *a;
+    int s1, s2, s3, s4;
+    if (p.stride != 2) return 0;
+    if (p.k == 3) {
+        if (p.c % 48 == 0 && p.c < 192) return march_bwd_s2_plan<3, 4, 12, 1, true>(p, &s1, &s2, &s3, &s4);
+        return march_bwd_s2_plan<3, 4, 16, 1, true>(p, &s1, &s2, &s3, &s4);
+    }
+    return march_bwd_s2_plan<5, 2, 32, 2, true>(p, &s1, &s2, &s3, &s4);
+}
+
 extern "C" int mc_dwconv_fwd(const mc_dwconv_args* a, void* stream) {
     const mc_dwconv_args& p = *a;
     if (int e = check_common(p)) return e;
@@ -1071,6 +1196,16 @@ extern "C" int mc_dwconv_bwd_data(const mc_dwconv_args* a, void* stream) {
     const mc_dwconv_args& p = *a;
     if (int e = check_common(p)) return e;
     MC_CHECK(p.dy && p.w_kkc, "dwconv_bwd_data: null dy / w");
+    MC_CHECK(!p.epi_x || (p.stride == 2 && p.epi_scale && p.epi_shift && p.epi_mean && p.epi_invstd && p.stat_partials),
+             "dwconv_bwd_data: the BatchNorm-backward epilogue is provided for stride 2 here (stride 1: mc_dwconv_fwd on flipped taps) and needs scale/shift/mean/invstd and stat_partials");
+    if (p.stride == 2 && p.epi_x) {
+        hipStream_t st = (hipStream_t)stream;
+        if (p.k == 3) {
+            if (p.c % 48 == 0 && p.c < 192) return launch_march_bwd_s2_epi<3, 4, 12, 1>(p, st);
+            return launch_march_bwd_s2_epi<3, 4, 16, 1>(p, st);
+        }
+        return launch_march_bwd_s2_epi<5, 2, 32, 2>(p, st);
+    }
     if (p.stride == 2) {                                               // marching form
         hipStream_t st = (hipStream_t)stream;
         if (p.k == 3) {

@@ -108,6 +108,7 @@ _SIGS = {
     "mc_gate_weights_bf16": ([P, P, I, I, I, P, P], I),
     "mc_stem_im2col_u8": ([P, LL, LL, LL, LL, P, F, F, I, I, I, I, I, I, I, P, P], I),
     "mc_dwconv_stat_rows": ([C.POINTER(DwconvArgs)], I),
+    "mc_dwconv_bwd_data_stat_rows": ([C.POINTER(DwconvArgs)], I),
     "mc_dwconv_fwd": ([C.POINTER(DwconvArgs), P], I),
     "mc_dwconv_bwd_data": ([C.POINTER(DwconvArgs), P], I),
     "mc_dwconv_bwd_weight": ([C.POINTER(DwconvArgs), P], I),

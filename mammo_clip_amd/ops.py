@@ -486,16 +486,24 @@ def _dwconv_fwd_impl(x, w_kkc, n, h, w, c, k, stride, pad_l, pad_t, oh, ow, pro=
 
 def _dwconv_bwd_data_impl(dy, w_kkc, n, h, w, c, k, stride, pad_l, pad_t, oh, ow, w_kkc_flipped=None, epi=None):
     """dx [n*h*w, c].  stride 1 runs the LDS-tiled forward kernel on the flipped filter; stride 2 the marching
-    super-pixel kernel.  epi (stride 1 only) = (e, BNStats): returns (dZ, BatchNorm-backward partials), see dwconv_fwd."""
+    super-pixel kernel.  epi = (e, BNStats): the launch finishes the BatchNorm + SiLU backward of the conv's input
+    silu(bn(e)) and returns (dZ, BatchNorm-backward partials) instead of dx, see dwconv_fwd."""
     if stride == 1 and w_kkc_flipped is not None:
         return _dwconv_fwd_impl(dy, w_kkc_flipped, n, oh, ow, c, k, 1, k - 1 - pad_l, k - 1 - pad_t, h, w, epi=epi)
-    assert epi is None
+    assert epi is None or stride == 2
     a = _dw_args(n, h, w, c, k, stride, pad_l, pad_t, oh, ow)
     dx = empty((n * h * w, c), BF16, dy)
     a.dy, a.out, a.w_kkc = _p(dy), _p(dx), _p(w_kkc)
-    _note(2 * n * c * (h * w + oh * ow), 2 * n * c * oh * ow * k * k)
-    L.call("mc_dwconv_bwd_data", C.byref(a), _st(), kind=f"k{k}s{stride}")
-    return dx
+    part = None
+    if epi is not None:
+        e, st = epi
+        assert e.shape == dx.shape
+        a.epi_x, a.epi_scale, a.epi_shift, a.epi_mean, a.epi_invstd = _p(e), _p(st.scale), _p(st.shift), _p(st.mean), _p(st.invstd)
+        part = empty((L.load().mc_dwconv_bwd_data_stat_rows(C.byref(a)), 2, c), torch.float32, dy)
+        a.stat_partials = _p(part)
+    _note(2 * n * c * (h * w * (2 if epi is not None else 1) + oh * ow), 2 * n * c * oh * ow * k * k)
+    L.call("mc_dwconv_bwd_data", C.byref(a), _st(), kind=f"k{k}s{stride}" + ("|dgrad_bn" if epi is not None else ""))
+    return dx if epi is None else (dx, part)
 
 
 def _dwconv_bwd_weight_impl(x, dy, n, h, w, c, k, stride, pad_l, pad_t, oh, ow, pro=None):

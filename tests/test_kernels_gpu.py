@@ -893,6 +893,37 @@ def test_dwconv_dgrad_with_bn_backward_epilogue(k, n, h, w, c):
     check(db, db_ref, 1e-2, "dbeta")
 
 
+@pytest.mark.parametrize("k,n,h,w,c,pad", [(3, 2, 40, 33, 144, (0, 1)), (3, 2, 41, 34, 240, (1, 1)), (5, 2, 29, 23, 384, (1, 2)),
+                                          (5, 1, 60, 64, 64, (2, 2)), (3, 3, 17, 50, 48, (0, 0)), (5, 2, 30, 31, 1056, (2, 1))])
+def test_dwconv_s2_dgrad_with_bn_backward_epilogue(k, n, h, w, c, pad):
+    """stride-2 depthwise data gradient (marching super-pixel kernel) with the fused BatchNorm(+SiLU)-backward epilogue ==
+    plain stride-2 data gradient followed by the two-pass BatchNorm backward (static "same" padding incl. the asymmetric
+    forms, odd and even maps): dZ0, dE, dgamma, dbeta."""
+    pl, pt = pad
+    oh, ow = (h + 1) // 2, (w + 1) // 2
+    e = rnd(n * h * w, c, seed=1)
+    dd = rnd(n * oh * ow, c, seed=2)
+    wk = rnd(k * k, c, seed=3, dtype=torch.float32)
+    gamma, beta = rnd(c, seed=4, dtype=torch.float32) * 0.2 + 1.0, rnd(c, seed=5, dtype=torch.float32) * 0.1
+    ef = e.float()
+    mean, var = ef.mean(0), ef.var(0, unbiased=False)
+    st = ops.BNStats()
+    st.mean, st.invstd = mean.contiguous(), (var + 1e-3).rsqrt().contiguous()
+    st.scale = (gamma * st.invstd).contiguous()
+    st.shift = (beta - mean * st.scale).contiguous()
+    st.count = float(n * h * w)
+    da0 = ops.dwconv_bwd_data(dd, wk, n, h, w, c, k, 2, pl, pt, oh, ow)
+    de_ref, dg_ref, db_ref = ops.bnact_bwd(e, n, h * w, c, st, gamma, 1, g=da0)
+    dz, part = ops.dwconv_bwd_data(dd, wk, n, h, w, c, k, 2, pl, pt, oh, ow, epi=(e, st))
+    de, dg, db = ops.bnact_bwd(e, n, h * w, c, st, gamma, 0, g=dz, partials=part)
+    z = ef * st.scale + st.shift
+    sg = torch.sigmoid(z)
+    check(dz, da0.float() * (sg * (1 + z * (1 - sg))), 1.5e-2, "dZ0 (stride 2)")
+    check(de, de_ref, 1.5e-2, "dE through the fused stride-2 epilogue")
+    check(dg, dg_ref, 1e-2, "dgamma")
+    check(db, db_ref, 1e-2, "dbeta")
+
+
 # ------------------------------------------------------------------------------------------- fused attention
 def _attn_inputs(b, t, nh, seed):
     H = nh * 64
