@@ -112,7 +112,7 @@ int mc_quant_fp8_bf16(const mc_bf16* x, long long n, const float* amax_in, unsig
  *   C[M,N] = pro(X)[M,K] . W[N,K]^T (+ R);  N <= 256, K <= 384 (mc_gemm_rows_supported), bf16 in/out.
  * Weights live in LDS for the whole launch, each workgroup writes complete, contiguous output rows.
  * The data gradient of a 1x1 conv is the same call with the transposed weight (mc_cast_transpose_f32_bf16).
- * stat_partials (optional): float[mc_gemm_rows_blocks(M)][2][N] column sums / sums of squares of C. */
+ * stat_partials (optional): float[mc_gemm_rows_blocks(args)][2][N] column sums / sums of squares of C. */
 typedef struct mc_gemm_rows_args {
     const mc_bf16* X;
     long long M;
@@ -133,7 +133,7 @@ typedef struct mc_gemm_rows_args {
     const float* bias;       /* optional float[N], added to every output row (after the statistics, with the residual) */
 } mc_gemm_rows_args;
 int mc_gemm_rows_supported(int n, int k);
-int mc_gemm_rows_blocks(long long m);
+int mc_gemm_rows_blocks(const mc_gemm_rows_args* args);     /* persistent workgroups of the launch = rows of stat_partials */
 int mc_gemm_rows_bf16(const mc_gemm_rows_args* args, void* stream);
 
 /* Streaming weight gradient of the same layers: dW[N,K] (fp32) (+)= dY[M,N]^T . pro(X)[M,K]; both operands are

@@ -262,33 +262,80 @@ template <int FN, int KC> size_t lds_bytes() {
     return (size_t)KC * FN * 1024 + 2 * KC * 32 * 4 + (staging > red ? staging : red);
 }
 
-template <int FN, int KC> int launch_rows(const mc_gemm_rows_args& p, int blocks, hipStream_t st) {
+// Persistent workgroups per CU = what the instance's registers and LDS allow (round 3: the launch used to be capped at two
+// per CU; the write-heavy expand convs (24 -> 144: 142 VGPRs) gain 16 % from a third, instances above 168 VGPRs stay at two)
+template <int FN, int KC, int PF, int RG> int rows_occupancy(bool gated) {
+    static int occ[2] = {0, 0};
+    if (!occ[gated]) {
+        static unsigned long long attr_done = 0;
+        const void* kfn = reinterpret_cast<const void*>(&gemm_rows_kernel<FN, KC, PF, RG>);
+        const size_t lds_max = lds_bytes<FN, KC>() + (size_t)4 * 2 * KC * 32 * 4;
+        const size_t lds = lds_bytes<FN, KC>() + (gated ? (size_t)4 * 2 * KC * 32 * 4 : 0);
+        if (lds > 64 * 1024) MC_SET_MAX_LDS(attr_done, kfn, lds_max);
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kfn, 256, lds) != hipSuccess || nb < 1) nb = 2;
+        occ[gated] = nb > 3 ? 3 : nb;
+    }
+    return occ[gated];
+}
+
+// query != nullptr: report the workgroup count (= rows of stat_partials) instead of launching
+template <int FN, int KC> int launch_rows(const mc_gemm_rows_args& p, hipStream_t st, int* query) {
     constexpr int RG = (FN >= 6 || KC >= 12) ? 1 : 2;   // wide outputs / deep K: 16 rows per iteration (register budget)
     constexpr int PF = KC >= 12 ? 1 : (KC >= 6 ? (RG == 1 ? 2 : 1) : 8 / KC);   // ~8-16 KB of activations in flight per wave
+    const long long groups = (p.M + 15) / 16;
+    long long b = (groups + 3) / 4;
+    const int ntiles = (p.N + FN * 16 - 1) / (FN * 16);
+    const long long cap = ntiles > 1 ? 512 : 256LL * rows_occupancy<FN, KC, PF, RG>(p.pro_gate != nullptr);
+    if (b > cap) b = cap;
+    if (b < 1) b = 1;
+    const int blocks = (int)b;
+    if (query) { *query = blocks; return MC_OK; }
     size_t lds = lds_bytes<FN, KC>() + (p.pro_gate ? (size_t)4 * 2 * KC * 32 * 4 : 0);     // + per-wave SE gate cache
     static unsigned long long attr_done = 0;
     const void* kfn = reinterpret_cast<const void*>(&gemm_rows_kernel<FN, KC, PF, RG>);
     const size_t lds_max = lds_bytes<FN, KC>() + (size_t)4 * 2 * KC * 32 * 4;
     if (lds > 64 * 1024) MC_SET_MAX_LDS(attr_done, kfn, lds_max);
-    const int ntiles = (p.N + FN * 16 - 1) / (FN * 16);
     hipLaunchKernelGGL((gemm_rows_kernel<FN, KC, PF, RG>), dim3((blocks + 7) / 8 * 8 * ntiles), dim3(256), lds, st, p, blocks, ntiles);
     MC_LAUNCH_CHECK();
     return MC_OK;
 }
 
-template <int FN> int dispatch_kc(const mc_gemm_rows_args& p, int blocks, hipStream_t st) {
-    if (p.K <= 32) return launch_rows<FN, 1>(p, blocks, st);
-    if (p.K <= 64) return launch_rows<FN, 2>(p, blocks, st);
-    if (p.K <= 128) return launch_rows<FN, 4>(p, blocks, st);
+template <int FN> int dispatch_kc(const mc_gemm_rows_args& p, hipStream_t st, int* query) {
+    if (p.K <= 32) return launch_rows<FN, 1>(p, st, query);
+    if (p.K <= 64) return launch_rows<FN, 2>(p, st, query);
+    if (p.K <= 128) return launch_rows<FN, 4>(p, st, query);
     if constexpr (FN == 8) {
-        if (p.K <= 192) return launch_rows<FN, 6>(p, blocks, st);     // 48 KiB weight slice: two workgroups per CU
+        if (p.K <= 192) return launch_rows<FN, 6>(p, st, query);     // 48 KiB weight slice: two workgroups per CU
     }
     if constexpr (FN <= 8) {
-        if (p.K <= 256) return launch_rows<FN, 8>(p, blocks, st);
-        if constexpr (FN <= 5) return launch_rows<FN, 12>(p, blocks, st);
+        if (p.K <= 256) return launch_rows<FN, 8>(p, st, query);
+        if constexpr (FN <= 5) return launch_rows<FN, 12>(p, st, query);
     }
     mc_set_error("gemm_rows: internal: no instantiation");
     return MC_ERR_ARG;
+}
+
+int dispatch_fn(const mc_gemm_rows_args& p, hipStream_t st, int* query) {
+    if (p.N > 256) return dispatch_kc<8>(p, st, query);   // wide output: 128-column tiles
+    switch ((p.N + 15) / 16) {                     // exact fragment count: no dead accumulators, no predicated MFMAs
+        case 1: return dispatch_kc<1>(p, st, query);
+        case 2: return dispatch_kc<2>(p, st, query);
+        case 3: return dispatch_kc<3>(p, st, query);
+        case 4: return dispatch_kc<4>(p, st, query);
+        case 5: return dispatch_kc<5>(p, st, query);
+        case 6: return dispatch_kc<6>(p, st, query);
+        case 7: return dispatch_kc<7>(p, st, query);
+        case 8: return dispatch_kc<8>(p, st, query);
+        case 9: return dispatch_kc<9>(p, st, query);
+        case 10: return dispatch_kc<10>(p, st, query);
+        case 11: return dispatch_kc<11>(p, st, query);
+        case 12: return dispatch_kc<12>(p, st, query);
+        case 13: return dispatch_kc<13>(p, st, query);
+        case 14: return dispatch_kc<14>(p, st, query);
+        case 15: return dispatch_kc<15>(p, st, query);
+        default: return dispatch_kc<16>(p, st, query);
+    }
 }
 
 }  // namespace
@@ -303,12 +350,12 @@ extern "C" int mc_gemm_rows_supported(int n, int k) {
     return fn * kcp <= 64;                        // weight image <= 64 KiB of LDS
 }
 
-extern "C" int mc_gemm_rows_blocks(long long m) {
-    long long groups = (m + 15) / 16;
-    long long b = (groups + 3) / 4;
-    if (b > 512) b = 512;
-    if (b < 1) b = 1;
-    return (int)b;
+// rows of stat_partials = persistent workgroups of the launch mc_gemm_rows_bf16 makes for these arguments
+extern "C" int mc_gemm_rows_blocks(const mc_gemm_rows_args* a) {
+    int q = 0;
+    if (!mc_gemm_rows_supported(a->N, a->K) || a->M <= 0) return 0;
+    if (dispatch_fn(*a, nullptr, &q) != MC_OK) return 0;
+    return q;
 }
 
 extern "C" int mc_gemm_rows_bf16(const mc_gemm_rows_args* a, void* stream) {
@@ -320,25 +367,5 @@ extern "C" int mc_gemm_rows_bf16(const mc_gemm_rows_args* a, void* stream) {
     MC_CHECK(!p.R || (p.ldr % 8 == 0 && mc_aligned16(p.R)), "gemm_rows: bad residual");
     MC_CHECK((p.pro_scale == nullptr) == (p.pro_shift == nullptr), "gemm_rows: prologue needs scale and shift");
     MC_CHECK(!p.pro_gate || (p.pro_scale && p.pro_rows_per_img >= 16), "gemm_rows: gate needs the BN prologue and >= 16 rows per image");
-    hipStream_t st = (hipStream_t)stream;
-    int blocks = mc_gemm_rows_blocks(p.M);
-    if (p.N > 256) return dispatch_kc<8>(p, blocks, st);   // wide output: 128-column tiles
-    switch ((p.N + 15) / 16) {                     // exact fragment count: no dead accumulators, no predicated MFMAs
-        case 1: return dispatch_kc<1>(p, blocks, st);
-        case 2: return dispatch_kc<2>(p, blocks, st);
-        case 3: return dispatch_kc<3>(p, blocks, st);
-        case 4: return dispatch_kc<4>(p, blocks, st);
-        case 5: return dispatch_kc<5>(p, blocks, st);
-        case 6: return dispatch_kc<6>(p, blocks, st);
-        case 7: return dispatch_kc<7>(p, blocks, st);
-        case 8: return dispatch_kc<8>(p, blocks, st);
-        case 9: return dispatch_kc<9>(p, blocks, st);
-        case 10: return dispatch_kc<10>(p, blocks, st);
-        case 11: return dispatch_kc<11>(p, blocks, st);
-        case 12: return dispatch_kc<12>(p, blocks, st);
-        case 13: return dispatch_kc<13>(p, blocks, st);
-        case 14: return dispatch_kc<14>(p, blocks, st);
-        case 15: return dispatch_kc<15>(p, blocks, st);
-        default: return dispatch_kc<16>(p, blocks, st);
-    }
+    return dispatch_fn(p, (hipStream_t)stream, nullptr);
 }

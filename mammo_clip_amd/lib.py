@@ -93,7 +93,7 @@ _SIGS = {
     "mc_amax_bf16": ([P, LL, P, P], I),
     "mc_quant_fp8_bf16": ([P, LL, P, P, P, P, P], I),
     "mc_gemm_rows_supported": ([I, I], I),
-    "mc_gemm_rows_blocks": ([LL], I),
+    "mc_gemm_rows_blocks": ([C.POINTER(GemmRowsArgs)], I),
     "mc_gemm_rows_bf16": ([C.POINTER(GemmRowsArgs), P], I),
     "mc_cast_transpose_f32_bf16": ([P, P, I, I, P], I),
     "mc_wgrad_rows_supported": ([I, I], I),

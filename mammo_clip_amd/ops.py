@@ -137,7 +137,8 @@ def linear_fwd_fp8(x, w, amax_x=None, amax_w=None, stats=False, batch_w=None):
 ROWS_MIN_M = 8192       # below this the tiled kernel is as good
 
 
-def gemm_rows(x, w, y, residual=None, pro=None, stat_partials=None, kind=None, bias=None):
+def gemm_rows(x, w, y, residual=None, pro=None, stats=False, kind=None, bias=None):
+    """row-streaming 1x1 convolution; stats = True returns the [workgroups, 2, N] BatchNorm partials of the output"""
     a = L.GemmRowsArgs()
     M, K = x.shape
     N = w.shape[0]
@@ -148,9 +149,11 @@ def gemm_rows(x, w, y, residual=None, pro=None, stat_partials=None, kind=None, b
         a.R, a.ldr = _p(residual), residual.stride(0)
     if pro is not None:
         a.pro_scale, a.pro_shift, a.pro_gate, a.pro_rows_per_img = _p(pro[0]), _p(pro[1]), _p(pro[2]), pro[3]
-    a.stat_partials, a.bias = _p(stat_partials), _p(bias)
+    part = empty((L.load().mc_gemm_rows_blocks(C.byref(a)), 2, N), torch.float32, x) if stats else None
+    a.stat_partials, a.bias = _p(part), _p(bias)
     _note(2 * M * (K + N) + 2 * N * K + (2 * M * N if residual is not None else 0), 2 * M * N * K)
     L.call("mc_gemm_rows_bf16", C.byref(a), _st(), kind=kind)
+    return part
 
 
 def _rows_ok(M, N, K, bias, act):
@@ -237,8 +240,7 @@ def _linear_fwd_impl(x, w, bias=None, act=0, residual=None, stats=False, pro=Non
     y = out if out is not None else empty((M, N), BF16, x)
     if _rows_ok(M, N, K, bias, act) and (pro is None or pro[0] is not None) and not (
             pro is None and bias is None and not tag and _prefer_tiles(N, K)):
-        part = empty((L.load().mc_gemm_rows_blocks(M), 2, N), torch.float32, x) if stats else None
-        gemm_rows(x, w, y, residual=residual, pro=pro, stat_partials=part, kind="fwd_rows" + tag, bias=bias)
+        part = gemm_rows(x, w, y, residual=residual, pro=pro, stats=stats, kind="fwd_rows" + tag, bias=bias)
         return (y, part) if stats else y
     if pro is not None and pro[0] is None and residual is None and bias is None and M % pro[3] == 0 and pro[3] >= 256:
         # x is already activated and only carries the per-image gate: one GEMM per image (batched) whose weight tile
