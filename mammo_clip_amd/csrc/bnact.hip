@@ -127,11 +127,13 @@ __global__ __launch_bounds__(256) void bnact_apply_k(const mc_bnact_args p) {
         load8f(p.scale + cv * 8, s);
         load8f(p.shift + cv * 8, t);
         float rs = p.rowscale ? p.rowscale[pix / p.hw] : 1.f;
+        if (p.act == 1) bn_silu8(f, s, t);
+        else {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            float z = f[q] * s[q] + t[q];
-            f[q] = (p.act == 1 ? silu_f(z) : z) * rs;
+            for (int q = 0; q < 8; ++q) f[q] = f[q] * s[q] + t[q];
         }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) f[q] *= rs;
         if (p.res) {
             float r[8];
             unpack8(nt_load16(p.res + pix * p.c + cv * 8), r);
@@ -168,10 +170,10 @@ __global__ __launch_bounds__(256) void bnact_img_reduce_k(const mc_bnact_args p)
                 float f[8];
                 unpack8(xv, f);
                 if (MODE == 0) {
+                    if (p.act == 1) bn_silu8(f, s, t);
+                    else {
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        float z = f[q] * s[q] + t[q];
-                        f[q] = (p.act == 1 ? silu_f(z) : z);
+                        for (int q = 0; q < 8; ++q) f[q] = f[q] * s[q] + t[q];
                     }
                     if (ob) {                       // the pooled mean is taken over the stored (bf16-rounded) values
                         const uint4 o = pack8(f);
@@ -264,17 +266,20 @@ __global__ __launch_bounds__(256) void bnact_se_sums_k(const mc_bnact_args p) {
                 unpack8(xv, x);
                 unpack8(gv, g);
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    float z = x[q] * s[q] + t[q];
-                    float sg = sigmoid_f(z);
-                    float y = z * sg, yd = sg * (1.0f + z * (1.0f - sg));
-                    float xh = (x[q] - mu[q]) * is[q];
-                    float gyd = g[q] * yd;
-                    acc[0][q] += g[q] * y;
-                    acc[1][q] += gyd;
-                    acc[2][q] += gyd * xh;
-                    acc[3][q] += yd;
-                    acc[4][q] += yd * xh;
+                for (int q = 0; q < 8; q += 2) {
+                    const f32x2_t one = {1.f, 1.f};
+                    const f32x2_t xv = {x[q], x[q + 1]}, gv = {g[q], g[q + 1]};
+                    const f32x2_t z = __builtin_elementwise_fma(xv, f32x2_t{s[q], s[q + 1]}, f32x2_t{t[q], t[q + 1]});
+                    const f32x2_t sg = sigmoid2_f(z);
+                    const f32x2_t y = z * sg, yd = sg * __builtin_elementwise_fma(z, one - sg, one);
+                    const f32x2_t xh = (xv - f32x2_t{mu[q], mu[q + 1]}) * f32x2_t{is[q], is[q + 1]};
+                    const f32x2_t gyd = gv * yd;
+                    f32x2_t a;
+                    a = __builtin_elementwise_fma(gv, y, f32x2_t{acc[0][q], acc[0][q + 1]}); acc[0][q] = a.x; acc[0][q + 1] = a.y;
+                    a = f32x2_t{acc[1][q], acc[1][q + 1]} + gyd; acc[1][q] = a.x; acc[1][q + 1] = a.y;
+                    a = __builtin_elementwise_fma(gyd, xh, f32x2_t{acc[2][q], acc[2][q + 1]}); acc[2][q] = a.x; acc[2][q + 1] = a.y;
+                    a = f32x2_t{acc[3][q], acc[3][q + 1]} + yd; acc[3][q] = a.x; acc[3][q + 1] = a.y;
+                    a = __builtin_elementwise_fma(yd, xh, f32x2_t{acc[4][q], acc[4][q + 1]}); acc[4][q] = a.x; acc[4][q + 1] = a.y;
                 }
             };
             const long long rstride = (long long)gridDim.y * rm.rpb;
@@ -395,10 +400,11 @@ __global__ __launch_bounds__(256) void bnact_bwd_k(const mc_bnact_args p) {
                 unpack8(xv, x);
                 unpack8(gv, g);
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    float d = MA ? g[q] * mulv[q] + addv[q] : g[q] * rs;
-                    if (ACT) d *= silu_grad_f(x[q] * s[q] + t[q]);
-                    dz[q] = d;
+                for (int q = 0; q < 8; q += 2) {
+                    f32x2_t d = MA ? __builtin_elementwise_fma(f32x2_t{g[q], g[q + 1]}, f32x2_t{mulv[q], mulv[q + 1]}, f32x2_t{addv[q], addv[q + 1]})
+                                   : f32x2_t{g[q], g[q + 1]} * f32x2_t{rs, rs};
+                    if (ACT) d = d * silu_grad2_f(__builtin_elementwise_fma(f32x2_t{x[q], x[q + 1]}, f32x2_t{s[q], s[q + 1]}, f32x2_t{t[q], t[q + 1]}));
+                    dz[q] = d.x; dz[q + 1] = d.y;
                 }
                 if (APPLY) {
 #pragma unroll

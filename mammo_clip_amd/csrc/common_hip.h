@@ -72,13 +72,36 @@ __device__ __forceinline__ uint4 nt_load16(const void* p) {
     return make_uint4(w.x, w.y, w.z, w.w);
 }
 
-// v_exp_f32 + v_rcp_f32 (1 ulp): no IEEE division sequence on the streaming paths
-__device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+// v_exp_f32 + v_rcp_f32 (1 ulp): no IEEE division sequence on the streaming paths.
+// The streaming kernels run at 2-3 waves per SIMD, where every VALU instruction costs the same ~5 issue cycles whether it
+// is packed or not (scripts/valu_dep_ubench.hip): the arithmetic AROUND the two transcendentals is therefore written on
+// fp32 PAIRS (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32) -- 7 instructions per two sigmoids instead of 10.  The scalar
+// forms evaluate the same expression, bit for bit.
+#define MC_NLOG2E -1.4426950408889634f
+__device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * MC_NLOG2E)); }
 __device__ __forceinline__ float silu_f(float x) { return x * sigmoid_f(x); }
 // d silu(z)/dz = s(1 + z(1-s))  (efficient_net_custom_utils.py:71-75)
 __device__ __forceinline__ float silu_grad_f(float z) {
     float s = sigmoid_f(z);
     return s * (1.0f + z * (1.0f - s));
+}
+__device__ __forceinline__ f32x2_t sigmoid2_f(f32x2_t z) {
+    const f32x2_t t = z * f32x2_t{MC_NLOG2E, MC_NLOG2E};
+    const f32x2_t d = f32x2_t{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)} + f32x2_t{1.f, 1.f};
+    return f32x2_t{__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+}
+__device__ __forceinline__ f32x2_t silu2_f(f32x2_t z) { return z * sigmoid2_f(z); }
+__device__ __forceinline__ f32x2_t silu_grad2_f(f32x2_t z) {
+    const f32x2_t s = sigmoid2_f(z);
+    return s * __builtin_elementwise_fma(z, f32x2_t{1.f, 1.f} - s, f32x2_t{1.f, 1.f});
+}
+// f[q] = silu(f[q] * s[q] + t[q]), q < 8
+__device__ __forceinline__ void bn_silu8(float* f, const float* s, const float* t) {
+#pragma unroll
+    for (int q = 0; q < 8; q += 2) {
+        const f32x2_t z = silu2_f(__builtin_elementwise_fma(f32x2_t{f[q], f[q + 1]}, f32x2_t{s[q], s[q + 1]}, f32x2_t{t[q], t[q + 1]}));
+        f[q] = z.x; f[q + 1] = z.y;
+    }
 }
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 __device__ __forceinline__ float gelu_grad_f(float x) {

@@ -275,8 +275,7 @@ __global__ __launch_bounds__(256, (K == 3 && S == 1 && !EPI ? 3 : 2)) void dwcon
                 if (has_pro && real) {
                     float f[8];
                     unpack8(val, f);
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) f[q] = silu_f(f[q] * ps[q] + pt[q]);
+                    bn_silu8(f, ps, pt);
                     val = pack8(f);
                 }
                 *reinterpret_cast<uint4*>(smem + ((meta[i] >> 16) << 4)) = val;
@@ -385,7 +384,7 @@ __global__ __launch_bounds__(256, (K == 3 && S == 1 && !EPI ? 3 : 2)) void dwcon
                                         if constexpr (CPL == 4) ew = h == 0 ? ev[i].x : ev[i].y; else ew = ev[i];
                                         const f32x2_t e2 = {bf_lo(ew), bf_hi(ew)};
                                         const f32x2_t z = __builtin_elementwise_fma(e2, e_sc[h], e_sh[h]);
-                                        const f32x2_t dz = {acc[i][sl][h].x * silu_grad_f(z.x), acc[i][sl][h].y * silu_grad_f(z.y)};
+                                        const f32x2_t dz = acc[i][sl][h] * silu_grad2_f(z);
                                         o2[h] = pack_bf2(dz.x, dz.y);
                                         const f32x2_t r = {bf_lo(o2[h]), bf_hi(o2[h])};  // reductions of the stored (rounded) dZ0
                                         ssum[h] += r;
@@ -584,8 +583,7 @@ __global__ __launch_bounds__(256, 2) void dwconv_march_bww_kernel(const mc_dwcon
                 if (has_pro && real) {
                     float f[8];
                     unpack8(val, f);
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) f[q] = silu_f(f[q] * ps[q] + pt[q]);
+                    bn_silu8(f, ps, pt);
                     val = pack8(f);
                 }
                 *reinterpret_cast<uint4*>(smem + ((meta[i] >> 16) << 4)) = val;
@@ -963,7 +961,8 @@ __global__ __launch_bounds__(256, 2) void dwconv_march_bwd_s2_kernel(const mc_dw
                                                     const f32x2_t e2 = {bf_lo(ew), bf_hi(ew)};
                                                     const f32x2_t z = __builtin_elementwise_fma(e2, e_sc[h], e_sh[h]);
                                                     const f32x2_t a2 = acc[sl][i][f * 2 + e][h];
-                                                    o2[h] = pack_bf2(a2.x * silu_grad_f(z.x), a2.y * silu_grad_f(z.y));
+                                                    const f32x2_t dz2 = a2 * silu_grad2_f(z);
+                                                    o2[h] = pack_bf2(dz2.x, dz2.y);
                                                     const f32x2_t r = {bf_lo(o2[h]), bf_hi(o2[h])};     // reductions of the stored (rounded) dZ0
                                                     ssum[h] += r;
                                                     ssq[h] = __builtin_elementwise_fma(r, e2, ssq[h]);

@@ -38,8 +38,7 @@ __device__ __forceinline__ uint4 apply_prologue(uint4 v, const mc_gemm_args& p, 
         float s[8], t[8];
         load8f(p.pro_scale + ch0, s);
         load8f(p.pro_shift + ch0, t);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) f[i] = silu_f(f[i] * s[i] + t[i]);
+        bn_silu8(f, s, t);
     }
     if (p.pro_gate) {
         long long img = pix / p.pro_rows_per_img;

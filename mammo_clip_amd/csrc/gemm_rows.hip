@@ -134,8 +134,7 @@ __global__ __launch_bounds__(256, 2) void gemm_rows_kernel(const mc_gemm_rows_ar
                         unpack8(xf[rg][kc], f);
                         load8f(sScale + k, s);
                         load8f(sShift + k, t);
-#pragma unroll
-                        for (int q = 0; q < 8; ++q) f[q] = silu_f(f[q] * s[q] + t[q]);
+                        bn_silu8(f, s, t);
                         if (gate) {
                             float gv[8];
                             load8f(gate + k, gv);

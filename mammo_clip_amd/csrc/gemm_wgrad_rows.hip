@@ -127,8 +127,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_rows_kernel(const mc_wgrad_rows_
                     unpack8(v, f);
                     load8f(spro + cc8, sc);
                     load8f(spro + p.K + cc8, sh);
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) f[q] = silu_f(f[q] * sc[q] + sh[q]);
+                    bn_silu8(f, sc, sh);
                     if (p.pro_gate) {
                         float gv[8];
                         load8f(sgate + par * p.K + cc8, gv);
