@@ -62,14 +62,14 @@ RIDGE = MFMA_PEAK_TFS * 1e12 / (HBM_PEAK_GBS * 1e9)      # flop per byte above w
 
 # entry point (+ shape class) -> the kernel behind it, for the report
 KERNEL_NAMES = {
-    "mc_bnact_bwd_apply": "bnact_bwd_k<true> (BatchNorm+SiLU backward apply pass: dx = A*dz + B*x + C)",
-    "mc_bnact_bwd_reduce": "bnact_bwd_k<false> (BatchNorm backward reduce pass)",
+    "mc_bnact_bwd_apply": "bnact_bwd_k<true, ACT, MA> (BatchNorm(+SiLU) backward apply pass: dx = A*dz + B*x + C; all three instantiations)",
+    "mc_bnact_bwd_reduce": "bnact_bwd_k<false, ACT, MA> (BatchNorm backward reduce pass)",
     "mc_bnact_se_sums": "bnact_se_sums_k (SE-gate gradient + BatchNorm1 backward sums, one pass over (d, dA1))",
     "mc_bnact_pool": "bnact_img_reduce_k (BN+SiLU + squeeze-excite average pool)",
     "mc_bnact_apply": "bnact_apply_k (BatchNorm2 + drop-connect + residual)",
     "mc_dwconv_fwd": "dwconv_march_fwd_kernel (depthwise conv forward / stride-1 data gradient, marching LDS kernel)",
     "mc_dwconv_bwd_weight": "dwconv_march_bww_kernel (depthwise conv weight gradient)",
-    "mc_dwconv_bwd_data": "dwconv_march_bwd_s2_kernel (depthwise conv stride-2 data gradient)",
+    "mc_dwconv_bwd_data": "dwconv_march_bwd_s2_kernel (depthwise conv stride-2 data gradient, with the BatchNorm0+SiLU backward epilogue)",
     "mc_gemm_rows_bf16": "gemm_rows_kernel (row-streaming 1x1 conv forward / data gradient, weights resident in LDS)",
     "mc_wgrad_rows_bf16": "wgrad_rows_kernel (row-streaming 1x1 conv weight gradient, LDS transpose-reads)",
     "mc_gemm_bf16|glnt256": "g8::gemm8p_kernel (plain NT 256x256x64 MFMA tiles, 8 waves, 4 phases per K tile, LDS-direct DMA)",

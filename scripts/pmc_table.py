@@ -47,7 +47,7 @@ with open(os.path.join(dst, f"{tag}_cfg3_pmc_by_kernel.csv"), "w") as f:
     for r in rows:
         w.writerow([r[0], round(r[1], 2), r[2], round(r[3], 1), round(r[4], 1), round(r[5], 1), round(r[6], 2), round(r[7], 3)])
 # bench.py's timing classes whose launches map onto ONE rocprof kernel name: HBM bytes per launch (read + write)
-cls = {"mc_bnact_bwd_apply": "bnact_bwd_k<true>", "mc_gemm_bf16:|glnt256": "g8::gemm8p_kernel", "mc_gemm_bf16:|tn256": "g8t::gemm256_tn_kernel",
+cls = {"mc_bnact_bwd_apply": "bnact_bwd_k<true", "mc_gemm_bf16:|glnt256": "g8::gemm8p_kernel", "mc_gemm_bf16:|tn256": "g8t::gemm256_tn_kernel",
        "mc_gemm_bf16:|glnt": "gemm_kernel<128, 128, 64, 2, 2, 0, 0, false, true>", "mc_bnact_se_sums": "bnact_se_sums_k",
        "mc_bnact_pool": "bnact_img_reduce_k",
        # row-streaming 1x1 convolutions: forward and data-gradient launches are the same template family in rocprof's names,
