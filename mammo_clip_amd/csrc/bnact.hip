@@ -673,12 +673,25 @@ extern "C" int mc_bnact_apply(const mc_bnact_args* a, void* stream) {
     return MC_OK;
 }
 // out[i] = sum over splits of ws[split][i], in split order (deterministic, unlike float atomics)
+// 64 elements x 4 split-lanes per workgroup (the old one-thread-per-element loop ran 64 dependent-latency loads per
+// thread on 150 workgroups: 1 TB/s); the four partials of an element are combined in lane order -- deterministic
 __global__ __launch_bounds__(256) void split_sum_k(const float* __restrict__ ws, float* __restrict__ out, long long n, int splits) {
-    long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
+    __shared__ float sh[4][64];
+    const int el = threadIdx.x & 63, pl = threadIdx.x >> 6;
+    const long long i = (long long)blockIdx.x * 64 + el;
     float s = 0.f;
-    for (int k = 0; k < splits; ++k) s += ws[(long long)k * n + i];
-    out[i] = s;
+    if (i < n) {
+        int k = pl;
+        for (; k + 12 < splits; k += 16) {                    // four independent loads in flight
+            const float a = ws[(long long)k * n + i], b = ws[(long long)(k + 4) * n + i];
+            const float c = ws[(long long)(k + 8) * n + i], d = ws[(long long)(k + 12) * n + i];
+            s += a; s += b; s += c; s += d;
+        }
+        for (; k < splits; k += 4) s += ws[(long long)k * n + i];
+    }
+    sh[pl][el] = s;
+    __syncthreads();
+    if (pl == 0 && i < n) out[i] = ((sh[0][el] + sh[1][el]) + sh[2][el]) + sh[3][el];
 }
 // row splits per image of the per-image reductions: enough workgroups to fill the chip (target / n_img), but not so many
 // that a workgroup's stream gets short.  Measured on the B5 shapes: the one-tensor pool pass is best around 1024
@@ -706,7 +719,7 @@ extern "C" int mc_bnact_pool(const mc_bnact_args* a, void* stream) {
     MC_LAUNCH_CHECK();
     if (sp > 1) {
         long long n = p.n_img * p.c;
-        hipLaunchKernelGGL(split_sum_k, dim3(mc_div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, p.split_ws, p.pooled, n, sp);
+        hipLaunchKernelGGL(split_sum_k, dim3(mc_div_up(n, 64)), dim3(256), 0, (hipStream_t)stream, p.split_ws, p.pooled, n, sp);
         MC_LAUNCH_CHECK();
     }
     return MC_OK;
@@ -721,7 +734,7 @@ extern "C" int mc_bnact_se_dgate(const mc_bnact_args* a, void* stream) {
     MC_LAUNCH_CHECK();
     if (sp > 1) {
         long long n = p.n_img * p.c;
-        hipLaunchKernelGGL(split_sum_k, dim3(mc_div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, p.split_ws, p.dgate, n, sp);
+        hipLaunchKernelGGL(split_sum_k, dim3(mc_div_up(n, 64)), dim3(256), 0, (hipStream_t)stream, p.split_ws, p.dgate, n, sp);
         MC_LAUNCH_CHECK();
     }
     return MC_OK;
@@ -736,7 +749,7 @@ extern "C" int mc_bnact_se_sums(const mc_bnact_args* a, void* stream) {
     MC_LAUNCH_CHECK();
     if (sp > 1) {
         long long n = 5 * p.n_img * p.c;
-        hipLaunchKernelGGL(split_sum_k, dim3(mc_div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, p.split_ws, p.dgate, n, sp);
+        hipLaunchKernelGGL(split_sum_k, dim3(mc_div_up(n, 64)), dim3(256), 0, (hipStream_t)stream, p.split_ws, p.dgate, n, sp);
         MC_LAUNCH_CHECK();
     }
     return MC_OK;

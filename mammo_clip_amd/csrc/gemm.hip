@@ -722,7 +722,19 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, int splits, l
     if (i + 4 <= mn && (n & 3) == 0) {
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
         const int col = (int)(i % n);
-        for (int k = 0; k < splits; ++k) {
+        int k = 0;
+        if (!scale)
+            for (; k + 3 < splits; k += 4) {           // four independent 16-byte loads in flight, summed in split order
+                const float4 v0 = *reinterpret_cast<const float4*>(ws + (long long)k * mn + i);
+                const float4 v1 = *reinterpret_cast<const float4*>(ws + (long long)(k + 1) * mn + i);
+                const float4 v2 = *reinterpret_cast<const float4*>(ws + (long long)(k + 2) * mn + i);
+                const float4 v3 = *reinterpret_cast<const float4*>(ws + (long long)(k + 3) * mn + i);
+                s.x += v0.x; s.y += v0.y; s.z += v0.z; s.w += v0.w;
+                s.x += v1.x; s.y += v1.y; s.z += v1.z; s.w += v1.w;
+                s.x += v2.x; s.y += v2.y; s.z += v2.z; s.w += v2.w;
+                s.x += v3.x; s.y += v3.y; s.z += v3.z; s.w += v3.w;
+            }
+        for (; k < splits; ++k) {
             float4 v = *reinterpret_cast<const float4*>(ws + (long long)k * mn + i);
             if (scale) {
                 const float4 g = *reinterpret_cast<const float4*>(scale + (long long)(k / sub) * n + col);
