@@ -563,6 +563,7 @@ __global__ __launch_bounds__(256) void se_bwd_hidden_k(const float* __restrict__
     const float* pv = pooled + (long long)img * c;
     float* wsi = ws + (long long)img * (c + 2 * cs);
     float s = 0.f, d = 0.f;
+#pragma unroll 4
     for (int i = lane; i < c; i += 64) {
         s += w1[(long long)j * c + i] * pv[i];
         d += w2[(long long)i * cs + j] * wsi[i];
@@ -599,12 +600,14 @@ __global__ void se_wgrad_k(const float* __restrict__ pooled, const float* __rest
     if (e < n1) {                       // dw2[ci, j] = sum_n ds[n,ci] * r[n,j]
         int ci = (int)(e / cs), j = (int)(e % cs);
         float s = 0.f;
+#pragma unroll 8
         for (int i = 0; i < n; ++i) s += ws[i * stride + ci] * ws[i * stride + c + j];
         dw2[e] = s;
     } else if (e < 2 * n1) {            // dw1[j, ci] = sum_n du[n,j] * pooled[n,ci]
         long long e2 = e - n1;
         int j = (int)(e2 / c), ci = (int)(e2 % c);
         float s = 0.f;
+#pragma unroll 8
         for (int i = 0; i < n; ++i) s += ws[i * stride + c + cs + j] * pooled[(long long)i * c + ci];
         dw1[e2] = s;
     } else if (e < 2 * n1 + c) {

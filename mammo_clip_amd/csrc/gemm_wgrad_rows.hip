@@ -189,8 +189,15 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, int parts, lon
     const int el = threadIdx.x & 15, pl = threadIdx.x >> 4;
     const long long i = (long long)blockIdx.x * 16 + el;
     float s = 0.f;
-    if (i < nk)
-        for (int k = pl; k < parts; k += 16) s += ws[(long long)k * nk + i];
+    if (i < nk) {
+        int k = pl;
+        for (; k + 48 < parts; k += 64) {                     // four independent loads in flight, summed in part order
+            const float a = ws[(long long)k * nk + i], b = ws[(long long)(k + 16) * nk + i];
+            const float c = ws[(long long)(k + 32) * nk + i], d = ws[(long long)(k + 48) * nk + i];
+            s += a; s += b; s += c; s += d;
+        }
+        for (; k < parts; k += 16) s += ws[(long long)k * nk + i];
+    }
     sh[pl][el] = s;
     __syncthreads();
     if (pl != 0 || i >= nk) return;

@@ -262,8 +262,15 @@ __global__ void colsum_final_k(const float* __restrict__ partials, int rows, int
     const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
     const int i = blockIdx.x * 16 + cl;
     double s = 0.0;
-    if (i < c)
-        for (int r = rl; r < rows; r += 16) s += (double)partials[(long long)r * c + i];
+    if (i < c) {
+        int r = rl;
+        for (; r + 48 < rows; r += 64) {                      // four independent loads in flight, summed in row order
+            const float a = partials[(long long)r * c + i], b = partials[(long long)(r + 16) * c + i];
+            const float d = partials[(long long)(r + 32) * c + i], e = partials[(long long)(r + 48) * c + i];
+            s += (double)a; s += (double)b; s += (double)d; s += (double)e;
+        }
+        for (; r < rows; r += 16) s += (double)partials[(long long)r * c + i];
+    }
     sh[rl][cl] = s;
     __syncthreads();
     if (rl != 0 || i >= c) return;
@@ -372,7 +379,7 @@ extern "C" int mc_colsum_rows(long long m, int c) {
     int rpb = 256 / (cvp > 0 ? cvp : 1);
     long long blocks = (m + (long long)rpb * 16 - 1) / ((long long)rpb * 16);
     if (blocks < 1) blocks = 1;
-    if (blocks > 1024) blocks = 1024;
+    if (blocks > 512) blocks = 512;            // two workgroups per CU; the finishing kernel reads `blocks` rows per column
     return (int)blocks;
 }
 extern "C" int mc_colsum_bf16(const mc_bf16* x, long long m, int c, long long ld, float* partials, float* out,
