@@ -172,7 +172,7 @@ def main():
                          "0 = 2 for the global-batch workloads at <= 512 pairs per GPU (2 x 32 pairs = 232 GB of the 288 GB), 1 otherwise")
     ap.add_argument("--recompute", type=int, default=-1, choices=(-1, 0, 1, 2, 3),
                     help="MBConv activation recompute mode (EfficientNet.set_recompute); -1 = chosen with --keep-graphs")
-    ap.add_argument("--keep-kept", type=int, default=6, help="kept mode-2 graphs of the N = 1 / 2 global-batch runs")
+    ap.add_argument("--keep-kept", type=int, default=8, help="kept mode-2 graphs of the N = 1 / 2 global-batch runs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-n8-load", action="store_true", help="skip the n8_load block of the default N = 1 run")
     ap.add_argument("--fp8", action="store_true", help="fp8 (e4m3) operands for the late-stage 1x1 convolutions (config #5 arithmetic on any workload)")
@@ -227,8 +227,9 @@ def main():
     if args.keep_graphs <= 0 and args.recompute < 0 and strong and b <= 256:
         args.keep_graphs, args.recompute = args.micro_batches, (3 if b <= 128 else 2)
     elif args.keep_graphs <= 0 and args.recompute < 0 and strong:
-        # N = 1 / 2 (round 3): SIX kept graphs in recompute mode 2 (28 GB each; their backward pays the rebuild of e and d,
-        # ~32 ms, and saves a ~90 ms forward), the re-forwarded micro-batches stay in mode 0 (Trainer.keep_recompute)
+        # N = 1 / 2 (round 3): EIGHT kept graphs in recompute mode 2 (25 GB each; their backward pays the rebuild of e and d,
+        # ~32 ms, and saves a ~90 ms forward), the re-forwarded micro-batches stay in mode 0 (Trainer.keep_recompute);
+        # 252 GB peak at N = 1 (6 kept: 199 GB, 0.9 % slower; 9 kept: 278 GB -- too close to the device's 288 GB)
         args.keep_graphs, keep_recompute = args.keep_kept, 2
     if args.keep_graphs <= 0:
         args.keep_graphs = 2 if (strong and b <= 512) else 1
