@@ -131,8 +131,30 @@ typedef struct mc_gemm_rows_args {
     long long pro_rows_per_img;
     float* stat_partials;
     const float* bias;       /* optional float[N], added to every output row (after the statistics, with the residual) */
+    /* Fused elementwise epilogues for the DATA GRADIENT of an MBConv projection conv (round 3).  G = X.W^T is d loss / d (gated
+     * activation) [ref: efficientnet_custom.py:117-122 backwards]; it is rounded to bf16 like the stored tensor would be but never
+     * goes to memory (N <= 256, K <= 128, no residual / bias / statistics / prologue):
+     *   epi_mode 1: the five per-image sums of mc_bnact_se_sums over (epi_x, G) -> epi_sums [5][n_img][N]; C is not written;
+     *   epi_mode 2: mc_bnact_bwd_apply on (epi_x, G): C = coef0*dz + coef1*epi_x + coef2,
+     *               dz = (G * epi_mul[img] + epi_add[img] * epi_add_scale) * silu'(epi_x * epi_scale + epi_shift).
+     * epi_x [M,N] (leading dimension epi_ldx) = the depthwise conv output in front of BatchNorm1; epi_rows_per_img % 16 == 0. */
+    int epi_mode;
+    const mc_bf16* epi_x;
+    long long epi_ldx;
+    long long epi_rows_per_img;
+    const float* epi_scale;
+    const float* epi_shift;
+    const float* epi_mean;
+    const float* epi_invstd;
+    const float* epi_coef;   /* [3][N] (mc_bn_bwd_finalize) */
+    const float* epi_mul;    /* [n_img][N] */
+    const float* epi_add;    /* [n_img][N] */
+    float epi_add_scale;
+    float* epi_sums;         /* epi_mode 1: [5][n_img][N] */
+    float* epi_ws;           /* epi_mode 1: float[mc_gemm_rows_epi_ws_floats(args)] */
 } mc_gemm_rows_args;
 int mc_gemm_rows_supported(int n, int k);
+long long mc_gemm_rows_epi_ws_floats(const mc_gemm_rows_args* args);
 int mc_gemm_rows_blocks(const mc_gemm_rows_args* args);     /* persistent workgroups of the launch = rows of stat_partials */
 int mc_gemm_rows_bf16(const mc_gemm_rows_args* args, void* stream);
 

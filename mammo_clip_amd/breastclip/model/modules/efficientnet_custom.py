@@ -113,6 +113,7 @@ def _bn_stats(partials, count, bn: nn.BatchNorm2d, training: bool):
 
 # expanded-tensor bytes per call from which the BatchNorm0 backward is folded into the expand conv's gradient GEMMs
 # (ops.bn_fold_expand_bwd) instead of running the apply pass; tests set it to 0 to exercise the folded path at small sizes
+FUSE_PROJ_DGRAD = os.environ.get("MC_FUSE_PROJ_DGRAD", "1") != "0"        # projection data gradient with the SE / BatchNorm1 backward in its epilogue (ops.proj_dgrad_*)
 BN_FOLD_MIN_BYTES = int(os.environ.get("MC_BN_FOLD_MIN_BYTES", 400_000_000))
 BN_FOLD_S2_MIN_BYTES = int(os.environ.get("MC_BN_FOLD_S2_MIN_BYTES", 0))
 
@@ -244,7 +245,12 @@ class _MBConvFn(torch.autograd.Function):
         dp, dg2, db2 = ops.bnact_bwd(p, n, ohw, a.cout, st2, blk._bn2.weight, 0, g=dy, rowscale=sv["rowscale"])
         # project 1x1: p = A1 . wp^T, A1 = silu(bn1(d)) * gate   (A1 is recomputed inside the wgrad GEMM)
         wp_t = ops.cast_transpose_bf16(blk._project_conv.weight.view(a.cout, a.cexp))      # [cexp, cout]
-        da1 = ops.linear_dgrad(dp, sv["wp"], w_t=wp_t)
+        # Early stages (row-streaming shapes, whole 16-row groups per image): dA1 = dp . wp never goes to memory -- the
+        # projection's data-gradient GEMM runs TWICE with an elementwise epilogue over d, first for the squeeze-excite /
+        # BatchNorm1 sums, then (once the SE backward has produced d loss / d pooled) for the BatchNorm1 + swish backward
+        # itself: 1 + 2 passes over the depthwise-site tensor instead of 1 (dgrad) + 2 (sums) + 3 (apply)
+        fuse = FUSE_PROJ_DGRAD and ops.proj_dgrad_fusable(n * ohw, a.cexp, a.cout, ohw)
+        da1 = None if fuse else ops.linear_dgrad(dp, sv["wp"], w_t=wp_t)
         if act1 is not None:
             dwp = ops.linear_wgrad(dp, act1, pro=(None, None, gate, ohw))
             del act1
@@ -252,14 +258,18 @@ class _MBConvFn(torch.autograd.Function):
             dwp = ops.linear_wgrad(dp, d, pro=(st1.scale, st1.shift, gate, ohw))
         # squeeze-excite
         # ONE pass over (d, dA1) yields d loss / d gate AND the ingredients of the bn1-backward reductions
-        sums = ops.bnact_se_sums(d, da1, n, ohw, a.cexp, st1, 1)
+        sums = ops.proj_dgrad_se_sums(dp, wp_t, d, st1, n, ohw) if fuse else ops.bnact_se_sums(d, da1, n, ohw, a.cexp, st1, 1)
         dpooled, dw1, db1, dw2, dbse2 = ops.se_bwd(pooled, gate, sums[0], blk._se_reduce.weight.view(a.cse, a.cexp),
                                                    blk._se_reduce.bias, blk._se_expand.weight.view(a.cexp, a.cse),
                                                    blk._se_expand.bias)
         # bn1 + swish: upstream of swish output = dA1 * gate + dpooled / (oh*ow)
         part1 = ops.bn_partials_from_se_sums(sums, gate, dpooled, 1.0 / ohw)
-        dd, dg1, db1n = ops.bnact_bwd(d, n, ohw, a.cexp, st1, blk._bn1.weight, 1, g=da1, mul=gate, add=dpooled,
-                                      add_scale=1.0 / ohw, partials=part1)
+        if fuse:
+            coef1, dg1, db1n = ops.bn_bwd_coefs(part1, n * ohw, st1, blk._bn1.weight)
+            dd = ops.proj_dgrad_bn_apply(dp, wp_t, d, st1, coef1, gate, dpooled, 1.0 / ohw, ohw)
+        else:
+            dd, dg1, db1n = ops.bnact_bwd(d, n, ohw, a.cexp, st1, blk._bn1.weight, 1, g=da1, mul=gate, add=dpooled,
+                                          add_scale=1.0 / ohw, partials=part1)
         del da1
         # depthwise
         del d

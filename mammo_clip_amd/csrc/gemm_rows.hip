@@ -20,7 +20,14 @@ namespace {
 
 // FN = output fragments (exact: ceil(N/16)), KC = 32-wide K chunks (padded), RG = 16-row groups per wave iteration,
 // PF = iterations in flight per wave
-template <int FN, int KC, int PF, int RG>
+// EPI (round 3) -- fused elementwise epilogues for the data gradient of an MBConv projection conv, G = dP . Wp (the gradient
+// of the SE-gated activation): G is rounded to bf16 exactly like the stored tensor was, but never goes to memory.
+//   EPI = 1: the five per-image sums of mc_bnact_se_sums over (epi_x = depthwise output d, G); nothing is stored
+//   EPI = 2: mc_bnact_bwd_apply on (d, G): C = k0*dz + k1*d + k2, dz = (G*mul[img] + add[img]) * silu'(d*scale + shift)
+// Against dgrad -> se_sums -> apply (1 + 2 + 3 passes over the depthwise-site tensor) the two launches make 1 + 2.
+// Waves take contiguous row ranges (an image change happens at most once per wave: rows_per_img % 16 == 0, so a 16-row group
+// never straddles images); the d rows of the NEXT group are prefetched into registers while this one is computed.
+template <int FN, int KC, int PF, int RG, int EPI = 0>
 __global__ __launch_bounds__(256, 2) void gemm_rows_kernel(const mc_gemm_rows_args p, const int nblocks, const int ntiles) {
     constexpr int NP = FN * 16;                    // padded output width
     constexpr int CROW = (NP + 8) * 2;             // staging row bytes
@@ -31,6 +38,8 @@ __global__ __launch_bounds__(256, 2) void gemm_rows_kernel(const mc_gemm_rows_ar
     unsigned char* sC = reinterpret_cast<unsigned char*>(sShift + KC * 32);   // [4 waves][16][CROW]
     constexpr int SC_BYTES = (4 * 16 * CROW > 4 * 64 * 16 * 4) ? 4 * 16 * CROW : 4 * 64 * 16 * 4;
     float* sGate = reinterpret_cast<float*>(sC + SC_BYTES);                   // [4 waves][2 images][KC*32]: SE gate rows
+    float* sFlush = sGate;                                                    // EPI = 1 (no gate prologue there): [4 waves][64 lanes][8]
+    float* sPar = sFlush + 4 * 64 * 8;                                        // EPI = 1: scale | shift | mean | invstd, 256 floats each
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // Wide outputs (N > 256, K small) are split into column tiles of FN*16: every tile's workgroup keeps ITS slice of
     // the weights in LDS and streams the same rows.  The column tiles of one row-block index get consecutive slots on
@@ -68,7 +77,7 @@ __global__ __launch_bounds__(256, 2) void gemm_rows_kernel(const mc_gemm_rows_ar
     // fetched from global memory for every 16-byte chunk of every row -- those two extra vector-memory instructions per
     // activation load were the whole cost of the gated form (2.77 M x 40 x 240: 0.50 -> 0.40 ms, block-cyclic by 4: 0.44).
     const long long nwaves = (long long)nblocks * 4;
-    const bool cyc = p.pro_gate == nullptr;
+    const bool cyc = EPI == 0 && p.pro_gate == nullptr;
     const long long wid = (long long)bxr * 4 + wave;
     const long long gpw = (ngroups + nwaves - 1) / nwaves;
     const long long my_end = (wid + 1) * gpw < ngroups ? (wid + 1) * gpw : ngroups;       // contiguous form: this wave's range end
@@ -97,7 +106,73 @@ __global__ __launch_bounds__(256, 2) void gemm_rows_kernel(const mc_gemm_rows_ar
     float ssum[8], ssq[8], bias8[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) { ssum[q] = 0.f; ssq[q] = 0.f; bias8[q] = 0.f; }
-    if (p.bias && ep_active) load8f(p.bias + n0 + c8 * 8, bias8);
+    if (EPI == 0 && p.bias && ep_active) load8f(p.bias + n0 + c8 * 8, bias8);
+
+    // ---- EPI state (dead code for EPI = 0)
+    constexpr int SLOTS_MIN = 64 / (2 * FN);                // slots = 64 / cpr, cpr <= 2 * FN
+    constexpr int XCH = (16 + SLOTS_MIN - 1) / SLOTS_MIN;   // 16-byte chunks of a 16-row group a lane handles: ceil(16 / slots)
+    float es[8], et[8], e0[8], e1[8], e2[8], emul[8], eadd[8], acc5[5][8];
+    uint4 xe[PF][RG][XCH];                                  // d rows of the PF iterations in flight (slot u is reloaded as soon as its epilogue is done)
+    long long img_cur = -1, img_end = 0;                    // image of the rows being processed, first row of the next image
+    int eslot = 0;                                          // EPI = 1: workspace slot (0 / 1) of the image being accumulated
+    if constexpr (EPI != 0) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { es[q] = et[q] = e0[q] = e1[q] = e2[q] = emul[q] = eadd[q] = 0.f; }
+#pragma unroll
+        for (int k = 0; k < 5; ++k)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc5[k][q] = 0.f;
+        if constexpr (EPI == 1) {
+            // the sums form carries 40 accumulator registers per lane: its four BatchNorm vectors live in LDS and are
+            // re-read per 16-byte chunk (four ds_read_b128 beside ~50 VALU instructions)
+            for (int i = tid; i < 256; i += 256) {
+                const bool ok = i < p.N;
+                sPar[i] = ok ? p.epi_scale[i] : 0.f; sPar[256 + i] = ok ? p.epi_shift[i] : 0.f;
+                sPar[512 + i] = ok ? p.epi_mean[i] : 0.f; sPar[768 + i] = ok ? p.epi_invstd[i] : 0.f;
+            }
+            __syncthreads();
+        } else if (ep_active) {
+            load8f(p.epi_scale + c8 * 8, es);
+            load8f(p.epi_shift + c8 * 8, et);
+            load8f(p.epi_coef + c8 * 8, e0); load8f(p.epi_coef + p.N + c8 * 8, e1); load8f(p.epi_coef + 2 * p.N + c8 * 8, e2);
+        }
+    }
+    // d rows of iteration g for this lane's (row slot, chunk) role; unconditional loads (clamped addresses)
+    auto load_x = [&](uint4 (&x)[RG][XCH], long long g) __attribute__((always_inline)) {
+#pragma unroll
+        for (int rg = 0; rg < RG; ++rg)
+#pragma unroll
+            for (int u = 0; u < XCH; ++u) {
+                const int row = rs + u * slots;
+                long long m = (g * RG + rg) * 16 + (row < 16 ? row : 0);
+                if (m >= p.M) m = p.M - 1;
+                x[rg][u] = *reinterpret_cast<const uint4*>(p.epi_x + m * p.epi_ldx + (ep_active ? c8 : 0) * 8);
+            }
+    };
+    // EPI = 1: the wave's sums of the image just finished -> workspace slot (row slots combined through LDS, fixed order)
+    auto flush_sums = [&]() __attribute__((always_inline)) {
+        float* red = sFlush + wave * 64 * 8;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) red[lane * 8 + q] = ep_active ? acc5[k][q] : 0.f;
+            __builtin_amdgcn_wave_barrier();
+            if (ep_active && rs == 0) {
+                float* dst = p.epi_ws + ((wid * 2 + eslot) * 5 + k) * p.N + c8 * 8;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    float sm = 0.f;
+                    for (int r = 0; r < slots; ++r) sm += red[(r * cpr + c8) * 8 + q];
+                    dst[q] = sm;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc5[k][q] = 0.f;
+        }
+        if (lane == 0) reinterpret_cast<int*>(p.epi_ws + (long long)nwaves * 2 * 5 * p.N)[wid * 2 + eslot] = (int)img_cur;
+        ++eslot;
+    };
 
     // PF 32-row groups per wave are in flight (narrow K = few bytes per group: latency needs several groups ahead)
     uint4 xn[PF][RG][KC];
@@ -115,8 +190,8 @@ __global__ __launch_bounds__(256, 2) void gemm_rows_kernel(const mc_gemm_rows_ar
             }
         }
     };
-    auto process = [&](long long g, uint4 (&xf)[RG][KC]) {
-        if (has_pro) {
+    auto process = [&](long long g, uint4 (&xf)[RG][KC], uint4 (&xd)[RG][XCH]) __attribute__((always_inline)) {
+        if (EPI == 0 && has_pro) {
 #pragma unroll
             for (int rg = 0; rg < RG; ++rg) {
                 long long m = (g * RG + rg) * 16 + mrow;
@@ -177,6 +252,61 @@ __global__ __launch_bounds__(256, 2) void gemm_rows_kernel(const mc_gemm_rows_ar
                 *reinterpret_cast<uint2*>(myC + mrow * CROW + (f * 16 + kg * 4) * 2) = pk;
             }
             __builtin_amdgcn_wave_barrier();
+            if constexpr (EPI != 0) {
+                if (mbase >= img_end) {                     // (wave-uniform) the group starts a new image
+                    if (EPI == 1 && img_cur >= 0) flush_sums();
+                    img_cur = mbase / p.epi_rows_per_img;
+                    img_end = (img_cur + 1) * p.epi_rows_per_img;
+                    if (EPI == 2 && ep_active) {
+                        load8f(p.epi_mul + img_cur * p.N + c8 * 8, emul);
+                        load8f(p.epi_add + img_cur * p.N + c8 * 8, eadd);
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) eadd[q] *= p.epi_add_scale;
+                    }
+                }
+                if (ep_active) {
+#pragma unroll
+                    for (int u = 0; u < XCH; ++u) {
+                        const int row = rs + u * slots;
+                        const long long m = mbase + row;
+                        if (row < 16 && m < p.M) {
+                            float gq8[8], x[8];
+                            unpack8(*reinterpret_cast<const uint4*>(myC + row * CROW + c8 * 16), gq8);     // G, bf16-rounded
+                            unpack8(xd[rg][u], x);
+                            if constexpr (EPI == 1) {
+                                load8f(sPar + c8 * 8, es); load8f(sPar + 256 + c8 * 8, et);
+                                load8f(sPar + 512 + c8 * 8, e0); load8f(sPar + 768 + c8 * 8, e1);
+#pragma unroll
+                                for (int q = 0; q < 8; q += 2) {                 // (same arithmetic as bnact_se_sums_k)
+                                    const f32x2_t one = {1.f, 1.f};
+                                    const f32x2_t xv = {x[q], x[q + 1]}, gv = {gq8[q], gq8[q + 1]};
+                                    const f32x2_t z = __builtin_elementwise_fma(xv, f32x2_t{es[q], es[q + 1]}, f32x2_t{et[q], et[q + 1]});
+                                    const f32x2_t sg = sigmoid2_f(z);
+                                    const f32x2_t y = z * sg, yd = sg * __builtin_elementwise_fma(z, one - sg, one);
+                                    const f32x2_t xh = (xv - f32x2_t{e0[q], e0[q + 1]}) * f32x2_t{e1[q], e1[q + 1]};
+                                    const f32x2_t gyd = gv * yd;
+                                    f32x2_t a2;
+                                    a2 = __builtin_elementwise_fma(gv, y, f32x2_t{acc5[0][q], acc5[0][q + 1]}); acc5[0][q] = a2.x; acc5[0][q + 1] = a2.y;
+                                    a2 = f32x2_t{acc5[1][q], acc5[1][q + 1]} + gyd; acc5[1][q] = a2.x; acc5[1][q + 1] = a2.y;
+                                    a2 = __builtin_elementwise_fma(gyd, xh, f32x2_t{acc5[2][q], acc5[2][q + 1]}); acc5[2][q] = a2.x; acc5[2][q + 1] = a2.y;
+                                    a2 = f32x2_t{acc5[3][q], acc5[3][q + 1]} + yd; acc5[3][q] = a2.x; acc5[3][q + 1] = a2.y;
+                                    a2 = __builtin_elementwise_fma(yd, xh, f32x2_t{acc5[4][q], acc5[4][q + 1]}); acc5[4][q] = a2.x; acc5[4][q + 1] = a2.y;
+                                }
+                            } else {
+                                float o[8];
+#pragma unroll
+                                for (int q = 0; q < 8; q += 2) {                 // (same arithmetic as bnact_bwd_k<true, true, true>)
+                                    f32x2_t d2 = __builtin_elementwise_fma(f32x2_t{gq8[q], gq8[q + 1]}, f32x2_t{emul[q], emul[q + 1]}, f32x2_t{eadd[q], eadd[q + 1]});
+                                    d2 = d2 * silu_grad2_f(__builtin_elementwise_fma(f32x2_t{x[q], x[q + 1]}, f32x2_t{es[q], es[q + 1]}, f32x2_t{et[q], et[q + 1]}));
+                                    o[q] = e0[q] * d2.x + e1[q] * x[q] + e2[q];
+                                    o[q + 1] = e0[q + 1] * d2.y + e1[q + 1] * x[q + 1] + e2[q + 1];
+                                }
+                                *reinterpret_cast<uint4*>(p.C + m * p.ldc + n0 + c8 * 8) = pack8(o);
+                            }
+                        }
+                    }
+                }
+            } else
             if (ep_active) {
                 for (int row = rs; row < 16; row += slots) {
                     const long long m = mbase + row;
@@ -212,6 +342,10 @@ __global__ __launch_bounds__(256, 2) void gemm_rows_kernel(const mc_gemm_rows_ar
 #pragma unroll
     for (int u = 0; u < PF; ++u)
         if (gq[u] < ngroups) load_group(xn[u], gq[u]);
+    if constexpr (EPI != 0) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u) load_x(xe[u], gq[u] < ngroups ? gq[u] : 0);
+    }
     while (gq[0] < ngroups) {
 #pragma unroll
         for (int u = 0; u < PF; ++u) {
@@ -227,12 +361,19 @@ __global__ __launch_bounds__(256, 2) void gemm_rows_kernel(const mc_gemm_rows_ar
                 for (int t = 0; t < PF; ++t) gn = gnext(gn);
                 gq[u] = gn;
                 if (gn < ngroups) load_group(xn[u], gn);   // in flight during PF groups of work
-                process(gg, xf);
+                process(gg, xf, xe[u]);
+                if constexpr (EPI != 0) load_x(xe[u], gn < ngroups ? gn : gg);      // slot u again PF iterations from now
             }
         }
     }
 
-    if (p.stat_partials) {
+    if constexpr (EPI == 1) {
+        if (img_cur >= 0) flush_sums();
+        int* tags = reinterpret_cast<int*>(p.epi_ws + (long long)nwaves * 2 * 5 * p.N);
+        if (lane == 0)
+            for (int sl = eslot; sl < 2; ++sl) tags[wid * 2 + sl] = -1;
+    }
+    if (EPI == 0 && p.stat_partials) {
         __syncthreads();
         float* red = reinterpret_cast<float*>(sC);        // [4 waves][64 lanes][16]
 #pragma unroll
@@ -263,13 +404,13 @@ template <int FN, int KC> size_t lds_bytes() {
 
 // Persistent workgroups per CU = what the instance's registers and LDS allow (round 3: the launch used to be capped at two
 // per CU; the write-heavy expand convs (24 -> 144: 142 VGPRs) gain 16 % from a third, instances above 168 VGPRs stay at two)
-template <int FN, int KC, int PF, int RG> int rows_occupancy(bool gated) {
+template <int FN, int KC, int PF, int RG, int EPI> int rows_occupancy(bool gated) {
     static int occ[2] = {0, 0};
     if (!occ[gated]) {
         static unsigned long long attr_done = 0;
-        const void* kfn = reinterpret_cast<const void*>(&gemm_rows_kernel<FN, KC, PF, RG>);
-        const size_t lds_max = lds_bytes<FN, KC>() + (size_t)4 * 2 * KC * 32 * 4;
-        const size_t lds = lds_bytes<FN, KC>() + (gated ? (size_t)4 * 2 * KC * 32 * 4 : 0);
+        const void* kfn = reinterpret_cast<const void*>(&gemm_rows_kernel<FN, KC, PF, RG, EPI>);
+        const size_t lds_max = lds_bytes<FN, KC>() + (size_t)4 * 2 * KC * 32 * 4 + 12288;
+        const size_t lds = lds_bytes<FN, KC>() + (gated ? (size_t)4 * 2 * KC * 32 * 4 : 0) + (EPI == 1 ? 12288 : 0);
         if (lds > 64 * 1024) MC_SET_MAX_LDS(attr_done, kfn, lds_max);
         int nb = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kfn, 256, lds) != hipSuccess || nb < 1) nb = 2;
@@ -278,26 +419,70 @@ template <int FN, int KC, int PF, int RG> int rows_occupancy(bool gated) {
     return occ[gated];
 }
 
+// per-image sums of the EPI = 1 launch: sums[k][img][c] = sum over the (wave, slot) workspace entries tagged with img, in wave order
+__global__ __launch_bounds__(256) void rows_se_reduce_k(const float* __restrict__ ws, int nwaves, long long rows_per_wave,
+                                                        long long rpi, int n_img, int n, float* __restrict__ sums) {
+    const int img = blockIdx.y;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= 5 * n) return;
+    const int k = e / n, c = e % n;
+    const int* tags = reinterpret_cast<const int*>(ws + (long long)nwaves * 2 * 5 * n);
+    long long w_lo = ((long long)img * rpi) / rows_per_wave, w_hi = (((long long)img + 1) * rpi - 1) / rows_per_wave;
+    if (w_hi > nwaves - 1) w_hi = nwaves - 1;
+    float s = 0.f;
+    for (long long w = w_lo; w <= w_hi; ++w)
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl)
+            if (tags[w * 2 + sl] == img) s += ws[((w * 2 + sl) * 5 + k) * n + c];
+    sums[((long long)k * n_img + img) * n + c] = s;
+}
+
 // query != nullptr: report the workgroup count (= rows of stat_partials) instead of launching
-template <int FN, int KC> int launch_rows(const mc_gemm_rows_args& p, hipStream_t st, int* query) {
+template <int FN, int KC, int EPI> int launch_rows_e(const mc_gemm_rows_args& p, hipStream_t st, int* query) {
     constexpr int RG = (FN >= 6 || KC >= 12) ? 1 : 2;   // wide outputs / deep K: 16 rows per iteration (register budget)
-    constexpr int PF = KC >= 12 ? 1 : (KC >= 6 ? (RG == 1 ? 2 : 1) : 8 / KC);   // ~8-16 KB of activations in flight per wave
+    constexpr int PF0 = KC >= 12 ? 1 : (KC >= 6 ? (RG == 1 ? 2 : 1) : 8 / KC);   // ~8-16 KB of activations in flight per wave
+    // epilogue forms: every iteration in flight also holds its d rows (RG * XCH 16-byte registers per lane): <= 48 registers
+    constexpr int XCH_ = (16 + 64 / (2 * FN) - 1) / (64 / (2 * FN));
+    constexpr int PFE_ = 12 / (RG * XCH_) < 1 ? 1 : 12 / (RG * XCH_);
+    constexpr int PF = EPI == 0 ? PF0 : ((PF0 > 1 ? PF0 / 2 : 1) < PFE_ ? (PF0 > 1 ? PF0 / 2 : 1) : PFE_);
     const long long groups = (p.M + 15) / 16;
     long long b = (groups + 3) / 4;
     const int ntiles = (p.N + FN * 16 - 1) / (FN * 16);
-    const long long cap = ntiles > 1 ? 512 : 256LL * rows_occupancy<FN, KC, PF, RG>(p.pro_gate != nullptr);
+    const long long cap = ntiles > 1 ? 512 : 256LL * rows_occupancy<FN, KC, PF, RG, EPI>(p.pro_gate != nullptr);
     if (b > cap) b = cap;
     if (b < 1) b = 1;
     const int blocks = (int)b;
     if (query) { *query = blocks; return MC_OK; }
-    size_t lds = lds_bytes<FN, KC>() + (p.pro_gate ? (size_t)4 * 2 * KC * 32 * 4 : 0);     // + per-wave SE gate cache
+    size_t lds = lds_bytes<FN, KC>() + (p.pro_gate ? (size_t)4 * 2 * KC * 32 * 4 : 0) + (EPI == 1 ? 12288 : 0);     // + per-wave SE gate cache / flush tile
     static unsigned long long attr_done = 0;
-    const void* kfn = reinterpret_cast<const void*>(&gemm_rows_kernel<FN, KC, PF, RG>);
-    const size_t lds_max = lds_bytes<FN, KC>() + (size_t)4 * 2 * KC * 32 * 4;
+    const void* kfn = reinterpret_cast<const void*>(&gemm_rows_kernel<FN, KC, PF, RG, EPI>);
+    const size_t lds_max = lds_bytes<FN, KC>() + (size_t)4 * 2 * KC * 32 * 4 + 12288;
     if (lds > 64 * 1024) MC_SET_MAX_LDS(attr_done, kfn, lds_max);
-    hipLaunchKernelGGL((gemm_rows_kernel<FN, KC, PF, RG>), dim3((blocks + 7) / 8 * 8 * ntiles), dim3(256), lds, st, p, blocks, ntiles);
+    if constexpr (EPI != 0) {
+        // contiguous per-wave ranges of at most one image length (two workspace slots per wave)
+        const long long nwaves = (long long)blocks * 4, iters = (p.M + RG * 16 - 1) / (RG * 16);
+        const long long rows_per_wave = (iters + nwaves - 1) / nwaves * RG * 16;
+        MC_CHECK(ntiles == 1 && rows_per_wave <= p.epi_rows_per_img, "gemm_rows (epilogue forms): N <= 256 and at least as many waves as images");
+        hipLaunchKernelGGL((gemm_rows_kernel<FN, KC, PF, RG, EPI>), dim3((blocks + 7) / 8 * 8), dim3(256), lds, st, p, blocks, 1);
+        MC_LAUNCH_CHECK();
+        if constexpr (EPI == 1) {
+            const int n_img = (int)((p.M + p.epi_rows_per_img - 1) / p.epi_rows_per_img);
+            hipLaunchKernelGGL(rows_se_reduce_k, dim3(mc_div_up(5 * p.N, 256), n_img), dim3(256), 0, st, p.epi_ws, (int)nwaves, rows_per_wave,
+                               p.epi_rows_per_img, n_img, p.N, p.epi_sums);
+            MC_LAUNCH_CHECK();
+        }
+        return MC_OK;
+    }
+    hipLaunchKernelGGL((gemm_rows_kernel<FN, KC, PF, RG, EPI>), dim3((blocks + 7) / 8 * 8 * ntiles), dim3(256), lds, st, p, blocks, ntiles);
     MC_LAUNCH_CHECK();
     return MC_OK;
+}
+template <int FN, int KC> int launch_rows(const mc_gemm_rows_args& p, hipStream_t st, int* query) {
+    if constexpr (KC <= 4) {                               // epilogue forms: projection data gradients, K = c_out <= 128
+        if (p.epi_mode == 1) return launch_rows_e<FN, KC, 1>(p, st, query);
+        if (p.epi_mode == 2) return launch_rows_e<FN, KC, 2>(p, st, query);
+    }
+    return launch_rows_e<FN, KC, 0>(p, st, query);
 }
 
 template <int FN> int dispatch_kc(const mc_gemm_rows_args& p, hipStream_t st, int* query) {
@@ -357,12 +542,26 @@ extern "C" int mc_gemm_rows_blocks(const mc_gemm_rows_args* a) {
     return q;
 }
 
+// floats of epi_ws for an epi_mode = 1 launch: [waves][2 slots][5][N] sums + [waves][2] image tags
+extern "C" long long mc_gemm_rows_epi_ws_floats(const mc_gemm_rows_args* a) {
+    const int blocks = mc_gemm_rows_blocks(a);
+    return (long long)blocks * 4 * 2 * (5LL * a->N + 1);
+}
+
 extern "C" int mc_gemm_rows_bf16(const mc_gemm_rows_args* a, void* stream) {
     const mc_gemm_rows_args& p = *a;
-    MC_CHECK(p.X && p.W && p.C && p.M > 0 && p.N > 0 && p.K > 0, "gemm_rows: bad args");
+    MC_CHECK(p.X && p.W && (p.C || p.epi_mode == 1) && p.M > 0 && p.N > 0 && p.K > 0, "gemm_rows: bad args");
+    if (p.epi_mode != 0) {
+        MC_CHECK(p.epi_mode == 1 || p.epi_mode == 2, "gemm_rows: epi_mode must be 0, 1 or 2");
+        MC_CHECK(p.N <= 256 && p.K <= 128 && !p.R && !p.bias && !p.stat_partials && !p.pro_scale, "gemm_rows (epilogue forms): N <= 256, K <= 128, no residual / bias / statistics / prologue");
+        MC_CHECK(p.epi_x && p.epi_scale && p.epi_shift && p.epi_ldx % 8 == 0 && mc_aligned16(p.epi_x), "gemm_rows (epilogue forms): epi_x / scale / shift");
+        MC_CHECK(p.epi_rows_per_img >= 16 && p.epi_rows_per_img % 16 == 0, "gemm_rows (epilogue forms): rows per image must be a multiple of 16");
+        if (p.epi_mode == 1) MC_CHECK(p.epi_mean && p.epi_invstd && p.epi_sums && p.epi_ws, "gemm_rows (epi_mode 1): mean / invstd / sums / workspace");
+        else MC_CHECK(p.epi_coef && p.epi_mul && p.epi_add && p.C, "gemm_rows (epi_mode 2): coef / mul / add / C");
+    }
     MC_CHECK(mc_gemm_rows_supported(p.N, p.K), "gemm_rows: unsupported shape (see mc_gemm_rows_supported)");
     MC_CHECK(p.ldx % 8 == 0 && p.ldw % 8 == 0 && p.ldc % 8 == 0, "gemm_rows: leading dims must be multiples of 8");
-    MC_CHECK(mc_aligned16(p.X) && mc_aligned16(p.W) && mc_aligned16(p.C), "gemm_rows: operands must be 16-byte aligned");
+    MC_CHECK(mc_aligned16(p.X) && mc_aligned16(p.W) && (!p.C || mc_aligned16(p.C)), "gemm_rows: operands must be 16-byte aligned");
     MC_CHECK(!p.R || (p.ldr % 8 == 0 && mc_aligned16(p.R)), "gemm_rows: bad residual");
     MC_CHECK((p.pro_scale == nullptr) == (p.pro_shift == nullptr), "gemm_rows: prologue needs scale and shift");
     MC_CHECK(!p.pro_gate || (p.pro_scale && p.pro_rows_per_img >= 16), "gemm_rows: gate needs the BN prologue and >= 16 rows per image");

@@ -45,6 +45,10 @@ class GemmRowsArgs(C.Structure):
         ("R", P), ("ldr", LL),
         ("pro_scale", P), ("pro_shift", P), ("pro_gate", P), ("pro_rows_per_img", LL),
         ("stat_partials", P), ("bias", P),
+        ("epi_mode", I), ("epi_x", P), ("epi_ldx", LL), ("epi_rows_per_img", LL),
+        ("epi_scale", P), ("epi_shift", P), ("epi_mean", P), ("epi_invstd", P),
+        ("epi_coef", P), ("epi_mul", P), ("epi_add", P), ("epi_add_scale", C.c_float),
+        ("epi_sums", P), ("epi_ws", P),
     ]
 
 
@@ -94,6 +98,7 @@ _SIGS = {
     "mc_quant_fp8_bf16": ([P, LL, P, P, P, P, P], I),
     "mc_gemm_rows_supported": ([I, I], I),
     "mc_gemm_rows_blocks": ([C.POINTER(GemmRowsArgs)], I),
+    "mc_gemm_rows_epi_ws_floats": ([C.POINTER(GemmRowsArgs)], LL),
     "mc_gemm_rows_bf16": ([C.POINTER(GemmRowsArgs), P], I),
     "mc_cast_transpose_f32_bf16": ([P, P, I, I, P], I),
     "mc_wgrad_rows_supported": ([I, I], I),

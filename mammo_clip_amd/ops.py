@@ -5,6 +5,7 @@ bf16 activations in row-major [rows, channels] (NHWC) layout unless noted, fp32 
 """
 import ctypes as C
 import math
+import os
 
 import weakref
 
@@ -154,6 +155,58 @@ def gemm_rows(x, w, y, residual=None, pro=None, stats=False, kind=None, bias=Non
     _note(2 * M * (K + N) + 2 * N * K + (2 * M * N if residual is not None else 0), 2 * M * N * K)
     L.call("mc_gemm_rows_bf16", C.byref(a), _st(), kind=kind)
     return part
+
+
+# Measured on MI355X (scripts/epi_probe.py, 32 images): the two epilogue launches beat dgrad + se_sums + apply only for wide
+# expanded tensors -- c = 240: 1.18 vs 1.47 ms per block and view; c = 144: 0.91 vs 0.91; c = 48: 1.32 vs 1.28; c = 24: 0.94 vs
+# 0.75 (narrow rows: the row-streaming kernel's per-16-row overhead carries too little data, and the sums form runs at two
+# waves per SIMD with one iteration of d rows in flight)
+PROJ_DGRAD_FUSE_MIN_N = int(os.environ.get("MC_PROJ_DGRAD_FUSE_MIN_N", 192))
+
+
+def proj_dgrad_fusable(M, n_out, k_in, rows_per_img):
+    """can the data gradient of a projection conv (dP [M, k_in] -> G [M, n_out]) carry the squeeze-excite / BatchNorm1
+    backward in its epilogue (gemm_rows epi_mode 1 / 2)?  Row-streaming shapes with whole 16-row groups per image."""
+    if n_out < PROJ_DGRAD_FUSE_MIN_N:
+        return False
+    return (M >= ROWS_MIN_M and n_out <= 256 and k_in <= 128 and rows_per_img % 16 == 0 and rows_per_img >= 16
+            and bool(L.load().mc_gemm_rows_supported(n_out, k_in)) and not _prefer_tiles(n_out, k_in))
+
+
+def _proj_dgrad_epi_args(dp, w_t, d, stats, rows_per_img, mode):
+    a = L.GemmRowsArgs()
+    M, K = dp.shape
+    N = w_t.shape[0]
+    assert d.shape == (M, N) and w_t.shape[1] == K
+    a.X, a.M, a.K, a.ldx = _p(dp), M, K, dp.stride(0)
+    a.W, a.N, a.ldw = _p(w_t), N, w_t.stride(0)
+    a.epi_mode, a.epi_x, a.epi_ldx, a.epi_rows_per_img = mode, _p(d), d.stride(0), rows_per_img
+    a.epi_scale, a.epi_shift = _p(stats.scale), _p(stats.shift)
+    return a, M, N, K
+
+
+def proj_dgrad_se_sums(dp, w_t, d, stats, n_img, rows_per_img):
+    """bnact_se_sums(d, G) for G = dp . w_t^T WITHOUT G in memory: [5, n_img, c] (gemm_rows epi_mode 1)."""
+    a, M, N, K = _proj_dgrad_epi_args(dp, w_t, d, stats, rows_per_img, 1)
+    sums = empty((5, n_img, N), torch.float32, dp)
+    a.epi_mean, a.epi_invstd, a.epi_sums = _p(stats.mean), _p(stats.invstd), _p(sums)
+    ws = empty((L.load().mc_gemm_rows_epi_ws_floats(C.byref(a)),), torch.float32, dp)
+    a.epi_ws = _p(ws)
+    _note(2 * M * (K + N) + 2 * N * K, 2 * M * N * K)
+    L.call("mc_gemm_rows_bf16", C.byref(a), _st(), kind="dgrad_se_sums")
+    return sums
+
+
+def proj_dgrad_bn_apply(dp, w_t, d, stats, coef, mul, add, add_scale, rows_per_img):
+    """bnact_bwd's apply pass on (d, G) for G = dp . w_t^T without G in memory (gemm_rows epi_mode 2): returns
+    dd = coef0*dz + coef1*d + coef2, dz = (G*mul[img] + add[img]*add_scale) * silu'(bn(d))."""
+    a, M, N, K = _proj_dgrad_epi_args(dp, w_t, d, stats, rows_per_img, 2)
+    dd = empty((M, N), BF16, dp)
+    a.C, a.ldc = _p(dd), dd.stride(0)
+    a.epi_coef, a.epi_mul, a.epi_add, a.epi_add_scale = _p(coef), _p(mul), _p(add), float(add_scale)
+    _note(2 * M * (K + 2 * N) + 2 * N * K, 2 * M * N * K)
+    L.call("mc_gemm_rows_bf16", C.byref(a), _st(), kind="dgrad_bn_apply")
+    return dd
 
 
 def _rows_ok(M, N, K, bias, act):

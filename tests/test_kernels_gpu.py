@@ -924,6 +924,42 @@ def test_dwconv_s2_dgrad_with_bn_backward_epilogue(k, n, h, w, c, pad):
     check(db, db_ref, 1e-2, "dbeta")
 
 
+@pytest.mark.parametrize("n_img,hw,cexp,cout", [(4, 4096, 240, 40), (3, 6016, 144, 40), (5, 2048, 24, 24), (2, 16384, 48, 24),  # (the model fuses from 192 channels up)
+                                                (6, 1600, 96, 16), (2, 8192, 256, 64)])
+def test_proj_dgrad_with_se_and_bn1_backward_epilogues(n_img, hw, cexp, cout):
+    """gemm_rows epi_mode 1 / 2: the projection conv's data gradient G = dP . Wp with the squeeze-excite sums / the
+    BatchNorm1 + swish backward apply in its epilogue == linear_dgrad -> bnact_se_sums / bnact_bwd on the stored G
+    (same bf16 rounding of G, same elementwise arithmetic; the sums differ only in summation order)."""
+    M = n_img * hw
+    assert ops.proj_dgrad_fusable(M, 256, cout, hw) and L.load().mc_gemm_rows_supported(cexp, cout)
+    dp = rnd(M, cout, seed=1)
+    d = rnd(M, cexp, seed=2)
+    wp = rnd(cout, cexp, seed=3, scale=0.3)
+    wp_t = wp.t().contiguous()
+    gamma, beta = rnd(cexp, seed=4, dtype=torch.float32) * 0.2 + 1.0, rnd(cexp, seed=5, dtype=torch.float32) * 0.1
+    df = d.float()
+    mean, var = df.mean(0), df.var(0, unbiased=False)
+    st = ops.BNStats()
+    st.mean, st.invstd = mean.contiguous(), (var + 1e-3).rsqrt().contiguous()
+    st.scale = (gamma * st.invstd).contiguous()
+    st.shift = (beta - mean * st.scale).contiguous()
+    st.count = float(M)
+    gate = torch.sigmoid(rnd(n_img, cexp, seed=6, dtype=torch.float32))
+    dpooled = rnd(n_img, cexp, seed=7, dtype=torch.float32)
+    da1 = ops.linear_dgrad(dp, wp, w_t=wp_t)
+    sums_ref = ops.bnact_se_sums(d, da1, n_img, hw, cexp, st, 1)
+    sums = ops.proj_dgrad_se_sums(dp, wp_t, d, st, n_img, hw)
+    for k in range(5):
+        check(sums[k], sums_ref[k], 2e-5, f"se sums[{k}] through the dgrad epilogue")
+    part = ops.bn_partials_from_se_sums(sums_ref, gate, dpooled, 1.0 / hw)
+    dd_ref, dg_ref, db_ref = ops.bnact_bwd(d, n_img, hw, cexp, st, gamma, 1, g=da1, mul=gate, add=dpooled, add_scale=1.0 / hw, partials=part)
+    coef, dg, db = ops.bn_bwd_coefs(part, M, st, gamma)
+    dd = ops.proj_dgrad_bn_apply(dp, wp_t, d, st, coef, gate, dpooled, 1.0 / hw, hw)
+    assert torch.equal(dg, dg_ref) and torch.equal(db, db_ref)
+    check(dd, dd_ref, 4e-3, "BatchNorm1 + swish backward through the dgrad epilogue")          # (one bf16 ulp: the FMA contraction may differ)
+    assert float((dd.float() - dd_ref.float()).abs().max()) <= 2 ** -7 * float(dd_ref.float().abs().max())
+
+
 # ------------------------------------------------------------------------------------------- fused attention
 def _attn_inputs(b, t, nh, seed):
     H = nh * 64
