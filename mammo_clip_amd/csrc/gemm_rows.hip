@@ -190,7 +190,8 @@ __global__ __launch_bounds__(256, 2) void gemm_rows_kernel(const mc_gemm_rows_ar
             }
         }
     };
-    auto process = [&](long long g, uint4 (&xf)[RG][KC], uint4 (&xd)[RG][XCH]) __attribute__((always_inline)) {
+    // gx (EPI): the iteration whose d rows replace this one's in xd, chunk by chunk, as soon as each chunk is consumed
+    auto process = [&](long long g, uint4 (&xf)[RG][KC], uint4 (&xd)[RG][XCH], long long gx) __attribute__((always_inline)) {
         if (EPI == 0 && has_pro) {
 #pragma unroll
             for (int rg = 0; rg < RG; ++rg) {
@@ -269,10 +270,16 @@ __global__ __launch_bounds__(256, 2) void gemm_rows_kernel(const mc_gemm_rows_ar
                     for (int u = 0; u < XCH; ++u) {
                         const int row = rs + u * slots;
                         const long long m = mbase + row;
+                        float x[8];
+                        unpack8(xd[rg][u], x);
+                        {   // this chunk's register now takes the same (row slot, chunk) of iteration gx: a whole iteration of lead
+                            long long mx = (gx * RG + rg) * 16 + (row < 16 ? row : 0);
+                            if (mx >= p.M) mx = p.M - 1;
+                            xd[rg][u] = *reinterpret_cast<const uint4*>(p.epi_x + mx * p.epi_ldx + c8 * 8);
+                        }
                         if (row < 16 && m < p.M) {
-                            float gq8[8], x[8];
+                            float gq8[8];
                             unpack8(*reinterpret_cast<const uint4*>(myC + row * CROW + c8 * 16), gq8);     // G, bf16-rounded
-                            unpack8(xd[rg][u], x);
                             if constexpr (EPI == 1) {
                                 load8f(sPar + c8 * 8, es); load8f(sPar + 256 + c8 * 8, et);
                                 load8f(sPar + 512 + c8 * 8, e0); load8f(sPar + 768 + c8 * 8, e1);
@@ -361,8 +368,7 @@ __global__ __launch_bounds__(256, 2) void gemm_rows_kernel(const mc_gemm_rows_ar
                 for (int t = 0; t < PF; ++t) gn = gnext(gn);
                 gq[u] = gn;
                 if (gn < ngroups) load_group(xn[u], gn);   // in flight during PF groups of work
-                process(gg, xf, xe[u]);
-                if constexpr (EPI != 0) load_x(xe[u], gn < ngroups ? gn : gg);      // slot u again PF iterations from now
+                process(gg, xf, xe[u], gn < ngroups ? gn : gg);
             }
         }
     }

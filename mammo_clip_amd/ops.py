@@ -158,10 +158,10 @@ def gemm_rows(x, w, y, residual=None, pro=None, stats=False, kind=None, bias=Non
 
 
 # Measured on MI355X (scripts/epi_probe.py, 32 images): the two epilogue launches beat dgrad + se_sums + apply only for wide
-# expanded tensors -- c = 240: 1.18 vs 1.47 ms per block and view; c = 144: 0.91 vs 0.91; c = 48: 1.32 vs 1.28; c = 24: 0.94 vs
+# expanded tensors -- c = 240: 1.13 vs 1.47 ms per block and view; c = 144: 0.82 vs 0.90; c = 48: 1.26 vs 1.28; c = 24: 0.91 vs
 # 0.75 (narrow rows: the row-streaming kernel's per-16-row overhead carries too little data, and the sums form runs at two
 # waves per SIMD with one iteration of d rows in flight)
-PROJ_DGRAD_FUSE_MIN_N = int(os.environ.get("MC_PROJ_DGRAD_FUSE_MIN_N", 192))
+PROJ_DGRAD_FUSE_MIN_N = int(os.environ.get("MC_PROJ_DGRAD_FUSE_MIN_N", 144))
 
 
 def proj_dgrad_fusable(M, n_out, k_in, rows_per_img):
