@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256, 2) void gemm_rows_kernel(const mc_gemm_rows_ar
             for (int q = 0; q < 8; ++q) acc5[k][q] = 0.f;
         if constexpr (EPI == 1) {
             // the sums form carries 40 accumulator registers per lane: its four BatchNorm vectors live in LDS and are
-            // re-read per 16-byte chunk (four ds_read_b128 beside ~50 VALU instructions)
+            // re-read per 16-row group (re-reading them per 16-byte chunk made the kernel LDS-bound: 87 LDS instructions per group)
             for (int i = tid; i < 256; i += 256) {
                 const bool ok = i < p.N;
                 sPar[i] = ok ? p.epi_scale[i] : 0.f; sPar[256 + i] = ok ? p.epi_shift[i] : 0.f;
@@ -266,6 +266,10 @@ __global__ __launch_bounds__(256, 2) void gemm_rows_kernel(const mc_gemm_rows_ar
                     }
                 }
                 if (ep_active) {
+                    if constexpr (EPI == 1) {               // once per 16-row group (the MFMA accumulators are dead here: no extra registers)
+                        load8f(sPar + c8 * 8, es); load8f(sPar + 256 + c8 * 8, et);
+                        load8f(sPar + 512 + c8 * 8, e0); load8f(sPar + 768 + c8 * 8, e1);
+                    }
 #pragma unroll
                     for (int u = 0; u < XCH; ++u) {
                         const int row = rs + u * slots;
@@ -281,8 +285,6 @@ __global__ __launch_bounds__(256, 2) void gemm_rows_kernel(const mc_gemm_rows_ar
                             float gq8[8];
                             unpack8(*reinterpret_cast<const uint4*>(myC + row * CROW + c8 * 16), gq8);     // G, bf16-rounded
                             if constexpr (EPI == 1) {
-                                load8f(sPar + c8 * 8, es); load8f(sPar + 256 + c8 * 8, et);
-                                load8f(sPar + 512 + c8 * 8, e0); load8f(sPar + 768 + c8 * 8, e1);
 #pragma unroll
                                 for (int q = 0; q < 8; q += 2) {                 // (same arithmetic as bnact_se_sums_k)
                                     const f32x2_t one = {1.f, 1.f};
