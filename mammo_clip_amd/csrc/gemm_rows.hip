@@ -447,8 +447,10 @@ __global__ __launch_bounds__(256) void rows_se_reduce_k(const float* __restrict_
 
 // query != nullptr: report the workgroup count (= rows of stat_partials) instead of launching
 template <int FN, int KC, int EPI> int launch_rows_e(const mc_gemm_rows_args& p, hipStream_t st, int* query) {
-    constexpr int RG = (FN >= 6 || KC >= 12) ? 1 : 2;   // wide outputs / deep K: 16 rows per iteration (register budget)
-    constexpr int PF0 = KC >= 12 ? 1 : (KC >= 6 ? (RG == 1 ? 2 : 1) : 8 / KC);   // ~8-16 KB of activations in flight per wave
+    // wide outputs / deep K: 16 rows per iteration (register budget); 16-32 column outputs over K <= 64: 64 rows per
+    // iteration (a 16-row group is only 0.8-3 KB of traffic there: the per-iteration overhead was the limit)
+    constexpr int RG = (FN >= 6 || KC >= 12) ? 1 : ((FN <= 2 && KC <= 2 && EPI == 0) ? 4 : 2);
+    constexpr int PF0 = KC >= 12 ? 1 : (KC >= 6 ? (RG == 1 ? 2 : 1) : (RG == 4 ? 4 / KC : 8 / KC));   // ~8-16 KB of activations in flight per wave
     // epilogue forms: every iteration in flight also holds its d rows (RG * XCH 16-byte registers per lane): <= 48 registers
     constexpr int XCH_ = (16 + 64 / (2 * FN) - 1) / (64 / (2 * FN));
     constexpr int PFE_ = 12 / (RG * XCH_) < 1 ? 1 : 12 / (RG * XCH_);
