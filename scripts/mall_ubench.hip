@@ -10,6 +10,19 @@ __global__ __launch_bounds__(256) void k_read(const uint4* a, size_t n, unsigned
 __global__ __launch_bounds__(256) void k_fill(uint4* o, size_t n, unsigned v) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) o[i] = make_uint4(v, 2, 3, 4);
 }
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_fill_nt(uint4* o, size_t n, unsigned v) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        u32x4 w = {v, 2, 3, 4};
+        __builtin_nontemporal_store(w, reinterpret_cast<u32x4*>(o + i));
+    }
+}
+__global__ __launch_bounds__(256) void k_read_nt(const uint4* a, size_t n, unsigned* out) {
+    unsigned s = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a + i)); s += v.x ^ v.y ^ v.z ^ v.w; }
+    if (s == 0x12345u) out[0] = s;
+}
 int main() {
     const size_t maxb = 2ull << 30;
     uint4 *a, *big; unsigned* out;
@@ -33,7 +46,24 @@ int main() {
         hipLaunchKernelGGL(k_read, dim3(4096), dim3(256), 0, 0, big, maxb / 16, out);
         hipEventRecord(e0); hipLaunchKernelGGL(k_read, dim3(4096), dim3(256), 0, 0, a, n, out); hipEventRecord(e1); hipEventSynchronize(e1);
         hipEventElapsedTime(&ms, e0, e1); const double cold = bytes / ms / 1e9;
-        printf("%5zu MB: cold %6.2f TB/s   read-after-read %6.2f   read-after-write %6.2f\n", mb, cold, rar, raw);
+        // (4) flush, NON-TEMPORAL write of `a`, read it
+        hipLaunchKernelGGL(k_read, dim3(4096), dim3(256), 0, 0, big, maxb / 16, out);
+        hipLaunchKernelGGL(k_fill_nt, dim3(4096), dim3(256), 0, 0, a, n, 7u);
+        hipEventRecord(e0); hipLaunchKernelGGL(k_read, dim3(4096), dim3(256), 0, 0, a, n, out); hipEventRecord(e1); hipEventSynchronize(e1);
+        hipEventElapsedTime(&ms, e0, e1); const double rawnt = bytes / ms / 1e9;
+        // (5) plain write, non-temporal read
+        hipLaunchKernelGGL(k_read, dim3(4096), dim3(256), 0, 0, big, maxb / 16, out);
+        hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, a, n, 7u);
+        hipEventRecord(e0); hipLaunchKernelGGL(k_read_nt, dim3(4096), dim3(256), 0, 0, a, n, out); hipEventRecord(e1); hipEventSynchronize(e1);
+        hipEventElapsedTime(&ms, e0, e1); const double rntaw = bytes / ms / 1e9;
+        // (6) write + read pair timed together: plain vs nt write
+        hipLaunchKernelGGL(k_read, dim3(4096), dim3(256), 0, 0, big, maxb / 16, out);
+        hipEventRecord(e0); hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, a, n, 7u); hipLaunchKernelGGL(k_read, dim3(4096), dim3(256), 0, 0, a, n, out); hipEventRecord(e1); hipEventSynchronize(e1);
+        hipEventElapsedTime(&ms, e0, e1); const double pair = ms;
+        hipLaunchKernelGGL(k_read, dim3(4096), dim3(256), 0, 0, big, maxb / 16, out);
+        hipEventRecord(e0); hipLaunchKernelGGL(k_fill_nt, dim3(4096), dim3(256), 0, 0, a, n, 7u); hipLaunchKernelGGL(k_read, dim3(4096), dim3(256), 0, 0, a, n, out); hipEventRecord(e1); hipEventSynchronize(e1);
+        hipEventElapsedTime(&ms, e0, e1); const double pairnt = ms;
+        printf("%5zu MB: cold %6.2f TB/s   read-after-read %6.2f   read-after-write %6.2f   read-after-NT-write %6.2f   NT-read-after-write %6.2f | write+read %.3f ms, NT-write+read %.3f ms\n", mb, cold, rar, raw, rawnt, rntaw, pair, pairnt);
     }
     return 0;
 }
