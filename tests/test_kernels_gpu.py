@@ -925,7 +925,7 @@ def test_dwconv_s2_dgrad_with_bn_backward_epilogue(k, n, h, w, c, pad):
 
 
 @pytest.mark.parametrize("n_img,hw,cexp,cout", [(4, 4096, 240, 40), (3, 6016, 144, 40), (5, 2048, 24, 24), (2, 16384, 48, 24),  # (the model fuses from 192 channels up)
-                                                (6, 1600, 96, 16), (2, 8192, 256, 64)])
+                                                (6, 1600, 96, 16), (2, 8192, 256, 64), (2, 4096, 144, 24), (3, 2736, 208, 32), (2, 4112, 176, 128)])
 def test_proj_dgrad_with_se_and_bn1_backward_epilogues(n_img, hw, cexp, cout):
     """gemm_rows epi_mode 1 / 2: the projection conv's data gradient G = dP . Wp with the squeeze-excite sums / the
     BatchNorm1 + swish backward apply in its epilogue == linear_dgrad -> bnact_se_sums / bnact_bwd on the stored G
