@@ -92,12 +92,17 @@ def kernel_name(key):
 
 
 def class_key(key):
-    """merge the timer's record keys into kernel classes: 'mc_gemm_bf16:fwd|glnt256' and ':dgrad|glnt256' -> one class"""
+    """merge the timer's record keys into kernel classes = one class per kernel TEMPLATE (rocprof kernel-name family):
+    'mc_gemm_bf16:fwd|glnt256' and ':dgrad|glnt256' -> one class per tile kernel and roofline side; every depthwise
+    forward / stride-1 data-gradient launch (all kernel sizes and strides) -> 'mc_dwconv_fwd' (dwconv_march_fwd_kernel);
+    every row-streaming 1x1 convolution launch (forward, data gradient, the epilogue forms) -> 'mc_gemm_rows_bf16'"""
     ep, _, kind = key.partition(":")
     for tag in ("glnt256", "glnt", "tn256"):
         for side in ("mfma", "hbm"):
             if ep == "mc_gemm_bf16" and kind.endswith(f"|{tag}|{side}"):
                 return f"{ep}:|{tag}|{side}"
+    if ep in ("mc_dwconv_fwd", "mc_gemm_rows_bf16", "mc_dwconv_bwd_weight", "mc_wgrad_rows_bf16"):
+        return ep
     return key
 
 

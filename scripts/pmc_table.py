@@ -50,10 +50,9 @@ with open(os.path.join(dst, f"{tag}_cfg3_pmc_by_kernel.csv"), "w") as f:
 cls = {"mc_bnact_bwd_apply": "bnact_bwd_k<true", "mc_gemm_bf16:|glnt256": "g8::gemm8p_kernel", "mc_gemm_bf16:|tn256": "g8t::gemm256_tn_kernel",
        "mc_gemm_bf16:|glnt": "gemm_kernel<128, 128, 64, 2, 2, 0, 0, false, true>", "mc_bnact_se_sums": "bnact_se_sums_k",
        "mc_bnact_pool": "bnact_img_reduce_k",
-       # row-streaming 1x1 convolutions: forward and data-gradient launches are the same template family in rocprof's names,
-       # so the two timing classes share ONE figure (launch-weighted average over all gemm_rows_kernel instances)
-       "mc_gemm_rows_bf16:fwd_rows": "gemm_rows_kernel", "mc_gemm_rows_bf16:dgrad_rows": "gemm_rows_kernel",
-       "mc_wgrad_rows_bf16:wgrad_rows": "wgrad_rows_kernel"}
+       # one class per kernel template (bench.py::class_key): launch-weighted averages over all instances of the family
+       "mc_gemm_rows_bf16": "gemm_rows_kernel", "mc_wgrad_rows_bf16": "wgrad_rows_kernel",
+       "mc_dwconv_fwd": "dwconv_march_fwd_kernel", "mc_dwconv_bwd_weight": "dwconv_march_bww_kernel"}
 traffic = {}
 for key, kn in cls.items():
     sel = [r for r in rows if r[0].startswith(kn)]
