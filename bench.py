@@ -177,7 +177,7 @@ def main():
                          "0 = 2 for the global-batch workloads at <= 512 pairs per GPU (2 x 32 pairs = 232 GB of the 288 GB), 1 otherwise")
     ap.add_argument("--recompute", type=int, default=-1, choices=(-1, 0, 1, 2, 3),
                     help="MBConv activation recompute mode (EfficientNet.set_recompute); -1 = chosen with --keep-graphs")
-    ap.add_argument("--keep-kept", type=int, default=8, help="kept mode-2 graphs of the N = 1 / 2 global-batch runs")
+    ap.add_argument("--keep-kept", type=int, default=7, help="kept mode-2 graphs of the N = 1 / 2 global-batch runs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-n8-load", action="store_true", help="skip the n8_load block of the default N = 1 run")
     ap.add_argument("--fp8", action="store_true", help="fp8 (e4m3) operands for the late-stage 1x1 convolutions (config #5 arithmetic on any workload)")
@@ -232,9 +232,10 @@ def main():
     if args.keep_graphs <= 0 and args.recompute < 0 and strong and b <= 256:
         args.keep_graphs, args.recompute = args.micro_batches, (3 if b <= 128 else 2)
     elif args.keep_graphs <= 0 and args.recompute < 0 and strong:
-        # N = 1 / 2 (round 3): EIGHT kept graphs in recompute mode 2 (25 GB each; their backward pays the rebuild of e and d,
+        # N = 1 / 2 (round 3): SEVEN kept graphs in recompute mode 2 (25 GB each; their backward pays the rebuild of e and d,
         # ~32 ms, and saves a ~90 ms forward), the re-forwarded micro-batches stay in mode 0 (Trainer.keep_recompute);
-        # 252 GB peak at N = 1 (6 kept: 199 GB, 0.9 % slower; 9 kept: 278 GB -- too close to the device's 288 GB)
+        # 225 GB allocated / 239 GB reserved at N = 1 (6 kept: 199 GB, 0.9 % slower; 8 kept: 0.1 % faster at 252 / 263 GB;
+        # 9 kept: 278 GB -- too close to the device's 288 GiB)
         args.keep_graphs, keep_recompute = args.keep_kept, 2
     if args.keep_graphs <= 0:
         args.keep_graphs = 2 if (strong and b <= 512) else 1
@@ -286,6 +287,7 @@ def main():
     raw_timed = timer.summary()
     summ = merged(raw_timed)
     peak_gb = torch.cuda.max_memory_allocated() / 1e9
+    peak_res_gb = torch.cuda.max_memory_reserved() / 1e9
 
     n8 = None
     if world == 1 and args.workload == "cfg4" and strong and not args.no_n8_load:
@@ -343,7 +345,7 @@ def main():
                                    f"(2 views + 2 reports each), {H}x{W} images, {T}-token reports, breast_clip loss, "
                                    f"AdamW; fwd+loss+bwd+optimizer; dropout/drop-connect on",
                        "global_batch": b * world, "parallelism": f"dp{world}" + (f" x {args.micro_batches} micro-batches" if args.micro_batches > 1 else ""),
-                       "loss": round(loss_val, 5), "peak_hbm_gb": round(peak_gb, 1),
+                       "loss": round(loss_val, 5), "peak_hbm_gb": round(peak_gb, 1), "peak_reserved_gb": round(peak_res_gb, 1),
                        "keep_graphs": args.keep_graphs, "recompute": args.recompute, "keep_recompute": keep_recompute},
             "roofline": first, "roofline_runner_up": second, "roofline_third": third,
         }
