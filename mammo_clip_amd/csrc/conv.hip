@@ -901,7 +901,8 @@ __global__ __launch_bounds__(256, 2) void dwconv_march_bwd_s2_kernel(const mc_dw
                     if (ch_ok && x >= 0 && x < p.w) ok_mask |= 1u << (i * 2 + e);
                 }
         }
-#pragma unroll (EPI ? C::NR : 1)
+        constexpr int SB_UNROLL = EPI ? C::NR : 1;            // (the epilogue form indexes its e registers by sb)
+#pragma unroll SB_UNROLL
         for (int sb = 0; sb < C::NR; ++sb) {
             const unsigned char* lp = smem + lbase + sb * (C::D * C::IW_T * C::PSB);
 #pragma unroll
