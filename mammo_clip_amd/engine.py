@@ -17,6 +17,7 @@ import torch
 import torch.distributed as dist
 
 from . import ops
+from .breastclip.model.modules import efficientnet_custom as _encmod
 
 
 class GradBuckets:
@@ -116,7 +117,8 @@ class GradBuckets:
 
 class Trainer:
     def __init__(self, model, loss_func, optimizer, scheduler=None, device=None, bucket_mb: int = 256,
-                 overlap_micro: bool = False, keep_graphs: int = 1, grad_sink: bool = True, keep_recompute: Optional[int] = None):
+                 overlap_micro: bool = False, keep_graphs: int = 1, grad_sink: bool = True, keep_recompute: Optional[int] = None,
+                 stat_tapes: bool = True):
         self.model, self.loss_func, self.optimizer, self.scheduler = model, loss_func, optimizer, scheduler
         self.device = device
         # Gradient reduction: by default the flat buckets are all-reduced AFTER the last backward (reduce_all) -- the whole
@@ -124,6 +126,9 @@ class Trainer:
         # that mode does not depend on autograd's hook order.  overlap_micro = True (needs grad_sink = False) launches each
         # bucket from the post-accumulate hooks of the last backward instead.
         self.grad_sink = bool(grad_sink)        # parameter gradients combined by multi-tensor adds (ops.GradSink)
+        # micro-batched step: the re-forward of a micro-batch replays the BatchNorm statistics / pooled means its first
+        # (graph-less) forward recorded instead of computing them again (efficientnet_custom.StatTape)
+        self.stat_tapes = bool(stat_tapes) and os.environ.get("MC_STAT_TAPES", "1") != "0"
         self.overlap_micro = bool(overlap_micro) and not self.grad_sink
         self.keep_graphs = max(1, int(keep_graphs))   # micro-batched step: micro-batches forwarded once, graph kept
         # MBConv recompute mode for the KEPT graphs only (EfficientNet.set_recompute): a kept graph in mode 2 is 28 GB instead
@@ -228,11 +233,19 @@ def _step_micro(self, batch: Dict, k: int) -> Dict[str, torch.Tensor]:
     irng, trng = _rng_counters(model)
     keys = ("image_embeddings", "text_embeddings", "text_embeddings2", "image_view_embeddings")
     keep = min(self.keep_graphs, k)            # micro-batches whose graph is kept (activation memory: `keep` micro-batches)
-    counters, parts = [], []
+    counters, parts, tapes = [], [], []
+    set_tape = getattr(_encmod, "set_stat_tape", None) if self.stat_tapes else None
     with torch.no_grad():
         for mb in mbs[:k - keep]:
             counters.append((irng.calls, trng._calls))
-            out = model(mb, self.device)
+            if set_tape is not None:               # record this micro-batch's BatchNorm statistics / pooled means (StatTape)
+                tapes.append(_encmod.StatTape())
+                set_tape(tapes[-1])
+            try:
+                out = model(mb, self.device)
+            finally:
+                if set_tape is not None:
+                    set_tape(None)
             parts.append({kk: out[kk] for kk in keys if kk in out})
     # the LAST `keep` micro-batches are forwarded with their graph kept: they are back-propagated straight from the loss
     # and never forwarded again (k - keep extra forwards per step instead of k: at 4 micro-batches per GPU and keep = 1
@@ -271,7 +284,15 @@ def _step_micro(self, batch: Dict, k: int) -> Dict[str, torch.Tensor]:
                 # gradients become final during the LAST backward: each bucket is all-reduced as soon as its parameters
                 # have accumulated their last contribution, overlapped with the rest of that backward
                 self.buckets.enabled = True
-            out = model(mb, self.device)
+            if set_tape is not None:               # the re-forward replays them: no statistics epilogues / finalize / squeeze passes
+                set_tape(tapes[i].replay())
+            try:
+                out = model(mb, self.device)
+            finally:
+                if set_tape is not None:
+                    set_tape(None)
+                    assert tapes[i].pos == len(tapes[i].items), "statistics tape out of step with the re-forward"
+                    tapes[i] = None
             ks = list(leaf)
             self._backward(lambda: torch.autograd.backward([out[kk] for kk in ks], [leaf[kk].grad[i * b:(i + 1) * b] for kk in ks]))
     finally:

@@ -416,6 +416,20 @@ def test_micro_batched_step_matches_full_graph():
     # the seed counters continue where the first pass left them
     assert model2.image_encoder.rng.calls == model.image_encoder.rng.calls
 
+    # the re-forward REPLAYS the BatchNorm statistics / pooled means its first forward recorded (StatTape): same step with
+    # the tapes off -- same loss bit for bit, same gradients (the depthwise tap gradients are float-atomic sums: 1e-5)
+    model3, lossf3, _ = _build("tf_efficientnet_b5_ns-detect", "efficientnet-b5", stochastic_off=False)
+    util.GlobalEnv.reset()
+    tr3 = engine.Trainer(model3, lossf3, torch.optim.SGD(model3.parameters(), lr=0.0), None, DEV, stat_tapes=False)
+    assert tr.stat_tapes and not tr3.stat_tapes
+    out3 = tr3.step(bt, micro_batches=k)
+    assert float(out3["total"]) == float(out["total"])
+    g3 = {n: p.grad for n, p in model3.named_parameters() if p.grad is not None}
+    for n in g2:
+        assert relerr(g3[n], g2[n]) < 1e-5, (n, relerr(g3[n], g2[n]))
+    for n, v in model3.named_buffers():
+        assert torch.equal(v, ref_buf[n]), n
+
 
 def test_fp8_pointwise_convs_config5():
     """BASELINE config #5 arithmetic: the late-stage 1x1 convolutions (expand / project / head on the tiled MFMA path) with
