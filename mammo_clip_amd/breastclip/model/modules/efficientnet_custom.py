@@ -254,8 +254,13 @@ class _MBConvFn(torch.autograd.Function):
             pooled, act1 = ops.bnact_pool(d, n, ohw, a.cexp, st1.scale, st1.shift, 1), None
             if training and _TAPE is not None:
                 _TAPE.put(pooled)
-        gate = ops.se_fwd(pooled, blk._se_reduce.weight.view(a.cse, a.cexp), blk._se_reduce.bias,
-                          blk._se_expand.weight.view(a.cexp, a.cse), blk._se_expand.bias)
+        if training and _replaying():
+            gate = _TAPE.get()                                     # (every block: the squeeze-excite MLP's two launches)
+        else:
+            gate = ops.se_fwd(pooled, blk._se_reduce.weight.view(a.cse, a.cexp), blk._se_reduce.bias,
+                              blk._se_expand.weight.view(a.cexp, a.cse), blk._se_expand.bias)
+            if training and _TAPE is not None:
+                _TAPE.put(gate)
         wp = ops.cast_bf16(blk._project_conv.weight.view(a.cout, a.cexp))
         if keep and blk.fp8 and a.cexp % 16 == 0 and a.cout > 64:
             wg = ops.gate_weights(wp, gate)                       # [n, cout, cexp] bf16: the SE gate folded into the weights
