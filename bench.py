@@ -346,7 +346,8 @@ def main():
                                    f"AdamW; fwd+loss+bwd+optimizer; dropout/drop-connect on",
                        "global_batch": b * world, "parallelism": f"dp{world}" + (f" x {args.micro_batches} micro-batches" if args.micro_batches > 1 else ""),
                        "loss": round(loss_val, 5), "peak_hbm_gb": round(peak_gb, 1), "peak_reserved_gb": round(peak_res_gb, 1),
-                       "keep_graphs": args.keep_graphs, "recompute": args.recompute, "keep_recompute": keep_recompute},
+                       "keep_graphs": args.keep_graphs, "recompute": args.recompute, "keep_recompute": keep_recompute,
+                       "stat_tapes": bool(getattr(trainer, "stat_tapes", False)) and args.micro_batches > args.keep_graphs},
             "roofline": first, "roofline_runner_up": second, "roofline_third": third,
         }
         if n8 is not None:
