@@ -178,6 +178,8 @@ def main():
     ap.add_argument("--recompute", type=int, default=-1, choices=(-1, 0, 1, 2, 3),
                     help="MBConv activation recompute mode (EfficientNet.set_recompute); -1 = chosen with --keep-graphs")
     ap.add_argument("--keep-kept", type=int, default=7, help="kept mode-2 graphs of the N = 1 / 2 global-batch runs")
+    ap.add_argument("--as-gpus", type=int, default=0, help="with --gpus 1: run ONE rank's share of the N-GPU strong-scaling run "
+                    "(1024 / N pairs, that run's micro-batch / kept-graph policy, no collectives): the per-GPU load of the N-GPU point")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-n8-load", action="store_true", help="skip the n8_load block of the default N = 1 run")
     ap.add_argument("--fp8", action="store_true", help="fp8 (e4m3) operands for the late-stage 1x1 convolutions (config #5 arithmetic on any workload)")
@@ -215,8 +217,9 @@ def main():
         b = args.batch
     strong = args.workload in ("cfg4", "cfg5") and not args.batch
     if strong:
-        assert b % world == 0
-        b = b // world
+        share = args.as_gpus if (args.as_gpus and world == 1) else world
+        assert b % share == 0
+        b = b // share
         args.micro_batches = max(1, b // 32)
     fp8 = args.workload == "cfg5" or args.fp8
     # Kept graphs against activation memory (measured on one MI355X at the per-GPU load, scripts/recompute_sweep.sh):
