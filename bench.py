@@ -175,9 +175,10 @@ def main():
     ap.add_argument("--keep-graphs", type=int, default=0,
                     help="micro-batched step: micro-batches forwarded once with their graph kept (activation memory x this); "
                          "0 = 2 for the global-batch workloads at <= 512 pairs per GPU (2 x 32 pairs = 232 GB of the 288 GB), 1 otherwise")
-    ap.add_argument("--recompute", type=int, default=-1, choices=(-1, 0, 1, 2, 3),
+    ap.add_argument("--recompute", type=int, default=-1, choices=(-1, 0, 1, 2, 3, 4),
                     help="MBConv activation recompute mode (EfficientNet.set_recompute); -1 = chosen with --keep-graphs")
     ap.add_argument("--keep-kept", type=int, default=7, help="kept mode-2 graphs of the N = 1 / 2 global-batch runs")
+    ap.add_argument("--keep-mode", type=int, default=2, choices=(1, 2, 3, 4), help="recompute mode of those kept graphs")
     ap.add_argument("--as-gpus", type=int, default=0, help="with --gpus 1: run ONE rank's share of the N-GPU strong-scaling run "
                     "(1024 / N pairs, that run's micro-batch / kept-graph policy, no collectives): the per-GPU load of the N-GPU point")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -239,7 +240,7 @@ def main():
         # ~32 ms, and saves a ~90 ms forward), the re-forwarded micro-batches stay in mode 0 (Trainer.keep_recompute);
         # 225 GB allocated / 239 GB reserved at N = 1 (6 kept: 199 GB, 0.9 % slower; 8 kept: 0.1 % faster at 252 / 263 GB;
         # 9 kept: 278 GB -- too close to the device's 288 GiB)
-        args.keep_graphs, keep_recompute = args.keep_kept, 2
+        args.keep_graphs, keep_recompute = args.keep_kept, args.keep_mode
     if args.keep_graphs <= 0:
         args.keep_graphs = 2 if (strong and b <= 512) else 1
     util.GlobalEnv.reset()

@@ -273,9 +273,9 @@ class _MBConvFn(torch.autograd.Function):
         y = ops.bnact_apply(p, n, ohw, a.cout, st2.scale, st2.shift, 0,
                             rowscale=rowscale if a.skip else None, res=x if a.skip else None)
         # recompute modes (activation memory of a kept graph, see EfficientNet.set_recompute): 1 drops the expanded
-        # tensor e, 2 also the depthwise output d (+ the stored activation of the late stages); the backward rebuilds
-        # them from the block input x and the saved BatchNorm coefficients
-        saved.update(x=x, d=None if rc >= 2 else d, p=p, wkkc=wkkc, wp=wp, st1=st1, st2=st2, pooled=pooled, gate=gate,
+        # tensor e, 2 also the depthwise output d (+ the stored activation of the late stages), 4 also the projection
+        # output p; the backward rebuilds them from the block input x and the saved BatchNorm coefficients
+        saved.update(x=x, d=None if rc >= 2 else d, p=None if rc >= 4 else p, wkkc=wkkc, wp=wp, st1=st1, st2=st2, pooled=pooled, gate=gate,
                      act1=None if rc >= 2 else act1, keep_act=keep,
                      rowscale=rowscale if a.skip else None, geo=(n, h, w, oh, ow))
         ctx.blk, ctx.saved = blk, saved
@@ -303,6 +303,13 @@ class _MBConvFn(torch.autograd.Function):
                                pro=(st0.scale, st0.shift) if a.expand != 1 else None)
             if sv["keep_act"]:
                 act1 = ops.bnact_pool(d, n, ohw, a.cexp, st1.scale, st1.shift, 1, keep_act=True)[1]
+        if p is None:                                        # mode 4: the projection conv again, from the rebuilt d
+            if sv["keep_act"] and blk.fp8 and a.cexp % 16 == 0 and a.cout > 64:
+                p = ops.linear_fwd_fp8(act1, ops.gate_weights(sv["wp"], gate), stats=True, batch_w=(n, ohw))[0]
+            elif sv["keep_act"]:
+                p = ops.linear_fwd(act1, sv["wp"], pro=(None, None, gate, ohw))
+            else:
+                p = ops.linear_fwd(d, sv["wp"], pro=(st1.scale, st1.shift, gate, ohw))
         # y = bn2(p) * rowscale + x
         dp, dg2, db2 = ops.bnact_bwd(p, n, ohw, a.cout, st2, blk._bn2.weight, 0, g=dy, rowscale=sv["rowscale"])
         # project 1x1: p = A1 . wp^T, A1 = silu(bn1(d)) * gate   (A1 is recomputed inside the wgrad GEMM)
@@ -594,12 +601,14 @@ class EfficientNet(nn.Module):
         tensor e and its depthwise output d (the two big ones, ~72 % of the graph); 1 = e is rebuilt in the backward by
         one more expand GEMM from the block input; 2 = e and d (and the stored late-stage activation) are rebuilt
         (expand GEMM + depthwise forward); 3 = mode 1 everywhere plus mode 2 on the blocks whose depthwise stage is a
-        stride-1 3x3 (the depthwise kernels that run near HBM rate: 45 % of the d bytes of B5 for ~1.5 % more work).
+        stride-1 3x3 (the depthwise kernels that run near HBM rate: 45 % of the d bytes of B5 for ~1.5 % more work);
+        4 = mode 2 plus the projection conv's output p (needed first thing in the backward, by BatchNorm2): rebuilt from the
+        rebuilt d -- the graph of a block is then its input x alone.
         Same kernels on the same operands: gradients agree across modes to the spread of the atomically reduced ones."""
-        assert mode in (0, 1, 2, 3)
+        assert mode in (0, 1, 2, 3, 4)
         for blk in self._blocks:
             a = blk.args
-            blk.recompute = int(mode) if mode < 3 else (2 if (a.k == 3 and a.s == 1 and a.expand != 1) else 1)
+            blk.recompute = int(mode) if mode != 3 else (2 if (a.k == 3 and a.s == 1 and a.expand != 1) else 1)
         return self
 
     def set_swish(self, memory_efficient=True):
