@@ -9,6 +9,7 @@
 // as a small [workgroups][2][C] partial buffer (deterministic, no atomics).  The stride-2 data gradient is a gather.
 #include "common_hip.h"
 #include <type_traits>
+#include <cstdlib>
 #include "../../include/mammoclip_hip.h"
 
 namespace {
@@ -1160,9 +1161,24 @@ int check_common(const mc_dwconv_args& p) {
     return MC_OK;
 }
 
+// lane = column form (conv_lane.hip): MC_DW_LANE=0 never, =1 wherever it is supported, unset: the policy below
+extern "C" int mc_dwconv_lane_supported(const mc_dwconv_args* a);
+extern "C" int mc_dwconv_lane_stat_rows(const mc_dwconv_args* a);
+extern "C" int mc_dwconv_fwd_lane(const mc_dwconv_args* a, void* stream);
+bool use_lane_fwd(const mc_dwconv_args& p) {
+    static const int mode = [] { const char* e = getenv("MC_DW_LANE"); return e ? atoi(e) : -1; }();
+    if (mode == 0 || !mc_dwconv_lane_supported(&p)) return false;
+    if (mode == 1) return true;
+    // measured (scripts/dwbench.hip, same box): the 5x5 forms win from 57 output columns up (stride 1: 1.15-1.35x with the
+    // BatchNorm+SiLU prologue) and for wide stride-2 maps; the 3x3 forms and the 29-column maps stay on the marching kernels
+    if (p.k != 5) return false;
+    return p.stride == 1 ? p.ow >= 50 : p.ow >= 100;
+}
+
 }  // namespace
 
 extern "C" int mc_dwconv_stat_rows(const mc_dwconv_args* a) {
+    if (use_lane_fwd(*a)) return mc_dwconv_lane_stat_rows(a);
     if (a->k == 3) return a->stride == 1 ? march_rows<3, 1>(*a) : march_rows<3, 2>(*a);
     return a->stride == 1 ? march_rows<5, 1>(*a) : march_rows<5, 2>(*a);
 }
@@ -1186,6 +1202,7 @@ extern "C" int mc_dwconv_fwd(const mc_dwconv_args* a, void* stream) {
     MC_CHECK(!p.epi_x || (p.stride == 1 && p.epi_scale && p.epi_shift && p.epi_mean && p.epi_invstd && p.stat_partials),
              "dwconv_fwd: the BatchNorm-backward epilogue needs stride 1, scale/shift/mean/invstd and stat_partials");
     hipStream_t st = (hipStream_t)stream;
+    if (use_lane_fwd(p)) return mc_dwconv_fwd_lane(a, stream);
     if (p.k == 3 && p.stride == 1) return launch_march_cp<3, 1>(p, st);
     if (p.k == 3 && p.stride == 2) return launch_march_cp<3, 2>(p, st);
     if (p.k == 5 && p.stride == 1) return launch_march_cp<5, 1>(p, st);

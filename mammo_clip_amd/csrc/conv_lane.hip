@@ -1,0 +1,482 @@
+// Depthwise k x k convolution, "lane = column" form (round 4), NHWC bf16, gfx950.
+// [ref: efficientnet_custom.py:109-111  _depthwise_conv (+ static ZeroPad2d, efficient_net_custom_utils.py:248-276)]
+//
+// The marching kernels of conv.hip give a lane 2-4 CHANNELS of a few columns, so the K*K filter taps of those channels
+// live in 36-50 VGPRs per lane and the 5x5 instances run at two waves per SIMD: VALU-issue bound at 0.61 VALU activity
+// (profiles/r03_*).  Here all 64 lanes of a wave own the SAME channel pair and a lane is a pixel column:
+//   * the K*K taps of the pair are wave-uniform and live in SGPRs (v_pk_fma_f32 takes the 64-bit SGPR pair as an operand:
+//     measured 4.6 SIMD cycles per instruction at four waves per SIMD against 6.9 for the VGPR form at two);
+//   * a 1024-thread workgroup (16 waves = one per channel pair of a 32-channel tile, ONE workgroup per CU with all the
+//     LDS) marches down a strip of 64 * NCOL output columns; each wave keeps its A = ceil(K/S) partial output rows in
+//     registers (20 VGPRs for 5x5), so the whole kernel needs < 128 VGPRs and runs four waves per SIMD;
+//   * staged pixels are [row][position][17 dwords] in LDS (16 channel pairs + 1 pad): a lane reads ONE dword (its wave's
+//     pair) per pixel and consecutive lanes are 17 dwords apart -- conflict-free ds_read_b32; columns are stored
+//     de-interleaved by their residue mod NCOL*S so that "lane x reads column x*NCOL*S + i" is a unit-stride access;
+//   * outputs go back through an LDS tile in the same format and leave as coalesced 16-byte NHWC stores;
+//   * software pipeline with ONE barrier per block of RB input rows: in interval b every thread (1) stores the block
+//     b+1 it prefetched into registers to LDS (BN+SiLU prologue applied on the way) and copies the finished output rows
+//     of block b-1 from LDS to global memory, (2) issues the global loads of block b+2, (3) computes block b.  All
+//     waves run the same mix, so VALU, LDS and memory instructions of different waves overlap without role splitting;
+//   * work is cut into per-workgroup ranges of "virtual rows" (image, strip, output row) of equal length, so every CU
+//     gets the same number of rows whatever the image count; the two 32-channel tiles that share a 128-byte line run on
+//     the same XCD (same L2).
+// The accumulator rotation is static: a block is RB = 4 input rows, the rotation period P = A*S rows, and the interval
+// body is unrolled over the U = P / gcd(RB, P) phases.
+#include "common_hip.h"
+#include "../../include/mammoclip_hip.h"
+
+namespace lane {
+
+constexpr int pmod_c(int a, int m) { return ((a % m) + m) % m; }
+constexpr int fdiv_c(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
+constexpr int gcd_c(int a, int b) { return b == 0 ? a : gcd_c(b, a % b); }
+
+template <int K, int S, int NCOL> struct Cfg {
+    static constexpr int WAVES = 16;
+    static constexpr int NT = WAVES * 64;
+    static constexpr int TCH = 2 * WAVES;               // channels per tile: one channel pair per wave
+    static constexpr int VPP = TCH / 8;                 // 16-byte vectors per staged pixel
+    static constexpr int PXD = TCH / 2 + 1;             // dwords per LDS pixel (odd: lane = column reads are conflict-free)
+    static constexpr int NS = NCOL * S;                 // input-pixel distance between neighbouring lanes
+    static constexpr int IWMAX = 64 * NCOL * S;         // staged input columns: RB * IWMAX * VPP = a multiple of NT vectors
+    static constexpr int TOW = (IWMAX - K) / S + 1;     // output columns per strip (the last K-1 column slots of a wave idle)
+    static constexpr int IW_T = (TOW - 1) * S + K;      // staged input columns
+    static constexpr int NIN = (NCOL - 1) * S + K;      // input pixels a lane reads per row
+    static constexpr int HQ = (IW_T + NS - 1) / NS;     // positions per residue class
+    static constexpr int IWP = HQ * NS;
+    static constexpr int A = (K + S - 1) / S;           // output rows in flight per lane
+    static constexpr int P = A * S;                     // accumulator rotation period (input rows)
+    static constexpr int RB = 4;                        // input rows per block
+    static constexpr int ORB = RB / S;                  // output rows a block completes
+    static constexpr int U = P / gcd_c(RB, P);          // phases of the unrolled interval body
+    static constexpr int IN_DW = RB * IWP * PXD;
+    static constexpr int TOWP = 64 * NCOL;              // output-tile positions per row (lane x, column i -> i * 64 + x)
+    static constexpr int OUT_DW = ORB * TOWP * PXD;
+    static constexpr int NV = (RB * IW_T * VPP + NT - 1) / NT;
+    static constexpr int NVO = (ORB * TOW * VPP + NT - 1) / NT;
+    static constexpr int LDS_BYTES = (2 * IN_DW + 2 * OUT_DW) * 4 + 2 * TCH * 4 + (128 * 16 + 20) * 4;
+    static_assert(RB % S == 0 && (K - 1) % S == 0, "block / tap geometry");
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+};
+
+// Block descriptors live in LDS (a ring of 128, refilled 64 at a time by the lanes of wave 0 from a closed form of
+// block index -> (item, block)); everybody reads the few fields a pipeline stage needs when it needs them -- no long-lived
+// scalar state besides the filter taps (50 SGPRs for 5x5), no per-block cursor arithmetic on any wave's critical path.
+enum { D_FLAGS = 0, D_INB_LO, D_INB_HI, D_RLO, D_RHI, D_CLO, D_CHI, D_OUTB_LO, D_OUTB_HI, D_ORLO, D_ORHI, D_OCHI, D_WORDS = 16 };
+constexpr int NDESC = 128;
+
+// EPI (stride 1): the launch is the DATA GRADIENT of a depthwise conv whose input was silu(bn0(e)); the kernel reads e at
+// the output position, writes dZ0 = dA0 * silu'(e*scale+shift) and leaves the BatchNorm-backward partials (see conv.hip).
+// The e rows travel through the OUTPUT tile: they are staged into the slots the lane later overwrites with dZ0.
+template <int K, int S, int NCOL, bool EPI>
+__global__ __launch_bounds__(1024, 4) void dwconv_lane_fwd_kernel(const mc_dwconv_args p, int strips, int nunits, int cpairs,
+                                                                  int ctiles, int ymax) {
+    using C = Cfg<K, S, NCOL>;
+    static_assert(!EPI || S == 1, "the BatchNorm-backward epilogue is provided for stride 1");
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    uint32_t* const s_in = smem;                                    // [2][RB][IWP][PXD]
+    uint32_t* const s_out = smem + 2 * C::IN_DW;                    // [2][ORB][TOW][PXD]
+    float* const pro_lds = reinterpret_cast<float*>(smem + 2 * C::IN_DW + 2 * C::OUT_DW);   // [2][TCH]
+    int* const s_desc = reinterpret_cast<int*>(pro_lds + 2 * C::TCH);                        // [NDESC][D_WORDS]
+
+    // ---- workgroup -> (channel tile, virtual-row range); the two tiles of a 128-byte line share an XCD (block id % 8)
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, rr = bid >> 3;
+    const int member = rr & 1, unit = (rr >> 1) * 8 + xcd;
+    if (unit >= nunits) return;
+    const int cpair = unit % cpairs, yslot = unit / cpairs;
+    const int ycp = (nunits - cpair + cpairs - 1) / cpairs;          // y slots of this tile pair
+    const int ct = 2 * cpair + member;
+    if (ct >= ctiles) return;
+
+    const int tid = threadIdx.x, x = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c0 = ct * C::TCH;
+    const int cl = c0 + 2 * wv;                                      // the wave's channel pair
+    const bool ch_ok = cl < p.c;
+    const bool has_pro = p.pro_scale != nullptr;
+
+    // ---- taps of the wave's channel pair: wave-uniform -> SGPRs
+    f32x2_t w[K * K];
+#pragma unroll
+    for (int t = 0; t < K * K; ++t) {
+        float a = 0.f, b = 0.f;
+        if (ch_ok) { a = p.w_kkc[(long long)t * p.c + cl]; b = p.w_kkc[(long long)t * p.c + cl + 1]; }
+        w[t] = f32x2_t{__uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(a))),
+                       __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(b)))};
+    }
+    f32x2_t e_sc = {0.f, 0.f}, e_sh = {0.f, 0.f};
+    if constexpr (EPI) {
+        if (ch_ok) {
+            e_sc = f32x2_t{__uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(p.epi_scale[cl]))),
+                           __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(p.epi_scale[cl + 1])))};
+            e_sh = f32x2_t{__uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(p.epi_shift[cl]))),
+                           __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(p.epi_shift[cl + 1])))};
+        }
+    }
+    if (has_pro && tid < 2 * C::TCH) {
+        const int ch = tid % C::TCH;
+        const float* src = tid < C::TCH ? p.pro_scale : p.pro_shift;
+        pro_lds[tid] = (c0 + ch < p.c) ? src[c0 + ch] : 0.f;
+    }
+
+    // ---- per-thread staging geometry (constant for the whole kernel)
+    const int vv = tid % C::VPP;
+    const bool st_ch = c0 + vv * 8 < p.c;
+    unsigned meta[C::NV];                                  // row | col << 8 | LDS dword offset << 16
+#pragma unroll
+    for (int i = 0; i < C::NV; ++i) {
+        const int v = tid + i * C::NT;
+        const int row = v / (C::IW_T * C::VPP), col = (v / C::VPP) % C::IW_T;
+        const int pos = (col % C::NS) * C::HQ + col / C::NS;
+        meta[i] = (unsigned)row | ((unsigned)col << 8) | ((unsigned)((row * C::IWP + pos) * C::PXD + vv * 4) << 16);
+        if (v >= C::RB * C::IW_T * C::VPP || !st_ch) meta[i] = 0xffffu;   // row 255, col 255: never valid
+    }
+    unsigned metao[C::NVO];                                // out row | col << 8 | LDS dword offset << 16
+#pragma unroll
+    for (int i = 0; i < C::NVO; ++i) {
+        const int v = tid + i * C::NT;
+        const int row = v / (C::TOW * C::VPP), col = (v / C::VPP) % C::TOW;
+        const int pos = (col % NCOL) * 64 + col / NCOL;
+        metao[i] = (unsigned)row | ((unsigned)col << 8) | ((unsigned)((row * C::TOWP + pos) * C::PXD + vv * 4) << 16);
+        if (v >= C::ORB * C::TOW * C::VPP || !st_ch) metao[i] = 0xffffu;
+    }
+    const int in_row_pitch = p.w * p.c, out_row_pitch = p.ow * p.c;      // elements (< 2^31: one image row)
+
+    // ---- block descriptors: closed form of (block index -> item, block of the item), 64 blocks at a time by the lanes
+    // of wave 0.  A range is: rest of the first (image, strip) unit, whole units, head of the last unit.
+    // (plain local copies: lambdas that capture the by-value argument struct by reference make the compiler keep a
+    // private-memory image of it)
+    const int a_h = p.h, a_w = p.w, a_c = p.c, a_oh = p.oh, a_ow = p.ow, a_pad_t = p.pad_t, a_pad_l = p.pad_l, a_n = p.n;
+    const bf16_t* const a_x = p.x;
+    const bf16_t* const a_epi_x = p.epi_x;
+    bf16_t* const a_out = reinterpret_cast<bf16_t*>(p.out);
+    int* const s_gen = s_desc + NDESC * D_WORDS;                      // range parameters (thread 0 computes them once)
+    enum { G_U0 = 0, G_U1, G_O0, G_O1, G_NR0, G_NB0, G_NBF, G_NFULL, G_NBTOT, G_H, G_W, G_C, G_OH, G_OW, G_PT, G_PL, G_STRIPS, G_C0, G_WORDS = 20 };
+    auto nblk_of = [&](int nrows) { return ((nrows - 1) * S + K + C::RB - 1) / C::RB; };
+    if (tid == 0) {
+        const long long vt = (long long)a_n * strips * a_oh;
+        const long long v0 = vt * yslot / ycp, v1 = vt * (yslot + 1) / ycp;         // [v0, v1) of (image, strip, row)
+        const int u0 = (int)(v0 / a_oh), u1 = (int)(v1 / a_oh);
+        const int o0 = (int)(v0 - (long long)u0 * a_oh), o1 = (int)(v1 - (long long)u1 * a_oh);
+        const int nr0 = u0 == u1 ? o1 - o0 : a_oh - o0;
+        const int nb0 = nr0 > 0 ? nblk_of(nr0) : 0, nbf = nblk_of(a_oh);
+        const int nfull = u1 - u0 - 1 > 0 ? u1 - u0 - 1 : 0;
+        const int nbl = (u1 > u0 && o1 > 0) ? nblk_of(o1) : 0;
+        s_gen[G_U0] = u0; s_gen[G_U1] = u1; s_gen[G_O0] = o0; s_gen[G_O1] = o1; s_gen[G_NR0] = nr0; s_gen[G_NB0] = nb0;
+        s_gen[G_NBF] = nbf; s_gen[G_NFULL] = nfull; s_gen[G_NBTOT] = nb0 + nfull * nbf + nbl;   // blocks of this workgroup
+        s_gen[G_H] = a_h; s_gen[G_W] = a_w; s_gen[G_C] = a_c; s_gen[G_OH] = a_oh; s_gen[G_OW] = a_ow; s_gen[G_PT] = a_pad_t;
+        s_gen[G_PL] = a_pad_l; s_gen[G_STRIPS] = strips; s_gen[G_C0] = c0;
+    }
+    __syncthreads();
+    const int nbtot = __builtin_amdgcn_readfirstlane(s_gen[G_NBTOT]);
+    auto gen_desc = [&](int base) {                        // lane x of wave 0: descriptor of block base + x
+        const int t = base + x;
+        int* d = s_desc + (t & (NDESC - 1)) * D_WORDS;
+        if (t >= nbtot) { d[D_FLAGS] = 0; return; }
+        const int u0 = s_gen[G_U0], u1 = s_gen[G_U1], o0 = s_gen[G_O0], o1 = s_gen[G_O1], nr0 = s_gen[G_NR0], nb0 = s_gen[G_NB0],
+                  nbf = s_gen[G_NBF], nfull = s_gen[G_NFULL];
+        const int g_h = s_gen[G_H], g_w = s_gen[G_W], g_c = s_gen[G_C], g_oh = s_gen[G_OH], g_ow = s_gen[G_OW], g_pt = s_gen[G_PT],
+                  g_pl = s_gen[G_PL], g_strips = s_gen[G_STRIPS], g_c0 = s_gen[G_C0];
+        int u, oy0, nrows, b;
+        if (t < nb0) { u = u0; oy0 = o0; nrows = nr0; b = t; }
+        else {
+            const int t2 = t - nb0, k = t2 / nbf;
+            if (k < nfull) { u = u0 + 1 + k; oy0 = 0; nrows = g_oh; b = t2 - k * nbf; }
+            else { u = u1; oy0 = 0; nrows = o1; b = t2 - nfull * nbf; }
+        }
+        const int img = u / g_strips, strip = u - img * g_strips;
+        const int ox0 = strip * C::TOW;
+        const int iy0 = oy0 * S - g_pt + b * C::RB, ix0 = ox0 * S - g_pl;
+        const long long inb = (((long long)img * g_h + iy0) * g_w + ix0) * (long long)g_c + g_c0;
+        const int need = (nrows - 1) * S + K - b * C::RB;             // input rows of this block the item still needs
+        int rhi = g_h - iy0; if (rhi > C::RB) rhi = C::RB; if (rhi > need) rhi = need;
+        int chi = g_w - ix0; if (chi > C::IW_T) chi = C::IW_T;
+        const int o_first = (b * C::RB - (K - 1)) / S;                  // (exact: RB and K-1 are multiples of S)
+        const long long outb = (((long long)img * g_oh + oy0 + o_first) * g_ow + ox0) * (long long)g_c + g_c0;
+        int orhi = nrows - o_first; if (orhi > C::ORB) orhi = C::ORB;
+        int ochi = g_ow - ox0; if (ochi > C::TOW) ochi = C::TOW;
+        d[D_FLAGS] = 1 | (b == 0 ? 2 : 0);
+        d[D_INB_LO] = (int)(unsigned)inb; d[D_INB_HI] = (int)(inb >> 32);
+        d[D_RLO] = iy0 < 0 ? -iy0 : 0; d[D_RHI] = rhi;
+        d[D_CLO] = ix0 < 0 ? -ix0 : 0; d[D_CHI] = chi;
+        d[D_OUTB_LO] = (int)(unsigned)outb; d[D_OUTB_HI] = (int)(outb >> 32);
+        d[D_ORLO] = o_first < 0 ? -o_first : 0; d[D_ORHI] = orhi;
+        d[D_OCHI] = ochi;
+    };
+    if (wv == 0) { gen_desc(0); gen_desc(64); }            // blocks 0 .. 127
+    // the output tile doubles as the e tile of the epilogue form: slots no stage ever writes (columns >= TOW) must not
+    // hold NaN patterns (0 * NaN in the reductions)
+    for (int i = tid; i < 2 * C::OUT_DW; i += C::NT) s_out[i] = 0u;
+    __syncthreads();                                        // pro_lds, descriptors
+
+    uint4 vals[C::NV];
+    unsigned inb = 0;
+    uint4 evals[EPI ? C::NVO : 1];
+    unsigned einb = 0;
+    // global -> registers for block q
+    auto stage_load = [&](int q) {
+        const int* d = s_desc + (q & (NDESC - 1)) * D_WORDS;
+        const long long base = ((long long)d[D_INB_HI] << 32) | (unsigned)d[D_INB_LO];
+        const int rlo = d[D_RLO], rhi = d[D_RHI], clo = d[D_CLO], chi = d[D_CHI];
+        const bf16_t* org = a_x + base + vv * 8;
+        inb = 0;
+#pragma unroll
+        for (int i = 0; i < C::NV; ++i) {
+            const int row = (int)(meta[i] & 0xffu), col = (int)((meta[i] >> 8) & 0xffu);
+            const bool ok = row >= rlo && row < rhi && col >= clo && col < chi;
+            const int goff = row * in_row_pitch + col * a_c;
+            vals[i] = *reinterpret_cast<const uint4*>(ok ? org + goff : a_x);       // unconditional load, clamped address
+            inb |= (ok ? 1u : 0u) << i;
+        }
+        if constexpr (EPI) {                               // e rows of the output rows block q completes
+            const long long obase = ((long long)d[D_OUTB_HI] << 32) | (unsigned)d[D_OUTB_LO];
+            const int orlo = d[D_ORLO], orhi = d[D_ORHI], ochi = d[D_OCHI];
+            const bf16_t* eorg = a_epi_x + obase + vv * 8;
+            einb = 0;
+#pragma unroll
+            for (int i = 0; i < C::NVO; ++i) {
+                const int row = (int)(metao[i] & 0xffu), col = (int)((metao[i] >> 8) & 0xffu);
+                const bool ok = row >= orlo && row < orhi && col < ochi;
+                const int goff = row * out_row_pitch + col * a_c;
+                evals[i] = *reinterpret_cast<const uint4*>(ok ? eorg + goff : a_epi_x);
+                einb |= (ok ? 1u : 0u) << i;
+            }
+        }
+    };
+    // registers -> LDS in-buffer `buf` (BN+SiLU prologue on real pixels; padding stays zero)
+    auto stage_store = [&](int buf) {
+        uint32_t* dst = s_in + buf * C::IN_DW;
+        float ps[8], pt[8];
+        if (has_pro) { load8f(&pro_lds[vv * 8], ps); load8f(&pro_lds[C::TCH + vv * 8], pt); }
+#pragma unroll
+        for (int i = 0; i < C::NV; ++i) {
+            if ((meta[i] & 0xffu) != 0xffu) {
+                const bool real = (inb >> i) & 1u;
+                uint4 val = real ? vals[i] : make_uint4(0u, 0u, 0u, 0u);
+                if (has_pro && real) {
+                    float f[8];
+                    unpack8(val, f);
+                    bn_silu8(f, ps, pt);
+                    val = pack8(f);
+                }
+                uint32_t* dd = dst + (meta[i] >> 16);
+                dd[0] = val.x; dd[1] = val.y; dd[2] = val.z; dd[3] = val.w;
+            }
+        }
+    };
+    // finished output rows of block q: LDS out-buffer `buf` -> global
+    auto flush_out = [&](int q, int buf) {
+        const int* d = s_desc + (q & (NDESC - 1)) * D_WORDS;
+        const long long obase = ((long long)d[D_OUTB_HI] << 32) | (unsigned)d[D_OUTB_LO];
+        const int orlo = d[D_ORLO], orhi = d[D_ORHI], ochi = d[D_OCHI];
+        const uint32_t* src = s_out + buf * C::OUT_DW;
+        bf16_t* org = a_out + obase + vv * 8;
+#pragma unroll
+        for (int i = 0; i < C::NVO; ++i) {
+            const int row = (int)(metao[i] & 0xffu), col = (int)((metao[i] >> 8) & 0xffu);
+            if (row >= orlo && row < orhi && col < ochi) {
+                const uint32_t* sp = src + (metao[i] >> 16);
+                const uint4 val = make_uint4(sp[0], sp[1], sp[2], sp[3]);
+                *reinterpret_cast<uint4*>(org + (row * out_row_pitch + col * a_c)) = val;
+            }
+        }
+    };
+    auto estore = [&](int buf) {                           // EPI: the e rows of the block just loaded, into its output slots
+        if constexpr (EPI) {
+            uint32_t* dst = s_out + buf * C::OUT_DW;
+#pragma unroll
+            for (int i = 0; i < C::NVO; ++i) {
+                if ((metao[i] & 0xffu) != 0xffu) {
+                    const uint4 val = ((einb >> i) & 1u) ? evals[i] : make_uint4(0u, 0u, 0u, 0u);
+                    uint32_t* dd = dst + (metao[i] >> 16);
+                    dd[0] = val.x; dd[1] = val.y; dd[2] = val.z; dd[3] = val.w;
+                }
+            }
+        }
+    };
+
+    f32x2_t acc[NCOL][C::A];
+#pragma unroll
+    for (int i = 0; i < NCOL; ++i)
+#pragma unroll
+        for (int a = 0; a < C::A; ++a) acc[i][a] = f32x2_t{0.f, 0.f};
+    f32x2_t ssum = {0.f, 0.f}, ssq = {0.f, 0.f};
+
+    // interval q: store block q (loaded in interval q-1), flush block q-2, load block q+1, compute block q-1.
+    // in-buffer of block q: q & 1; out-buffer of block q: q & 1.  nbtot + 2 intervals.
+    if (nbtot > 0) stage_load(0);
+    int q = 0;
+    while (true) {
+#pragma unroll
+        for (int ph = 0; ph < C::U; ++ph) {
+            if (wv == 0 && q >= 66 && ((q - 2) & 63) == 0) gen_desc(q + 62);   // refill the slots of blocks q-66 .. q-3
+            const bool v_st = q < nbtot, v_ld = q + 1 < nbtot, v_cp = q >= 1 && q <= nbtot, v_fl = q >= 2;
+            // (1) registers -> LDS for block q; finished rows of block q-2 -> global (EPI: then the e rows of block q)
+            __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0): the prefetched registers (see conv.hip)
+            if (v_st) stage_store(q & 1);
+            if (v_fl) flush_out(q - 2, q & 1);
+            if (EPI && v_st) estore(q & 1);
+            // (2) prefetch block q+1
+            if (v_ld) stage_load(q + 1);
+            // (3) compute block q-1
+            if (v_cp) {
+                const int* d = s_desc + ((q - 1) & (NDESC - 1)) * D_WORDS;
+                const int orlo = __builtin_amdgcn_readfirstlane(d[D_ORLO]), orhi = __builtin_amdgcn_readfirstlane(d[D_ORHI]);
+                const int ochi = d[D_OCHI];
+                const uint32_t* lin = s_in + ((q - 1) & 1) * C::IN_DW + x * C::PXD + wv;
+                uint32_t* lout = s_out + ((q - 1) & 1) * C::OUT_DW + x * C::PXD + wv;
+                uint32_t cm[NCOL];                                     // all ones where the lane's i-th column exists
+#pragma unroll
+                for (int i = 0; i < NCOL; ++i) cm[i] = (ch_ok && x * NCOL + i < ochi) ? 0xffffffffu : 0u;
+#pragma unroll
+                for (int j = 0; j < C::RB; ++j) {
+                    const int jr = (ph * C::RB + j) % C::P;            // rotation index of this input row (static)
+                    f32x2_t in[C::NIN];
+#pragma unroll
+                    for (int i = 0; i < C::NIN; ++i) {
+                        const uint32_t v = lin[(j * C::IWP + (i % C::NS) * C::HQ + i / C::NS) * C::PXD];
+                        in[i] = f32x2_t{bf_lo(v), bf_hi(v)};
+                    }
+#pragma unroll
+                    for (int kh = 0; kh < K; ++kh) {
+                        if (pmod_c(jr - kh, S) != 0) continue;
+                        const int sl = pmod_c(fdiv_c(jr - kh, S), C::A);
+#pragma unroll
+                        for (int kw = 0; kw < K; ++kw)
+#pragma unroll
+                            for (int i = 0; i < NCOL; ++i) {
+                                // the first contribution of an output row (tap row 0) starts its accumulator
+                                if (kh == 0 && kw == 0) acc[i][sl] = in[i * S + kw] * w[kh * K + kw];
+                                else acc[i][sl] = __builtin_elementwise_fma(in[i * S + kw], w[kh * K + kw], acc[i][sl]);
+                            }
+                    }
+                    if (pmod_c(jr - (K - 1), S) == 0) {                 // an output row is complete: out-tile row j / S
+                        const int sl = pmod_c(fdiv_c(jr - (K - 1), S), C::A);
+                        const bool o_ok = j / S >= orlo && j / S < orhi;  // (wave-uniform)
+#pragma unroll
+                        for (int i = 0; i < NCOL; ++i) {
+                            uint32_t* slot = lout + ((j / S) * C::TOWP + i * 64) * C::PXD;
+                            if constexpr (EPI) {
+                                const uint32_t ew = *slot;
+                                const f32x2_t e2 = {bf_lo(ew), bf_hi(ew)};
+                                const f32x2_t z = __builtin_elementwise_fma(e2, e_sc, e_sh);
+                                const f32x2_t dz = acc[i][sl] * silu_grad2_f(z);
+                                const uint32_t o2 = pack_bf2(dz.x, dz.y);
+                                *slot = o2;
+                                if (o_ok) {
+                                    const uint32_t m = o2 & cm[i];
+                                    const f32x2_t r = {bf_lo(m), bf_hi(m)};          // reductions of the stored (rounded) dZ0
+                                    ssum += r;
+                                    ssq = __builtin_elementwise_fma(r, e2, ssq);
+                                }
+                            } else {
+                                const uint32_t o2 = pack_bf2(acc[i][sl].x, acc[i][sl].y);
+                                *slot = o2;
+                                if (o_ok) {
+                                    const uint32_t m = o2 & cm[i];
+                                    const f32x2_t r = {bf_lo(m), bf_hi(m)};          // statistics of the stored (rounded) tensor
+                                    ssum += r;
+                                    ssq = __builtin_elementwise_fma(r, r, ssq);
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            ++q;
+            if (q >= nbtot + 2) goto done;
+        }
+    }
+done:
+    if (p.stat_partials) {
+        // the 64 lanes of a wave hold the same channel pair: butterfly sums, lane 0 writes
+        float s0 = wave_sum(ssum.x), s1 = wave_sum(ssum.y), q0 = wave_sum(ssq.x), q1 = wave_sum(ssq.y);
+        if (x == 0 && ch_ok) {
+            if constexpr (EPI) {
+                // sum dZ * xhat = invstd * (sum dZ * e - mean * sum dZ)
+                q0 = p.epi_invstd[cl] * (q0 - p.epi_mean[cl] * s0);
+                q1 = p.epi_invstd[cl + 1] * (q1 - p.epi_mean[cl + 1] * s1);
+            }
+            float* r0 = p.stat_partials + ((long long)yslot * 2 + 0) * p.c + cl;
+            float* r1 = p.stat_partials + ((long long)yslot * 2 + 1) * p.c + cl;
+            r0[0] = s0; r0[1] = s1; r1[0] = q0; r1[1] = q1;
+            if (yslot == 0)
+                for (int yy = ycp; yy < ymax; ++yy) {                 // tile pairs with one y slot fewer: zero rows
+                    float* z0 = p.stat_partials + ((long long)yy * 2) * p.c + cl;
+                    z0[0] = 0.f; z0[1] = 0.f; z0[p.c] = 0.f; z0[p.c + 1] = 0.f;
+                }
+        }
+    }
+}
+
+struct Plan { int strips, nunits, cpairs, ctiles, ymax, grid; };
+template <typename C> Plan plan(const mc_dwconv_args& p) {
+    Plan m;
+    m.strips = mc_div_up(p.ow, C::TOW);
+    m.ctiles = mc_div_up(p.c, C::TCH);
+    m.cpairs = (m.ctiles + 1) / 2;
+    const long long vt = (long long)p.n * m.strips * p.oh;
+    long long ycap = vt / 8;                                          // at least 8 output rows per workgroup
+    if (ycap < 1) ycap = 1;
+    long long nunits = ycap * m.cpairs;
+    if (nunits > 128) nunits = 128;                                   // 256 CUs, two tiles per unit
+    if (nunits < m.cpairs) nunits = m.cpairs;
+    m.nunits = (int)nunits;
+    m.ymax = (m.nunits + m.cpairs - 1) / m.cpairs;
+    m.grid = 16 * ((m.nunits + 7) / 8);
+    return m;
+}
+
+template <int K, int S, int NCOL, bool EPI> int launch(const mc_dwconv_args& p, hipStream_t st) {
+    using C = Cfg<K, S, NCOL>;
+    static unsigned long long attr_done = 0;
+    auto kern = dwconv_lane_fwd_kernel<K, S, NCOL, EPI>;
+    MC_SET_MAX_LDS(attr_done, kern, C::LDS_BYTES);
+    const Plan m = plan<C>(p);
+    hipLaunchKernelGGL(kern, dim3(m.grid), dim3(C::NT), C::LDS_BYTES, st, p, m.strips, m.nunits, m.cpairs, m.ctiles, m.ymax);
+    MC_LAUNCH_CHECK();
+    return MC_OK;
+}
+
+}  // namespace lane
+
+// Shapes the lane = column form takes (the marching kernels of conv.hip keep everything else): at most 128 tile pairs
+// (c <= 8192) and enough columns to fill a 64-lane strip reasonably.
+extern "C" int mc_dwconv_lane_supported(const mc_dwconv_args* a) {
+    const mc_dwconv_args& p = *a;
+    if (p.c % 8 != 0 || p.c > 8192) return 0;
+    if (!((p.k == 3 || p.k == 5) && (p.stride == 1 || p.stride == 2))) return 0;
+    if (p.epi_x && p.stride != 1) return 0;
+    return 1;
+}
+
+extern "C" int mc_dwconv_lane_stat_rows(const mc_dwconv_args* a) {
+    const mc_dwconv_args& p = *a;
+    const bool wide = p.stride == 1 && p.ow > (p.k == 3 ? lane::Cfg<3, 1, 1>::TOW : lane::Cfg<5, 1, 1>::TOW);
+    if (p.k == 3) {
+        if (p.stride == 2) return lane::plan<lane::Cfg<3, 2, 1>>(p).ymax;
+        return wide ? lane::plan<lane::Cfg<3, 1, 2>>(p).ymax : lane::plan<lane::Cfg<3, 1, 1>>(p).ymax;
+    }
+    if (p.stride == 2) return lane::plan<lane::Cfg<5, 2, 1>>(p).ymax;
+    return wide ? lane::plan<lane::Cfg<5, 1, 2>>(p).ymax : lane::plan<lane::Cfg<5, 1, 1>>(p).ymax;
+}
+
+extern "C" int mc_dwconv_fwd_lane(const mc_dwconv_args* a, void* stream) {
+    const mc_dwconv_args& p = *a;
+    MC_CHECK(mc_dwconv_lane_supported(a), "dwconv_fwd_lane: unsupported shape");
+    MC_CHECK(p.x && p.w_kkc && p.out, "dwconv_fwd_lane: null x / w / out");
+    MC_CHECK(!p.epi_x || (p.epi_scale && p.epi_shift && p.epi_mean && p.epi_invstd && p.stat_partials),
+             "dwconv_fwd_lane: the BatchNorm-backward epilogue needs scale/shift/mean/invstd and stat_partials");
+    hipStream_t st = (hipStream_t)stream;
+    const bool wide = p.stride == 1 && p.ow > (p.k == 3 ? lane::Cfg<3, 1, 1>::TOW : lane::Cfg<5, 1, 1>::TOW);
+    if (p.k == 3) {
+        if (p.stride == 2) return lane::launch<3, 2, 1, false>(p, st);
+        if (p.epi_x) return wide ? lane::launch<3, 1, 2, true>(p, st) : lane::launch<3, 1, 1, true>(p, st);
+        return wide ? lane::launch<3, 1, 2, false>(p, st) : lane::launch<3, 1, 1, false>(p, st);
+    }
+    if (p.stride == 2) return lane::launch<5, 2, 1, false>(p, st);
+    if (p.epi_x) return wide ? lane::launch<5, 1, 2, true>(p, st) : lane::launch<5, 1, 1, true>(p, st);
+    return wide ? lane::launch<5, 1, 2, false>(p, st) : lane::launch<5, 1, 1, false>(p, st);
+}

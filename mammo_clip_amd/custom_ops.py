@@ -264,3 +264,5 @@ for _name, (_schema, _impl, _meta) in _MODEL_OPS.items():
 
 OPS = ("linear", "linear_dgrad", "linear_wgrad", "dwconv", "dwconv_bwd_data", "dwconv_bwd_weight", "gelu", "gelu_bwd",
        "softmax", "l2norm", "cross_entropy_") + tuple(_MODEL_OPS)
+
+ops._bind_model_ops()      # ops' wrappers resolve the overloads once (either module may be imported first)

@@ -135,6 +135,7 @@ class Trainer:
         # of 100 GB, so more of them fit; the re-forwarded micro-batches (graph alive for one forward + backward only) keep
         # the model's own mode.  None = the model's mode everywhere.
         self.keep_recompute = keep_recompute
+        self._sink = None                       # ops.GradSink of the step in flight (installed only around a backward call)
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self.buckets = GradBuckets(list(model.parameters()), bucket_mb << 20) if self.world > 1 else None
         if self.world > 1:
@@ -143,8 +144,25 @@ class Trainer:
             sync_parameters_and_buffers(model)
 
     def step(self, batch: Dict, micro_batches: int = 1) -> Dict[str, torch.Tensor]:
-        if micro_batches > 1:
-            return self._step_micro(batch, micro_batches)
+        try:
+            if micro_batches > 1:
+                return self._step_micro(batch, micro_batches)
+            return self._step_single(batch)
+        except BaseException:
+            self._abort_step()                  # no partial gradients / disarmed buckets survive into the next step
+            raise
+
+    def _abort_step(self):
+        """a step that raised (OOM, a data error) leaves nothing behind: the sink with its partial gradients is dropped,
+        the module-level hand-over point is cleared and the bucket hooks are re-armed"""
+        self._sink = None
+        ops.GRAD_SINK = None
+        if self.buckets is not None:
+            self.buckets.enabled = True
+            self.buckets.pending = []
+            self.buckets.handles = []
+
+    def _step_single(self, batch: Dict) -> Dict[str, torch.Tensor]:
         self.model.train()
         self.optimizer.zero_grad(set_to_none=True)
         if self.buckets is not None:
@@ -163,21 +181,23 @@ class Trainer:
         """one backward call; with the gradient sink the hand-written functions deliver their parameter gradients to it"""
         if not self.grad_sink:
             return run()
-        if ops.GRAD_SINK is None:
-            ops.GRAD_SINK = ops.GradSink()
+        if self._sink is None:
+            self._sink = ops.GradSink()
+        # the sink is visible to the backward functions only while THIS backward call runs: a backward outside the Trainer
+        # (or after a failed step) sees plain autograd semantics
+        ops.GRAD_SINK = self._sink
         try:
             run()
-        except BaseException:
+        finally:
             ops.GRAD_SINK = None
-            raise
-        ops.GRAD_SINK.flush()
+        self._sink.flush()
 
     def _grads_done(self, hooked: bool):
         """after the last backward of a step: sink -> param.grad, then the data-parallel mean.  ``hooked``: the bucket
         hooks were armed during the backward that made the gradients final (they have launched the full buckets)."""
-        if self.grad_sink and ops.GRAD_SINK is not None:
-            ops.GRAD_SINK.finish()
-            ops.GRAD_SINK = None
+        if self._sink is not None:
+            self._sink.finish()
+            self._sink = None
         if self.buckets is not None:
             if hooked:
                 self.buckets.finish()
@@ -291,8 +311,9 @@ def _step_micro(self, batch: Dict, k: int) -> Dict[str, torch.Tensor]:
             finally:
                 if set_tape is not None:
                     set_tape(None)
-                    assert tapes[i].pos == len(tapes[i].items), "statistics tape out of step with the re-forward"
-                    tapes[i] = None
+            if set_tape is not None:               # (success path only: an assert in the finally would mask the real error)
+                assert tapes[i].pos == len(tapes[i].items), "statistics tape out of step with the re-forward"
+                tapes[i] = None
             ks = list(leaf)
             self._backward(lambda: torch.autograd.backward([out[kk] for kk in ks], [leaf[kk].grad[i * b:(i + 1) * b] for kk in ks]))
     finally:

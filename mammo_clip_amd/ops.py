@@ -1067,13 +1067,17 @@ def deliver_param_grads(params, grads):
     return (None,) * len(grads)
 
 
-from . import custom_ops  # noqa: E402,F401  (registers torch.ops.mammoclip.*; imported last: it binds the implementations above)
-
 # the overloads the wrappers above call (torch.ops.mammoclip.<name>.default, resolved once: two attribute look-ups and the
-# overload resolution per call are host time the launch-bound configurations notice)
-_OP_CONV1X1 = torch.ops.mammoclip.conv1x1.default
-_OP_CONV1X1_DGRAD = torch.ops.mammoclip.conv1x1_dgrad.default
-_OP_CONV1X1_WGRAD = torch.ops.mammoclip.conv1x1_wgrad.default
-_OP_DWCONV_BN = torch.ops.mammoclip.dwconv_bn.default
-_OP_DWCONV_DGRAD = torch.ops.mammoclip.dwconv_dgrad.default
-_OP_DWCONV_WGRAD = torch.ops.mammoclip.dwconv_wgrad.default
+# overload resolution per call are host time the launch-bound configurations notice).  custom_ops binds them through
+# _bind_model_ops() at the end of its own import, so either module may be imported first.
+_OP_CONV1X1 = _OP_CONV1X1_DGRAD = _OP_CONV1X1_WGRAD = _OP_DWCONV_BN = _OP_DWCONV_DGRAD = _OP_DWCONV_WGRAD = None
+
+
+def _bind_model_ops():
+    global _OP_CONV1X1, _OP_CONV1X1_DGRAD, _OP_CONV1X1_WGRAD, _OP_DWCONV_BN, _OP_DWCONV_DGRAD, _OP_DWCONV_WGRAD
+    ns = torch.ops.mammoclip
+    _OP_CONV1X1, _OP_CONV1X1_DGRAD, _OP_CONV1X1_WGRAD = ns.conv1x1.default, ns.conv1x1_dgrad.default, ns.conv1x1_wgrad.default
+    _OP_DWCONV_BN, _OP_DWCONV_DGRAD, _OP_DWCONV_WGRAD = ns.dwconv_bn.default, ns.dwconv_dgrad.default, ns.dwconv_wgrad.default
+
+
+from . import custom_ops  # noqa: E402,F401  (registers torch.ops.mammoclip.* and calls _bind_model_ops(); imported last)

@@ -20,7 +20,8 @@ from .arch import Arch, BN_EPS, BN_MOMENTUM
 # rounded to ``ROUND_DTYPE`` and back where the HIP path STORES (or feeds an MFMA with) that class -- "E" expand-conv
 # output, "D" depthwise output, "P" project-conv output, "Y" block output / residual stream (also the stem output),
 # "A1" the gated activation operand of the project GEMM, "W" the 1x1 / stem convolution weights, "H" the head-conv
-# output, "IN" the stem's input patches.  None = the plain fp32 restatement.  Straight-through in backward (the rounding has zero-width gradient
+# output, "IN" the stem's input patches, "A0" the activated depthwise input silu(bn0(e)) (rounded when it is staged in LDS),
+# "DW" the depthwise filter taps (bf16 operands of the packed dot-product form of the depthwise kernels).  None = the plain fp32 restatement.  Straight-through in backward (the rounding has zero-width gradient
 # support otherwise).
 ROUND = None
 ROUND_DTYPE = torch.bfloat16
@@ -89,7 +90,7 @@ def mbconv(sd, p: str, x, blk, train: bool, new_buffers=None, taps: Optional[dic
         if taps is not None:
             taps[p + ".expand_out"] = x
         x = swish(_bn(sd, p + "._bn0", x, train, new_buffers))
-    x = _q("D", _conv_static_same(x, sd[p + "._depthwise_conv.weight"], None, blk.s, blk.pad, groups=blk.cexp))
+    x = _q("D", _conv_static_same(_q("A0", x), _q("DW", sd[p + "._depthwise_conv.weight"]), None, blk.s, blk.pad, groups=blk.cexp))
     if taps is not None:
         taps[p + ".dw_out"] = x
     x = swish(_bn(sd, p + "._bn1", x, train, new_buffers))

@@ -1,6 +1,7 @@
 // Standalone micro-benchmark / phase profiler for the depthwise kernels (developer tool, not part of the library).
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 [-DMARCH_PROF] scripts/dwbench.hip -o /tmp/dwbench && /tmp/dwbench
 #include "../mammo_clip_amd/csrc/conv.hip"
+#include "../mammo_clip_amd/csrc/conv_lane.hip"
 #include <cstdio>
 #include <vector>
 static char g_err_msg[256];
