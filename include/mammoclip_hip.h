@@ -244,6 +244,13 @@ int mc_dwconv_bwd_data_stat_rows(const mc_dwconv_args* args);
 int mc_dwconv_fwd(const mc_dwconv_args* args, void* stream);
 int mc_dwconv_bwd_data(const mc_dwconv_args* args, void* stream);
 int mc_dwconv_bwd_weight(const mc_dwconv_args* args, void* stream);
+/* Two device forms of the forward / stride-1 data gradient exist: the "marching" kernels (a lane owns 2-4 channels, taps
+ * in VGPRs) and the "lane = column" kernels of round 4 (a wave owns one channel pair, taps in SGPRs, 16-wave workgroups;
+ * conv_lane.hip).  mc_dwconv_fwd picks by shape (5x5 from 50 output columns up); this switch overrides the choice for
+ * tests and A/B timing: -1 policy, 0 marching only, 1 lane = column wherever supported.  Returns the previous mode.
+ * (Environment variable MC_DW_LANE sets the initial mode.)  Both forms produce bit-identical outputs. */
+int mc_dwconv_set_lane_mode(int mode);
+int mc_dwconv_lane_supported(const mc_dwconv_args* args);
 
 /* ------------------------------------------------------------------------------------------------
  * training-mode BatchNorm pieces [ref: efficientnet_custom.py:64,74,88,177,205; momentum 0.01, eps 1e-3]

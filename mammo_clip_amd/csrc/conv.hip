@@ -1165,8 +1165,10 @@ int check_common(const mc_dwconv_args& p) {
 extern "C" int mc_dwconv_lane_supported(const mc_dwconv_args* a);
 extern "C" int mc_dwconv_lane_stat_rows(const mc_dwconv_args* a);
 extern "C" int mc_dwconv_fwd_lane(const mc_dwconv_args* a, void* stream);
+int g_lane_mode = -2;                 // -2: not read yet; -1 policy; 0 never; 1 wherever supported
 bool use_lane_fwd(const mc_dwconv_args& p) {
-    static const int mode = [] { const char* e = getenv("MC_DW_LANE"); return e ? atoi(e) : -1; }();
+    if (g_lane_mode == -2) { const char* e = getenv("MC_DW_LANE"); g_lane_mode = e ? atoi(e) : -1; }
+    const int mode = g_lane_mode;
     if (mode == 0 || !mc_dwconv_lane_supported(&p)) return false;
     if (mode == 1) return true;
     // measured (scripts/dwbench.hip, same box): the 5x5 forms win from 57 output columns up (stride 1: 1.15-1.35x with the
@@ -1176,6 +1178,14 @@ bool use_lane_fwd(const mc_dwconv_args& p) {
 }
 
 }  // namespace
+
+// developer / test switch of the depthwise forward form: -1 = the built-in policy, 0 = marching kernels only, 1 = the
+// lane = column kernels wherever they support the shape.  Returns the previous mode.
+extern "C" int mc_dwconv_set_lane_mode(int mode) {
+    const int old = g_lane_mode == -2 ? -1 : g_lane_mode;
+    g_lane_mode = mode;
+    return old;
+}
 
 extern "C" int mc_dwconv_stat_rows(const mc_dwconv_args* a) {
     if (use_lane_fwd(*a)) return mc_dwconv_lane_stat_rows(a);

@@ -105,9 +105,11 @@ __global__ __launch_bounds__(1024, 4) void dwconv_lane_fwd_kernel(const mc_dwcon
         w[t] = f32x2_t{__uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(a))),
                        __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(b)))};
     }
-    f32x2_t e_sc = {0.f, 0.f}, e_sh = {0.f, 0.f};
+    f32x2_t e_sc = {0.f, 0.f}, e_sh = {0.f, 0.f}, e_mu = {0.f, 0.f};
     if constexpr (EPI) {
         if (ch_ok) {
+            e_mu = f32x2_t{__uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(p.epi_mean[cl]))),
+                           __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(p.epi_mean[cl + 1])))};
             e_sc = f32x2_t{__uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(p.epi_scale[cl]))),
                            __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(p.epi_scale[cl + 1])))};
             e_sh = f32x2_t{__uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(p.epi_shift[cl]))),
@@ -368,7 +370,7 @@ __global__ __launch_bounds__(1024, 4) void dwconv_lane_fwd_kernel(const mc_dwcon
                                     const uint32_t m = o2 & cm[i];
                                     const f32x2_t r = {bf_lo(m), bf_hi(m)};          // reductions of the stored (rounded) dZ0
                                     ssum += r;
-                                    ssq = __builtin_elementwise_fma(r, e2, ssq);
+                                    ssq = __builtin_elementwise_fma(r, e2 - e_mu, ssq);   // centred: no cancelling difference at the end
                                 }
                             } else {
                                 const uint32_t o2 = pack_bf2(acc[i][sl].x, acc[i][sl].y);
@@ -395,9 +397,9 @@ done:
         float s0 = wave_sum(ssum.x), s1 = wave_sum(ssum.y), q0 = wave_sum(ssq.x), q1 = wave_sum(ssq.y);
         if (x == 0 && ch_ok) {
             if constexpr (EPI) {
-                // sum dZ * xhat = invstd * (sum dZ * e - mean * sum dZ)
-                q0 = p.epi_invstd[cl] * (q0 - p.epi_mean[cl] * s0);
-                q1 = p.epi_invstd[cl + 1] * (q1 - p.epi_mean[cl + 1] * s1);
+                // sum dZ * xhat = invstd * sum dZ * (e - mean)
+                q0 = p.epi_invstd[cl] * q0;
+                q1 = p.epi_invstd[cl + 1] * q1;
             }
             float* r0 = p.stat_partials + ((long long)yslot * 2 + 0) * p.c + cl;
             float* r1 = p.stat_partials + ((long long)yslot * 2 + 1) * p.c + cl;

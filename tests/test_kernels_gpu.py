@@ -893,6 +893,69 @@ def test_dwconv_dgrad_with_bn_backward_epilogue(k, n, h, w, c):
     check(db, db_ref, 1e-2, "dbeta")
 
 
+LANE_CASES = [  # k, s, n, h, w, c: several strips per row (w > 124 / 62), several items per workgroup, ragged channel tiles
+    (5, 1, 3, 150, 260, 96), (5, 1, 5, 95, 57, 72), (5, 1, 2, 61, 130, 40), (3, 1, 2, 70, 300, 48), (3, 1, 3, 33, 59, 24),
+    (5, 2, 2, 120, 250, 48), (3, 2, 3, 77, 131, 40), (5, 1, 33, 48, 29, 32), (5, 1, 1, 300, 114, 64)]
+
+
+@pytest.mark.parametrize("k,s,n,h,w,c", LANE_CASES)
+@pytest.mark.parametrize("use_pro", [False, True])
+def test_dwconv_lane_form_equals_marching_form(k, s, n, h, w, c, use_pro):
+    """Round 4: the lane = column depthwise kernels (conv_lane.hip) against the marching kernels on the same inputs -- both
+    add an output's taps in the same order with fp32 FMAs, so the OUTPUT is bit-identical; the BatchNorm statistics
+    partials are sums of the same stored values in a different order (<= 2e-5 of the largest column sum)."""
+    Lh = L.load()
+    pad = (k - 1) // 2 if s == 1 else (k - 2) // 2
+    oh, ow = (h + s - 1) // s, (w + s - 1) // s
+    x = rnd(n * h * w, c, seed=31)
+    wk = rnd(k * k, c, seed=32, dtype=torch.float32) * 0.3
+    pro = (rnd(c, seed=33, dtype=torch.float32) * 0.3 + 1.0, rnd(c, seed=34, dtype=torch.float32) * 0.3) if use_pro else None
+    out = {}
+    old = Lh.mc_dwconv_set_lane_mode(0)
+    try:
+        for mode in (0, 1):
+            Lh.mc_dwconv_set_lane_mode(mode)
+            out[mode] = ops.dwconv_fwd(x, wk, n, h, w, c, k, s, pad, pad, oh, ow, pro=pro, stats=True)
+    finally:
+        Lh.mc_dwconv_set_lane_mode(old)
+    torch.cuda.synchronize()
+    assert torch.equal(out[0][0], out[1][0]), "lane-form output differs from the marching form"
+    s0, s1 = out[0][1].double().sum(0), out[1][1].double().sum(0)
+    assert float((s0 - s1).abs().max()) <= 2e-5 * float(s0.abs().max()), "statistics partials"
+
+
+@pytest.mark.parametrize("k,n,h,w,c", [(5, 3, 150, 260, 96), (5, 5, 95, 57, 72), (3, 2, 70, 300, 48), (5, 33, 48, 29, 32)])
+def test_dwconv_lane_form_epilogue_equals_marching_form(k, n, h, w, c):
+    """the same for the stride-1 data gradient with the BatchNorm-backward epilogue (dZ0 bit-identical, partials to 2e-5)"""
+    Lh = L.load()
+    pad = (k - 1) // 2
+    e = rnd(n * h * w, c, seed=1)
+    dd = rnd(n * h * w, c, seed=2)
+    wk = rnd(k * k, c, seed=3, dtype=torch.float32)
+    gamma, beta = rnd(c, seed=4, dtype=torch.float32) * 0.2 + 1.0, rnd(c, seed=5, dtype=torch.float32) * 0.1
+    ef = e.float()
+    mean, var = ef.mean(0), ef.var(0, unbiased=False)
+    st = ops.BNStats()
+    st.mean, st.invstd = mean.contiguous(), (var + 1e-3).rsqrt().contiguous()
+    st.scale = (gamma * st.invstd).contiguous()
+    st.shift = (beta - mean * st.scale).contiguous()
+    st.count = float(n * h * w)
+    wflip = wk.flip(0).contiguous()
+    out = {}
+    old = Lh.mc_dwconv_set_lane_mode(0)
+    try:
+        for mode in (0, 1):
+            Lh.mc_dwconv_set_lane_mode(mode)
+            out[mode] = ops.dwconv_bwd_data(dd, wk, n, h, w, c, k, 1, pad, pad, h, w, w_kkc_flipped=wflip, epi=(e, st))
+    finally:
+        Lh.mc_dwconv_set_lane_mode(old)
+    torch.cuda.synchronize()
+    assert torch.equal(out[0][0], out[1][0]), "lane-form dZ0 differs from the marching form"
+    s0, s1 = out[0][1].double().sum(0), out[1][1].double().sum(0)
+    scale = s0.abs().amax(dim=1, keepdim=True)
+    assert float(((s0 - s1).abs() / scale).max()) <= 2e-4, "BatchNorm-backward partials"
+
+
 @pytest.mark.parametrize("k,n,h,w,c,pad", [(3, 2, 40, 33, 144, (0, 1)), (3, 2, 41, 34, 240, (1, 1)), (5, 2, 29, 23, 384, (1, 2)),
                                           (5, 1, 60, 64, 64, (2, 2)), (3, 3, 17, 50, 48, (0, 0)), (5, 2, 30, 31, 1056, (2, 1))])
 def test_dwconv_s2_dgrad_with_bn_backward_epilogue(k, n, h, w, c, pad):
