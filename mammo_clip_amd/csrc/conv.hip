@@ -1165,6 +1165,7 @@ int check_common(const mc_dwconv_args& p) {
 extern "C" int mc_dwconv_lane_supported(const mc_dwconv_args* a);
 extern "C" int mc_dwconv_lane_stat_rows(const mc_dwconv_args* a);
 extern "C" int mc_dwconv_fwd_lane(const mc_dwconv_args* a, void* stream);
+extern "C" int mc_dwconv_bwd_weight_lane(const mc_dwconv_args* a, void* stream);
 int g_lane_mode = -2;                 // -2: not read yet; -1 policy; 0 never; 1 wherever supported
 bool use_lane_fwd(const mc_dwconv_args& p) {
     if (g_lane_mode == -2) { const char* e = getenv("MC_DW_LANE"); g_lane_mode = e ? atoi(e) : -1; }
@@ -1173,8 +1174,17 @@ bool use_lane_fwd(const mc_dwconv_args& p) {
     if (mode == 1) return true;
     // measured (scripts/dwbench.hip, same box): the 5x5 forms win from 57 output columns up (stride 1: 1.15-1.35x with the
     // BatchNorm+SiLU prologue) and for wide stride-2 maps; the 3x3 forms and the 29-column maps stay on the marching kernels
-    if (p.k != 5) return false;
-    return p.stride == 1 ? p.ow >= 50 : p.ow >= 100;
+    if (p.k == 5) return p.stride == 1 ? p.ow >= 50 : p.ow >= 100;
+    return p.stride == 2 && !p.epi_x && p.ow >= 50 && p.ow < 100;          // (3x3 stride 2 at 57 columns: 1.36x)
+}
+
+bool use_lane_bww(const mc_dwconv_args& p) {
+    if (g_lane_mode == -2) { const char* e = getenv("MC_DW_LANE"); g_lane_mode = e ? atoi(e) : -1; }
+    if (g_lane_mode == 0 || p.epi_x || !mc_dwconv_lane_supported(&p)) return false;
+    if (g_lane_mode == 1) return true;
+    // measured like the forward forms: 5x5 1.16-1.37x from 57 columns (stride 2: wide maps only); 3x3 at 57 columns 1.24-1.36x
+    if (p.k == 5) return p.stride == 1 ? p.ow >= 50 : p.ow >= 100;
+    return p.ow >= 50 && p.ow < 100;
 }
 
 }  // namespace
@@ -1255,6 +1265,7 @@ extern "C" int mc_dwconv_bwd_weight(const mc_dwconv_args* a, void* stream) {
     if (int e = check_common(p)) return e;
     MC_CHECK(p.x && p.dy, "dwconv_bwd_weight: null x / dy");
     hipStream_t st = (hipStream_t)stream;
+    if (use_lane_bww(p)) return mc_dwconv_bwd_weight_lane(a, stream);
     if (p.k == 3 && p.stride == 1) return launch_march_bww_cp<3, 1>(p, st);
     if (p.k == 3 && p.stride == 2) return launch_march_bww_cp<3, 2>(p, st);
     if (p.k == 5 && p.stride == 1) return launch_march_bww_cp<5, 1>(p, st);

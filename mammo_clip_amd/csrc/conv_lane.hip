@@ -68,10 +68,15 @@ constexpr int NDESC = 128;
 // EPI (stride 1): the launch is the DATA GRADIENT of a depthwise conv whose input was silu(bn0(e)); the kernel reads e at
 // the output position, writes dZ0 = dA0 * silu'(e*scale+shift) and leaves the BatchNorm-backward partials (see conv.hip).
 // The e rows travel through the OUTPUT tile: they are staged into the slots the lane later overwrites with dZ0.
-template <int K, int S, int NCOL, bool EPI>
+// MODE 2 (weight gradient, dw[kh,kw,c] += dy[o,x,c] * x'[o*S+kh, x*S+kw, c]): the same staging with the dy rows of a block in
+// the "output" tile (dy row o enters when input row o*S is processed); the registers hold the K*K tap accumulators of the
+// wave's channel pair and an A-deep window of unpacked dy rows; one butterfly sum per tap + one atomic per (tap, channel)
+// and workgroup at the end.
+template <int K, int S, int NCOL, int MODE>
 __global__ __launch_bounds__(1024, 4) void dwconv_lane_fwd_kernel(const mc_dwconv_args p, int strips, int nunits, int cpairs,
                                                                   int ctiles, int ymax) {
     using C = Cfg<K, S, NCOL>;
+    constexpr bool EPI = MODE == 1, BWW = MODE == 2, ETILE = EPI || BWW;       // ETILE: a second global tensor staged in the output tile
     static_assert(!EPI || S == 1, "the BatchNorm-backward epilogue is provided for stride 1");
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     uint32_t* const s_in = smem;                                    // [2][RB][IWP][PXD]
@@ -152,6 +157,7 @@ __global__ __launch_bounds__(1024, 4) void dwconv_lane_fwd_kernel(const mc_dwcon
     const int a_h = p.h, a_w = p.w, a_c = p.c, a_oh = p.oh, a_ow = p.ow, a_pad_t = p.pad_t, a_pad_l = p.pad_l, a_n = p.n;
     const bf16_t* const a_x = p.x;
     const bf16_t* const a_epi_x = p.epi_x;
+    const bf16_t* const a_dy = p.dy;
     bf16_t* const a_out = reinterpret_cast<bf16_t*>(p.out);
     int* const s_gen = s_desc + NDESC * D_WORDS;                      // range parameters (thread 0 computes them once)
     enum { G_U0 = 0, G_U1, G_O0, G_O1, G_NR0, G_NB0, G_NBF, G_NFULL, G_NBTOT, G_H, G_W, G_C, G_OH, G_OW, G_PT, G_PL, G_STRIPS, G_C0, G_WORDS = 20 };
@@ -194,7 +200,7 @@ __global__ __launch_bounds__(1024, 4) void dwconv_lane_fwd_kernel(const mc_dwcon
         const int need = (nrows - 1) * S + K - b * C::RB;             // input rows of this block the item still needs
         int rhi = g_h - iy0; if (rhi > C::RB) rhi = C::RB; if (rhi > need) rhi = need;
         int chi = g_w - ix0; if (chi > C::IW_T) chi = C::IW_T;
-        const int o_first = (b * C::RB - (K - 1)) / S;                  // (exact: RB and K-1 are multiples of S)
+        const int o_first = BWW ? b * C::RB / S : (b * C::RB - (K - 1)) / S;   // (exact: RB and K-1 are multiples of S)
         const long long outb = (((long long)img * g_oh + oy0 + o_first) * g_ow + ox0) * (long long)g_c + g_c0;
         int orhi = nrows - o_first; if (orhi > C::ORB) orhi = C::ORB;
         int ochi = g_ow - ox0; if (ochi > C::TOW) ochi = C::TOW;
@@ -209,12 +215,13 @@ __global__ __launch_bounds__(1024, 4) void dwconv_lane_fwd_kernel(const mc_dwcon
     if (wv == 0) { gen_desc(0); gen_desc(64); }            // blocks 0 .. 127
     // the output tile doubles as the e tile of the epilogue form: slots no stage ever writes (columns >= TOW) must not
     // hold NaN patterns (0 * NaN in the reductions)
-    for (int i = tid; i < 2 * C::OUT_DW; i += C::NT) s_out[i] = 0u;
+    // (the weight-gradient form sums over ALL lanes: the staged positions no stage ever writes must be zero as well)
+    for (int i = tid; i < 2 * C::OUT_DW + (BWW ? 2 * C::IN_DW : 0); i += C::NT) (BWW ? s_in : s_out)[i] = 0u;
     __syncthreads();                                        // pro_lds, descriptors
 
     uint4 vals[C::NV];
     unsigned inb = 0;
-    uint4 evals[EPI ? C::NVO : 1];
+    uint4 evals[ETILE ? C::NVO : 1];
     unsigned einb = 0;
     // global -> registers for block q
     auto stage_load = [&](int q) {
@@ -231,17 +238,18 @@ __global__ __launch_bounds__(1024, 4) void dwconv_lane_fwd_kernel(const mc_dwcon
             vals[i] = *reinterpret_cast<const uint4*>(ok ? org + goff : a_x);       // unconditional load, clamped address
             inb |= (ok ? 1u : 0u) << i;
         }
-        if constexpr (EPI) {                               // e rows of the output rows block q completes
+        if constexpr (ETILE) {                             // e rows of the output rows block q completes / its dy rows
             const long long obase = ((long long)d[D_OUTB_HI] << 32) | (unsigned)d[D_OUTB_LO];
             const int orlo = d[D_ORLO], orhi = d[D_ORHI], ochi = d[D_OCHI];
-            const bf16_t* eorg = a_epi_x + obase + vv * 8;
+            const bf16_t* const esrc = BWW ? a_dy : a_epi_x;
+            const bf16_t* eorg = esrc + obase + vv * 8;
             einb = 0;
 #pragma unroll
             for (int i = 0; i < C::NVO; ++i) {
                 const int row = (int)(metao[i] & 0xffu), col = (int)((metao[i] >> 8) & 0xffu);
                 const bool ok = row >= orlo && row < orhi && col < ochi;
                 const int goff = row * out_row_pitch + col * a_c;
-                evals[i] = *reinterpret_cast<const uint4*>(ok ? eorg + goff : a_epi_x);
+                evals[i] = *reinterpret_cast<const uint4*>(ok ? eorg + goff : esrc);
                 einb |= (ok ? 1u : 0u) << i;
             }
         }
@@ -284,8 +292,8 @@ __global__ __launch_bounds__(1024, 4) void dwconv_lane_fwd_kernel(const mc_dwcon
             }
         }
     };
-    auto estore = [&](int buf) {                           // EPI: the e rows of the block just loaded, into its output slots
-        if constexpr (EPI) {
+    auto estore = [&](int buf) {                           // EPI / BWW: the e / dy rows of the block just loaded, into its output slots
+        if constexpr (ETILE) {
             uint32_t* dst = s_out + buf * C::OUT_DW;
 #pragma unroll
             for (int i = 0; i < C::NVO; ++i) {
@@ -298,11 +306,14 @@ __global__ __launch_bounds__(1024, 4) void dwconv_lane_fwd_kernel(const mc_dwcon
         }
     };
 
-    f32x2_t acc[NCOL][C::A];
+    f32x2_t acc[NCOL][C::A];                               // BWW: the dy window g[column][slot]
 #pragma unroll
     for (int i = 0; i < NCOL; ++i)
 #pragma unroll
         for (int a = 0; a < C::A; ++a) acc[i][a] = f32x2_t{0.f, 0.f};
+    f32x2_t dwa[BWW ? K * K : 1];                          // BWW: tap accumulators of the wave's channel pair
+#pragma unroll
+    for (int t = 0; t < (BWW ? K * K : 1); ++t) dwa[t] = f32x2_t{0.f, 0.f};
     f32x2_t ssum = {0.f, 0.f}, ssq = {0.f, 0.f};
 
     // interval q: store block q (loaded in interval q-1), flush block q-2, load block q+1, compute block q-1.
@@ -313,16 +324,55 @@ __global__ __launch_bounds__(1024, 4) void dwconv_lane_fwd_kernel(const mc_dwcon
 #pragma unroll
         for (int ph = 0; ph < C::U; ++ph) {
             if (wv == 0 && q >= 66 && ((q - 2) & 63) == 0) gen_desc(q + 62);   // refill the slots of blocks q-66 .. q-3
-            const bool v_st = q < nbtot, v_ld = q + 1 < nbtot, v_cp = q >= 1 && q <= nbtot, v_fl = q >= 2;
+            const bool v_st = q < nbtot, v_ld = q + 1 < nbtot, v_cp = q >= 1 && q <= nbtot, v_fl = q >= 2 && !BWW;
             // (1) registers -> LDS for block q; finished rows of block q-2 -> global (EPI: then the e rows of block q)
             __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0): the prefetched registers (see conv.hip)
             if (v_st) stage_store(q & 1);
             if (v_fl) flush_out(q - 2, q & 1);
-            if (EPI && v_st) estore(q & 1);
+            if (ETILE && v_st) estore(q & 1);
             // (2) prefetch block q+1
             if (v_ld) stage_load(q + 1);
             // (3) compute block q-1
             if (v_cp) {
+                if constexpr (BWW) {
+                    const int* d = s_desc + ((q - 1) & (NDESC - 1)) * D_WORDS;
+                    if (__builtin_amdgcn_readfirstlane(d[D_FLAGS]) & 2) {       // new item: the dy window starts empty
+#pragma unroll
+                        for (int i = 0; i < NCOL; ++i)
+#pragma unroll
+                            for (int a = 0; a < C::A; ++a) acc[i][a] = f32x2_t{0.f, 0.f};
+                    }
+                    const uint32_t* lin = s_in + ((q - 1) & 1) * C::IN_DW + x * C::PXD + wv;
+                    const uint32_t* lg = s_out + ((q - 1) & 1) * C::OUT_DW + x * C::PXD + wv;
+#pragma unroll
+                    for (int j = 0; j < C::RB; ++j) {
+                        const int jr = (ph * C::RB + j) % C::P;
+                        f32x2_t in[C::NIN];
+#pragma unroll
+                        for (int i = 0; i < C::NIN; ++i) {
+                            const uint32_t v = lin[(j * C::IWP + (i % C::NS) * C::HQ + i / C::NS) * C::PXD];
+                            in[i] = f32x2_t{bf_lo(v), bf_hi(v)};
+                        }
+                        if (jr % S == 0) {                                  // dy row (block row j / S) enters the window
+                            const int sl = (jr / S) % C::A;
+#pragma unroll
+                            for (int i = 0; i < NCOL; ++i) {
+                                const uint32_t v = lg[((j / S) * C::TOWP + i * 64) * C::PXD];
+                                acc[i][sl] = f32x2_t{bf_lo(v), bf_hi(v)};
+                            }
+                        }
+#pragma unroll
+                        for (int kh = 0; kh < K; ++kh) {
+                            if (pmod_c(jr - kh, S) != 0) continue;
+                            const int sl = pmod_c(fdiv_c(jr - kh, S), C::A);
+#pragma unroll
+                            for (int kw = 0; kw < K; ++kw)
+#pragma unroll
+                                for (int i = 0; i < NCOL; ++i)
+                                    dwa[kh * K + kw] = __builtin_elementwise_fma(acc[i][sl], in[i * S + kw], dwa[kh * K + kw]);
+                        }
+                    }
+                } else {
                 const int* d = s_desc + ((q - 1) & (NDESC - 1)) * D_WORDS;
                 const int orlo = __builtin_amdgcn_readfirstlane(d[D_ORLO]), orhi = __builtin_amdgcn_readfirstlane(d[D_ORHI]);
                 const int ochi = d[D_OCHI];
@@ -386,12 +436,22 @@ __global__ __launch_bounds__(1024, 4) void dwconv_lane_fwd_kernel(const mc_dwcon
                     }
                 }
             }
+                }
             __syncthreads();
             ++q;
             if (q >= nbtot + 2) goto done;
         }
     }
 done:
+    if constexpr (BWW) {
+        float* dw = reinterpret_cast<float*>(p.out);
+#pragma unroll
+        for (int t = 0; t < K * K; ++t) {
+            const float a = wave_sum(dwa[t].x), b = wave_sum(dwa[t].y);
+            if (x == 0 && ch_ok) { atomicAdd(dw + (long long)t * p.c + cl, a); atomicAdd(dw + (long long)t * p.c + cl + 1, b); }
+        }
+        return;
+    }
     if (p.stat_partials) {
         // the 64 lanes of a wave hold the same channel pair: butterfly sums, lane 0 writes
         float s0 = wave_sum(ssum.x), s1 = wave_sum(ssum.y), q0 = wave_sum(ssq.x), q1 = wave_sum(ssq.y);
@@ -431,10 +491,10 @@ template <typename C> Plan plan(const mc_dwconv_args& p) {
     return m;
 }
 
-template <int K, int S, int NCOL, bool EPI> int launch(const mc_dwconv_args& p, hipStream_t st) {
+template <int K, int S, int NCOL, int MODE> int launch(const mc_dwconv_args& p, hipStream_t st) {
     using C = Cfg<K, S, NCOL>;
     static unsigned long long attr_done = 0;
-    auto kern = dwconv_lane_fwd_kernel<K, S, NCOL, EPI>;
+    auto kern = dwconv_lane_fwd_kernel<K, S, NCOL, MODE>;
     MC_SET_MAX_LDS(attr_done, kern, C::LDS_BYTES);
     const Plan m = plan<C>(p);
     hipLaunchKernelGGL(kern, dim3(m.grid), dim3(C::NT), C::LDS_BYTES, st, p, m.strips, m.nunits, m.cpairs, m.ctiles, m.ymax);
@@ -474,11 +534,25 @@ extern "C" int mc_dwconv_fwd_lane(const mc_dwconv_args* a, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     const bool wide = p.stride == 1 && p.ow > (p.k == 3 ? lane::Cfg<3, 1, 1>::TOW : lane::Cfg<5, 1, 1>::TOW);
     if (p.k == 3) {
-        if (p.stride == 2) return lane::launch<3, 2, 1, false>(p, st);
-        if (p.epi_x) return wide ? lane::launch<3, 1, 2, true>(p, st) : lane::launch<3, 1, 1, true>(p, st);
-        return wide ? lane::launch<3, 1, 2, false>(p, st) : lane::launch<3, 1, 1, false>(p, st);
+        if (p.stride == 2) return lane::launch<3, 2, 1, 0>(p, st);
+        if (p.epi_x) return wide ? lane::launch<3, 1, 2, 1>(p, st) : lane::launch<3, 1, 1, 1>(p, st);
+        return wide ? lane::launch<3, 1, 2, 0>(p, st) : lane::launch<3, 1, 1, 0>(p, st);
     }
-    if (p.stride == 2) return lane::launch<5, 2, 1, false>(p, st);
-    if (p.epi_x) return wide ? lane::launch<5, 1, 2, true>(p, st) : lane::launch<5, 1, 1, true>(p, st);
-    return wide ? lane::launch<5, 1, 2, false>(p, st) : lane::launch<5, 1, 1, false>(p, st);
+    if (p.stride == 2) return lane::launch<5, 2, 1, 0>(p, st);
+    if (p.epi_x) return wide ? lane::launch<5, 1, 2, 1>(p, st) : lane::launch<5, 1, 1, 1>(p, st);
+    return wide ? lane::launch<5, 1, 2, 0>(p, st) : lane::launch<5, 1, 1, 0>(p, st);
+}
+
+extern "C" int mc_dwconv_bwd_weight_lane(const mc_dwconv_args* a, void* stream) {
+    const mc_dwconv_args& p = *a;
+    MC_CHECK(mc_dwconv_lane_supported(a) && !p.epi_x, "dwconv_bwd_weight_lane: unsupported shape");
+    MC_CHECK(p.x && p.dy && p.out, "dwconv_bwd_weight_lane: null x / dy / out");
+    hipStream_t st = (hipStream_t)stream;
+    const bool wide = p.stride == 1 && p.ow > (p.k == 3 ? lane::Cfg<3, 1, 1>::TOW : lane::Cfg<5, 1, 1>::TOW);
+    if (p.k == 3) {
+        if (p.stride == 2) return lane::launch<3, 2, 1, 2>(p, st);
+        return wide ? lane::launch<3, 1, 2, 2>(p, st) : lane::launch<3, 1, 1, 2>(p, st);
+    }
+    if (p.stride == 2) return lane::launch<5, 2, 1, 2>(p, st);
+    return lane::launch<5, 1, 1, 2>(p, st);         // (two columns per lane: 50 tap accumulators + a 20-register dy window spill)
 }

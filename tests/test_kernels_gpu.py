@@ -924,6 +924,29 @@ def test_dwconv_lane_form_equals_marching_form(k, s, n, h, w, c, use_pro):
     assert float((s0 - s1).abs().max()) <= 2e-5 * float(s0.abs().max()), "statistics partials"
 
 
+@pytest.mark.parametrize("k,s,n,h,w,c", LANE_CASES)
+def test_dwconv_lane_weight_gradient_equals_marching_form(k, s, n, h, w, c):
+    """the weight-gradient mode of the lane = column kernel against the marching weight-gradient kernel (both sum fp32
+    products of the same bf16 operands, in different orders: <= 2e-4 of the largest tap gradient; run twice -- the second
+    launch finds whatever the first left in LDS)"""
+    Lh = L.load()
+    pad = (k - 1) // 2 if s == 1 else (k - 2) // 2
+    oh, ow = (h + s - 1) // s, (w + s - 1) // s
+    x = rnd(n * h * w, c, seed=41)
+    dy = rnd(n * oh * ow, c, seed=42)
+    pro = (rnd(c, seed=33, dtype=torch.float32) * 0.3 + 1.0, rnd(c, seed=34, dtype=torch.float32) * 0.3)
+    out = {}
+    old = Lh.mc_dwconv_set_lane_mode(0)
+    try:
+        for mode in (0, 1, 1):
+            Lh.mc_dwconv_set_lane_mode(mode)
+            out[mode] = ops.dwconv_bwd_weight(x, dy, n, h, w, c, k, s, pad, pad, oh, ow, pro=pro)
+    finally:
+        Lh.mc_dwconv_set_lane_mode(old)
+    assert torch.isfinite(out[1]).all()
+    assert float((out[0] - out[1]).abs().max()) <= 2e-4 * float(out[0].abs().max())
+
+
 @pytest.mark.parametrize("k,n,h,w,c", [(5, 3, 150, 260, 96), (5, 5, 95, 57, 72), (3, 2, 70, 300, 48), (5, 33, 48, 29, 32)])
 def test_dwconv_lane_form_epilogue_equals_marching_form(k, n, h, w, c):
     """the same for the stride-1 data gradient with the BatchNorm-backward epilogue (dZ0 bit-identical, partials to 2e-5)"""
