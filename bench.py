@@ -25,7 +25,7 @@ The JSON line carries, besides the contract fields:
                   inside the timed steps and reported as "roofline", "roofline_runner_up", "roofline_third"
                   (achieved = algorithmic bytes or flops per launch / average launch duration; bound = hbm or mfma by
                   the class's flop / byte ratio against the 2.5 PFLOP/s : 8 TB/s ridge; traffic = PMC bytes per launch
-                  from profiles/r03_roofline_traffic.json where that class was measured, else null)
+                  from profiles/rNN_roofline_traffic.json (cfg3 launch mix; `traffic_source` says so) where that class was measured, else null)
   n8_load      -- (default workload, N = 1 only) ms/step of the step ONE GPU runs at N = 8: 128 pairs as 4 micro-batches,
                   recompute mode 3, all four graphs kept, no communication -- the like-for-like single-GPU time a
                   1 -> 8 scaling curve should be read against (the N = 1 point itself carries 31 re-forwards)
@@ -67,8 +67,8 @@ KERNEL_NAMES = {
     "mc_bnact_se_sums": "bnact_se_sums_k (SE-gate gradient + BatchNorm1 backward sums, one pass over (d, dA1))",
     "mc_bnact_pool": "bnact_img_reduce_k (BN+SiLU + squeeze-excite average pool)",
     "mc_bnact_apply": "bnact_apply_k (BatchNorm2 + drop-connect + residual)",
-    "mc_dwconv_fwd": "dwconv_march_fwd_kernel (depthwise conv forward / stride-1 data gradient, marching LDS kernel)",
-    "mc_dwconv_bwd_weight": "dwconv_march_bww_kernel (depthwise conv weight gradient)",
+    "mc_dwconv_fwd": "dwconv_march_fwd_kernel + lane::dwconv_lane_fwd_kernel<K,S,NCOL,0|1> (depthwise conv forward / stride-1 data gradient: marching LDS kernels for 3x3, lane = column kernels with the taps in SGPRs for 5x5)",
+    "mc_dwconv_bwd_weight": "dwconv_march_bww_kernel + lane::dwconv_lane_fwd_kernel<K,S,NCOL,2> (depthwise conv weight gradient)",
     "mc_dwconv_bwd_data": "dwconv_march_bwd_s2_kernel (depthwise conv stride-2 data gradient, with the BatchNorm0+SiLU backward epilogue)",
     "mc_gemm_rows_bf16": "gemm_rows_kernel (row-streaming 1x1 conv forward / data gradient, weights resident in LDS)",
     "mc_wgrad_rows_bf16": "wgrad_rows_kernel (row-streaming 1x1 conv weight gradient, LDS transpose-reads)",
@@ -140,27 +140,43 @@ def synth_batch_gpu(b, H, W, T, device, seed):
     return batch
 
 
-def cpu_baseline(arch_name, H, W, T, budget_s=30.0):
-    """CPU oracle (port of the reference path), train-mode fwd + bwd on ONE pair-group sample, host cores of this box."""
+def cpu_baseline(arch_name, H, W, T, budget_s=80.0):
+    """CPU oracle (port of the reference path) on the host cores of this box: ONE full training step (train-mode forward
+    + loss + backward + AdamW) of a bounded sample -- 1 pair = 2 images + 2 reports at the workload's size.  Protocol
+    (bounded): one untimed warm-up step, then the median of up to 3 timed steps within ``budget_s``
+    (at least one timed step)."""
     from oracle import arch as oarch, bert as obert, clip as oclip, loss as oloss, weights as ow
     cores = os.cpu_count() or 1
     threads = min(cores, 64)     # measured on the MI355X host: 64 threads 46 s vs 128 threads 79 s for the same sample
     torch.set_num_threads(threads)
     arch = oarch.build_arch(arch_name)
     cfg = obert.BertShape()
-    b = 1                      # one pair = 2 images + 2 reports (bounded sample: ~20-30 s of CPU work)
+    b = 1                      # one pair = 2 images + 2 reports (bounded sample: ~15-20 s of CPU work per step)
     sd = ow.synth_state_dict(ow.clip_shapes(arch, cfg), seed=10)
     sdg = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v) for k, v in sd.items()}
+    params = [v for v in sdg.values() if torch.is_tensor(v) and v.requires_grad]
+    opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=1e-4)
     batch = ow.synth_batch(b, H, W, T, seed=10, full_length=True)
-    t0 = time.time()
-    out = oclip.forward(sdg, batch, arch, cfg, train=True, new_buffers={})
-    loss = oloss.breast_clip_rank(out["image_embeddings"], out["text_embeddings"], out["text_embeddings2"],
-                                  out["image_view_embeddings"], out["logit_scale"], 0, b)["loss"]
-    loss.backward()
-    dt = time.time() - t0
+
+    def step():
+        t0 = time.time()
+        opt.zero_grad(set_to_none=True)
+        out = oclip.forward(sdg, batch, arch, cfg, train=True, new_buffers={})
+        loss = oloss.breast_clip_rank(out["image_embeddings"], out["text_embeddings"], out["text_embeddings2"],
+                                      out["image_view_embeddings"], out["logit_scale"], 0, b)["loss"]
+        loss.backward()
+        opt.step()
+        return time.time() - t0
+    t_start = time.time()
+    warm = step()                                                      # untimed: thread pool, primitive caches, allocator
+    times = [step()]
+    while len(times) < 3 and (time.time() - t_start) + 1.1 * times[-1] <= budget_s:
+        times.append(step())
+    dt = sorted(times)[len(times) // 2]
     return {"value": round(b / dt, 4), "unit": "image-text pairs/s", "cores": threads, "kind": "port",
-            "sample": f"{b} pairs ({2*b} images {H}x{W} + {2*b} reports T={T}), one train-mode fwd+bwd of the oracle "
-                      f"(no optimizer step), {dt:.1f} s on {threads} threads of {cores} host cores"}
+            "sample": f"{b} pair ({2*b} images {H}x{W} + {2*b} reports T={T}) per step, full train step of the oracle "
+                      f"(fwd + loss + bwd + AdamW); 1 untimed warm-up ({warm:.1f} s), median of {len(times)} timed steps "
+                      f"({', '.join('%.1f' % t for t in times)} s) on {threads} threads of {cores} host cores"}
 
 
 def main():
@@ -318,8 +334,14 @@ def main():
     if rank == 0:
         ms = dt / args.steps * 1e3
         pairs = b * world * args.steps / dt
-        tpath = os.path.join(ROOT, "profiles", "r03_roofline_traffic.json")
-        tj = json.load(open(tpath)) if os.path.exists(tpath) and args.workload in ("cfg3", "cfg4") and not args.batch else {}
+        tpath = next((q for q in (os.path.join(ROOT, "profiles", f"r{r:02d}_roofline_traffic.json") for r in (4, 3)) if os.path.exists(q)), "")
+        tj = json.load(open(tpath)) if tpath and args.workload in ("cfg3", "cfg4") and not args.batch else {}
+        # the PMC bytes were collected on the cfg3 launch mix (32 pairs in one pass): the same 32-pair launches as cfg4's
+        # micro-batches, but cfg4 adds the re-forward launches -- its per-class launch MIX differs, so the ratio of `traffic`
+        # to `algorithmic_bytes_per_launch` is only meaningful for --workload cfg3
+        tsrc = (f"{os.path.basename(tpath)}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over one cfg3 step, per-launch average "
+                f"of the class's kernels on the cfg3 launch mix" + ("" if args.workload == "cfg3" else
+                "; this run's launch mix differs (micro-batch re-forwards), compare traffic with algorithmic bytes on --workload cfg3 only")) if tj else None
         timing = "HIP events on the launch stream around every launch of this class inside the timed steps"
 
         def entry(key):
@@ -333,7 +355,8 @@ def main():
                 ach, peak, unit = (by / (t_ms * 1e-3) / 1e9 if t_ms > 0 else 0.0), HBM_PEAK_GBS, "GB/s"
             tkey = key[:-5] if key.endswith("|mfma") else (key[:-4] if key.endswith("|hbm") else key)
             return {"bound": "mfma" if mfma else "hbm", "achieved": round(ach, 1), "peak": peak, "unit": unit,
-                    "frac": round(ach / peak, 4), "traffic": tj.get(key, tj.get(tkey)), "kernel": kernel_name(key), "launches": cnt,
+                    "frac": round(ach / peak, 4), "traffic": tj.get(key, tj.get(tkey)), "traffic_source": tsrc if tj.get(key, tj.get(tkey)) is not None else None,
+                    "kernel": kernel_name(key), "launches": cnt,
                     "avg_launch_us": round(t_ms / max(cnt, 1) * 1e3, 1), "algorithmic_bytes_per_launch": int(by / max(cnt, 1)),
                     "algorithmic_flops_per_launch": int(fl / max(cnt, 1)), "gpu_ms_in_timed_steps": round(t_ms, 1),
                     "share_of_gpu_time_in_survey_step": round(ssum[key][1] / max(sum(v[1] for v in ssum.values()), 1e-9), 4),

@@ -155,6 +155,9 @@ typedef struct mc_gemm_rows_args {
 } mc_gemm_rows_args;
 int mc_gemm_rows_supported(int n, int k);
 long long mc_gemm_rows_epi_ws_floats(const mc_gemm_rows_args* args);
+/* can mc_gemm_rows_bf16 run the epilogue form epi_mode (1 / 2) of an [M, K] x [N, K]^T data gradient with rows_per_img rows per
+ * image?  (N <= 256, K <= 128, whole 16-row groups per image, at most one image boundary per wave range) */
+int mc_gemm_rows_epi_supported(long long M, int N, int K, long long rows_per_img, int epi_mode);
 int mc_gemm_rows_blocks(const mc_gemm_rows_args* args);     /* persistent workgroups of the launch = rows of stat_partials */
 int mc_gemm_rows_bf16(const mc_gemm_rows_args* args, void* stream);
 

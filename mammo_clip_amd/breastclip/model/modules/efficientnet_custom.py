@@ -502,9 +502,22 @@ class MBConvBlock(nn.Module):
 
     def _params(self):
         """the block's Parameter objects in ``_param_names`` order (cached: ``named_parameters`` walks the module tree)"""
-        ps = self.__dict__.get("_plist")
-        if ps is None:          # Parameter OBJECTS survive .to() / load_state_dict (both write .data in place)
-            ps = self.__dict__["_plist"] = [p for _, p in self.named_parameters()]
+        # cached with the (owner dict, key) slot of every parameter: a Parameter OBJECT survives .to() / load_state_dict (both
+        # write .data in place) but not ``module.weight = nn.Parameter(...)`` / ``load_state_dict(assign=True)`` / to_empty() --
+        # then the slots no longer hold the cached objects and the list is rebuilt (ADVICE r3: gradients must not go to
+        # orphaned Parameters)
+        cached = self.__dict__.get("_plist")
+        if cached is not None:
+            ps, slots = cached
+            for p_, (d_, k_) in zip(ps, slots):
+                if d_.get(k_) is not p_:
+                    cached = None
+                    break
+        if cached is None:
+            slots = [(m._parameters, k) for m in self.modules() for k, v in m._parameters.items() if v is not None]
+            ps = [d_[k_] for d_, k_ in slots]
+            assert len(ps) == len(self._param_names)
+            self.__dict__["_plist"] = (ps, slots)
         return ps
 
     def forward(self, inputs, n, h, w, rowscale=None):

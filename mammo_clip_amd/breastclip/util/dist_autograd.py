@@ -7,37 +7,22 @@ import torch
 import torch.distributed as dist
 
 
-def _tensor_collectives_ok():
-    """RCCL ("nccl") has native all_gather_into_tensor / reduce_scatter_tensor; the gloo backend used by the CPU
-    tests gets the list forms of the same collectives."""
-    return dist.get_backend() == "nccl"
-
-
 def _gather_ranks(x):
-    """x [...] on every rank -> [W, ...] in rank order (one collective)"""
+    """x [...] on every rank -> [W, ...] in rank order: ONE ``all_gather_into_tensor``.  The same call on every backend
+    (RCCL, and gloo in the CPU / shared-GPU tests -- torch 2.10's gloo implements the tensor collectives for host and
+    device tensors, probed with scripts/gloo_cuda_probe.py), so the world-size-2 tests execute exactly what RCCL will."""
     W = dist.get_world_size()
     x = x.contiguous()
     out = torch.empty((W,) + tuple(x.shape), dtype=x.dtype, device=x.device)
-    if _tensor_collectives_ok():
-        dist.all_gather_into_tensor(out.view(-1), x.reshape(-1))
-    else:
-        dist.all_gather(list(out.unbind(0)), x)
+    dist.all_gather_into_tensor(out.view(-1), x.reshape(-1))
     return out
 
 
 def _reduce_scatter_ranks(grad):
-    """grad [W, ...] on every rank -> sum over ranks of slice [rank] (one collective)"""
+    """grad [W, ...] on every rank -> sum over ranks of slice [rank]: ONE ``reduce_scatter_tensor`` (same on every backend)"""
     grad = grad.contiguous()
     out = torch.empty(grad.shape[1:], dtype=grad.dtype, device=grad.device)
-    if _tensor_collectives_ok():
-        dist.reduce_scatter_tensor(out.view(-1), grad.view(-1), op=dist.ReduceOp.SUM)
-    elif grad.is_cuda:
-        # gloo with device tensors (single-GPU multi-process tests): no reduce_scatter -> all_reduce + own slice
-        full = grad.clone()
-        dist.all_reduce(full, op=dist.ReduceOp.SUM)
-        out.copy_(full[dist.get_rank()])
-    else:
-        dist.reduce_scatter(out, list(grad.unbind(0)), op=dist.ReduceOp.SUM)
+    dist.reduce_scatter_tensor(out.view(-1), grad.view(-1), op=dist.ReduceOp.SUM)
     return out
 
 

@@ -462,7 +462,14 @@ template <int FN, int KC, int EPI> int launch_rows_e(const mc_gemm_rows_args& p,
     if (b > cap) b = cap;
     if (b < 1) b = 1;
     const int blocks = (int)b;
-    if (query) { *query = blocks; return MC_OK; }
+    if (query) {
+        if constexpr (EPI != 0) {                         // (query of an epilogue form: 0 workgroups = the launch would be refused)
+            const long long nwaves_q = (long long)blocks * 4, iters_q = (p.M + RG * 16 - 1) / (RG * 16);
+            if (ntiles != 1 || (iters_q + nwaves_q - 1) / nwaves_q * RG * 16 > p.epi_rows_per_img) { *query = 0; return MC_OK; }
+        }
+        *query = blocks;
+        return MC_OK;
+    }
     size_t lds = lds_bytes<FN, KC>() + (p.pro_gate ? (size_t)4 * 2 * KC * 32 * 4 : 0) + (EPI == 1 ? 12288 : 0);     // + per-wave SE gate cache / flush tile
     static unsigned long long attr_done = 0;
     const void* kfn = reinterpret_cast<const void*>(&gemm_rows_kernel<FN, KC, PF, RG, EPI>);
@@ -550,6 +557,18 @@ extern "C" int mc_gemm_rows_blocks(const mc_gemm_rows_args* a) {
     if (!mc_gemm_rows_supported(a->N, a->K) || a->M <= 0) return 0;
     if (dispatch_fn(*a, nullptr, &q) != MC_OK) return 0;
     return q;
+}
+
+// can mc_gemm_rows_bf16 run the epilogue form (epi_mode 1 / 2) of this problem?  (the host routes on this
+// instead of meeting the launch-time refusal: many tiny maps -- more images than waves, or maps under 16 pixels)
+extern "C" int mc_gemm_rows_epi_supported(long long M, int N, int K, long long rows_per_img, int epi_mode) {
+    if (epi_mode < 1 || epi_mode > 2 || M <= 0 || N > 256 || K > 128 || !mc_gemm_rows_supported(N, K)) return 0;
+    if (rows_per_img < 16 || rows_per_img % 16 != 0) return 0;
+    mc_gemm_rows_args a = {};
+    a.M = M; a.N = N; a.K = K; a.epi_mode = epi_mode; a.epi_rows_per_img = rows_per_img;
+    int q = 0;
+    if (dispatch_fn(a, nullptr, &q) != MC_OK) return 0;
+    return q > 0;
 }
 
 // floats of epi_ws for an epi_mode = 1 launch: [waves][2 slots][5][N] sums + [waves][2] image tags

@@ -70,11 +70,9 @@ class GradBuckets:
             self._reduce(flat)
 
     def _reduce(self, flat):
-        """mean over ranks: RCCL has a native AVG; gloo (CPU tests) gets SUM followed by a scale"""
-        if dist.get_backend() == "nccl":
-            self.handles.append((dist.all_reduce(flat, op=dist.ReduceOp.AVG, async_op=True), None))
-        else:
-            self.handles.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True), flat))
+        """mean over ranks: ``all_reduce(AVG)`` -- the same call over RCCL and over gloo (torch 2.10's gloo implements AVG
+        for host and device tensors), so the world-size-2 tests run the collective the 8-GPU job runs"""
+        self.handles.append(dist.all_reduce(flat, op=dist.ReduceOp.AVG, async_op=True))
 
     def reduce_all(self):
         """Micro-batched steps run several backward calls per step, so the per-parameter hooks cannot tell when a
@@ -88,10 +86,8 @@ class GradBuckets:
                     v.copy_(p.grad)
                     p.grad = v
             self._reduce(flat)
-        for h, flat in self.handles:
+        for h in self.handles:
             h.wait()
-            if flat is not None:
-                flat.div_(dist.get_world_size())
         self.pending = []
 
     def finish(self):
@@ -108,10 +104,8 @@ class GradBuckets:
                         v.copy_(p.grad)     # logit_scale, whose gradient comes from the loss backward alone)
                         p.grad = v
                 self._reduce(flat)
-        for h, flat in self.handles:
+        for h in self.handles:
             h.wait()
-            if flat is not None:
-                flat.div_(dist.get_world_size())
         self.pending = []
 
 

@@ -99,6 +99,7 @@ _SIGS = {
     "mc_gemm_rows_supported": ([I, I], I),
     "mc_gemm_rows_blocks": ([C.POINTER(GemmRowsArgs)], I),
     "mc_gemm_rows_epi_ws_floats": ([C.POINTER(GemmRowsArgs)], LL),
+    "mc_gemm_rows_epi_supported": ([LL, I, I, LL, I], I),
     "mc_gemm_rows_bf16": ([C.POINTER(GemmRowsArgs), P], I),
     "mc_cast_transpose_f32_bf16": ([P, P, I, I, P], I),
     "mc_wgrad_rows_supported": ([I, I], I),

@@ -177,8 +177,11 @@ def proj_dgrad_fusable(M, n_out, k_in, rows_per_img):
     backward in its epilogue (gemm_rows epi_mode 1 / 2)?  Row-streaming shapes with whole 16-row groups per image."""
     if n_out < PROJ_DGRAD_FUSE_MIN_N:
         return False
+    lib_ = L.load()
     return (M >= ROWS_MIN_M and n_out <= 256 and k_in <= 128 and rows_per_img % 16 == 0 and rows_per_img >= 16
-            and bool(L.load().mc_gemm_rows_supported(n_out, k_in)) and not _prefer_tiles(n_out, k_in))
+            and bool(lib_.mc_gemm_rows_supported(n_out, k_in)) and not _prefer_tiles(n_out, k_in)
+            and bool(lib_.mc_gemm_rows_epi_supported(M, n_out, k_in, rows_per_img, 1))
+            and bool(lib_.mc_gemm_rows_epi_supported(M, n_out, k_in, rows_per_img, 2)))
 
 
 def _proj_dgrad_epi_args(dp, w_t, d, stats, rows_per_img, mode):
@@ -300,7 +303,8 @@ def _linear_fwd_impl(x, w, bias=None, act=0, residual=None, stats=False, pro=Non
     N = w.shape[0]
     y = out if out is not None else empty((M, N), BF16, x)
     if _rows_ok(M, N, K, bias, act) and (pro is None or pro[0] is not None) and not (
-            pro is None and bias is None and not tag and _prefer_tiles(N, K)):
+            pro is None and bias is None and not tag and _prefer_tiles(N, K)) and not (
+            pro is not None and pro[2] is not None and pro[3] < 16):     # (gated rows kernel: >= 16 rows per image; else the tile GEMM)
         part = gemm_rows(x, w, y, residual=residual, pro=pro, stats=stats, kind="fwd_rows" + tag, bias=bias)
         return (y, part) if stats else y
     if pro is not None and pro[0] is None and residual is None and bias is None and M % pro[3] == 0 and pro[3] >= 256:

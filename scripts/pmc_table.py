@@ -52,10 +52,21 @@ cls = {"mc_bnact_bwd_apply": "bnact_bwd_k<true", "mc_gemm_bf16:|glnt256": "g8::g
        "mc_bnact_pool": "bnact_img_reduce_k",
        # one class per kernel template (bench.py::class_key): launch-weighted averages over all instances of the family
        "mc_gemm_rows_bf16": "gemm_rows_kernel", "mc_wgrad_rows_bf16": "wgrad_rows_kernel",
-       "mc_dwconv_fwd": "dwconv_march_fwd_kernel", "mc_dwconv_bwd_weight": "dwconv_march_bww_kernel"}
+       # (round 4: the depthwise classes span two kernel families -- marching and lane = column; the lane kernel's MODE
+       # template argument 2 = weight gradient)
+       "mc_dwconv_fwd": ("dwconv_march_fwd_kernel", "lane::dwconv_lane_fwd_kernel<#fwd"),
+       "mc_dwconv_bwd_weight": ("dwconv_march_bww_kernel", "lane::dwconv_lane_fwd_kernel<#bww")}
 traffic = {}
 for key, kn in cls.items():
-    sel = [r for r in rows if r[0].startswith(kn)]
+    def match(name, pat):
+        if "#" not in pat:
+            return name.startswith(pat)
+        base, mode = pat.split("#")
+        if not name.startswith(base):
+            return False
+        last = name.rstrip(">").rsplit(",", 1)[-1].strip()         # MODE template argument
+        return (last == "2") == (mode == "bww")
+    sel = [r for r in rows if any(match(r[0], q) for q in ((kn,) if isinstance(kn, str) else kn))]
     n = sum(r[2] for r in sel)
     if n:
         traffic[key] = int(sum((r[4] + r[5]) * 1e6 * r[2] for r in sel) / n)

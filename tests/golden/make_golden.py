@@ -13,6 +13,7 @@ Fixtures (checked by tests/test_oracle_golden.py and by the GPU parity tests):
   mbconv_kats.npz   MBConvBlock known-answer tests (eval + train, outputs + grads)
   bert_kat.npz      small BertModel known-answer test (padding mask, outputs + grads)
   loss_kats.npz     both loss classes, W in {1,2,4} ranks over gloo (losses + grads)
+  e2e_b2_cfg1_eval_seeds.npz   config #1, eval mode, two further (weights, inputs) seeds: embeddings + loss
   e2e_b2_cfg1.npz   BASELINE config #1 (B2 + BERT-base, b=4, 224^2, T=64): embeddings, losses, grads
   e2e_b5_small.npz  B5 + BERT-base, b=2, 160x96, T=32: same (pins the B5 table end to end)
   e2e_b2_bn8k.npz   B2 + BERT-base, b=8, 456^2, T=64: train-mode fixture in which every BatchNorm sees >= 1800 samples
@@ -373,6 +374,45 @@ def gen_e2e(tag, enc_name, arch_name, b, H, W, T):
     np.savez_compressed(os.path.join(HERE, f"{tag}.npz"), **store)
 
 
+def gen_e2e_eval_seeds(seeds=(11, 12), enc_name="tf_efficientnetv2-detect", arch_name="efficientnet-b2", b=4, H=224, W=224, T=64):
+    """BASELINE config #1 in EVAL mode on further (weights, inputs) seeds (VERDICT r3 #6b: the 1e-3 loss bound held with 11 %
+    margin on ONE seed): embeddings + loss of the reference for each seed -> e2e_b2_cfg1_eval_seeds.npz"""
+    from breastclip.model import build_model
+    from breastclip.loss import build_loss
+    from oracle import arch as oarch, weights as ow
+    from oracle.bert import BertShape
+    model_cfg = {"name": "clip_custom", "temperature": 0.07,
+                 "image_encoder": {"source": "cnn", "name": enc_name, "pretrained": True, "model_type": "cnn"},
+                 "text_encoder": {"source": "huggingface", "name": "emilyalsentzer/Bio_ClinicalBERT",
+                                  "pretrained": False, "gradient_checkpointing": False, "pooling": "eos",
+                                  "cache_dir": "/tmp/none", "trust_remote_code": True, "mlm_head": True},
+                 "projection_head": {"name": "linear", "dropout": 0.1, "proj_dim": 512}}
+    loss_cfg = {"breast_clip": dict(label_smoothing=0.0, i2i_weight=1.0, t2t_weight=0.5, loss_ratio=1.0)}
+    torch.manual_seed(10)
+    model = build_model(model_cfg, loss_cfg, types.SimpleNamespace(vocab_size=28996))
+    shapes = ow.clip_shapes(oarch.build_arch(arch_name), BertShape())
+    lf = build_loss(loss_cfg)
+    store = {"meta": np.array([b, H, W, T], dtype=np.int64), "seeds": np.array(seeds, dtype=np.int64)}
+
+    class BE(dict):
+        def to(self, device):
+            return self
+    for sd_ in seeds:
+        model.load_state_dict(ow.synth_state_dict(shapes, seed=sd_), strict=True)
+        model.eval()
+        batch = ow.synth_batch(b, H, W, T, seed=sd_)
+        bt = {"images": batch["images"], "image_views": batch["image_views"],
+              "text_tokens": BE(batch["text_tokens"]), "text_tokens2": BE(batch["text_tokens2"])}
+        with torch.no_grad():
+            out = model(bt, torch.device("cpu"))
+            ld = lf(**out, is_train=False)
+        for k in ("image_embeddings", "text_embeddings", "text_embeddings2", "image_view_embeddings"):
+            store[f"s{sd_}/eval/{k}"] = np_(out[k])
+        store[f"s{sd_}/eval/total"] = np_(ld["total"])
+        print("eval seeds", sd_, float(ld["total"]))
+    np.savez_compressed(os.path.join(HERE, "e2e_b2_cfg1_eval_seeds.npz"), **store)
+
+
 def gen_traj(tag="traj_b5_small", enc_name="tf_efficientnet_b5_ns-detect", arch_name="efficientnet-b5", b=2, H=160, W=96, T=32,
              steps=4):
     """Row H (the hot loop): the reference's own build_optimizer / build_scheduler / call order for a few steps on a
@@ -547,7 +587,7 @@ def time_reference_cfg1(warmup=3, reps=10):
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["arch", "mbconv", "bert", "loss", "e2e_b2", "e2e_b5", "traj", "e2e_bn8k", "inputs", "timing"]
+    which = sys.argv[1:] or ["arch", "mbconv", "bert", "loss", "e2e_b2", "e2e_seeds", "e2e_b5", "traj", "e2e_bn8k", "inputs", "timing"]
     import_reference()
     if "arch" in which:
         gen_arch_tables()
@@ -559,6 +599,8 @@ if __name__ == "__main__":
         gen_loss_kats()
     if "e2e_b2" in which:
         gen_e2e("e2e_b2_cfg1", "tf_efficientnetv2-detect", "efficientnet-b2", 4, 224, 224, 64)
+    if "e2e_seeds" in which:
+        gen_e2e_eval_seeds()
     if "traj" in which:
         gen_traj()
     if "e2e_b5" in which:

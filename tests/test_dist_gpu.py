@@ -27,6 +27,17 @@ from mammo_clip_amd.breastclip.model import build_model
 from mammo_clip_amd.breastclip.optimizer import build_optimizer
 from oracle import weights as ow
 
+# the exchange steps are ONE code path for every backend: count the torch.distributed entry points RCCL is given here --
+# the world-size-2 gloo tests (tests/test_host_cpu.py, below) assert the same names
+calls = {"all_gather_into_tensor": 0, "reduce_scatter_tensor": 0, "all_reduce_avg": 0}
+_ag, _rs, _ar = dist.all_gather_into_tensor, dist.reduce_scatter_tensor, dist.all_reduce
+def ag(*a_, **k_): calls["all_gather_into_tensor"] += 1; return _ag(*a_, **k_)
+def rs(*a_, **k_): calls["reduce_scatter_tensor"] += 1; return _rs(*a_, **k_)
+def ar(t_, op=dist.ReduceOp.SUM, **k_):
+    calls["all_reduce_avg"] += int(op == dist.ReduceOp.AVG); return _ar(t_, op=op, **k_)
+dist.all_gather_into_tensor, dist.reduce_scatter_tensor, dist.all_reduce = ag, rs, ar
+dist.all_gather = dist.reduce_scatter = None          # the list forms are not part of the product path any more
+
 # 1. fused gather / reduce-scatter and the reference-style per-tensor function on RCCL
 a = torch.randn(5, 512, device=dev, requires_grad=True); b = torch.randn(5, 512, device=dev, requires_grad=True)
 ga, gb = all_gather_fused([a, b])
@@ -37,6 +48,7 @@ t = torch.randn(4, 8, device=dev, requires_grad=True)
 (out,) = DistAutogradAllGatherFunction(partial=False).apply(t)
 out.sum().backward()
 assert torch.equal(out, t) and torch.equal(t.grad, torch.ones_like(t))
+assert calls["all_gather_into_tensor"] == 2 and calls["reduce_scatter_tensor"] == 3, calls    # (retain_graph: two backward calls)
 
 # 2. one training step with the gradient buckets forced on == the plain step (AVG over one rank is the identity)
 cfg = {"name": "clip_custom", "temperature": 0.07,
@@ -66,6 +78,7 @@ assert l0[0] == l1[0], (l0, l1)
 assert abs(l0[1] - l1[1]) < 5e-3, (l0, l1)        # float atomics in the depthwise weight gradient: round-off only
 worst = max(float((s0[k].float() - s1[k].float()).abs().max()) for k in s0)
 assert worst < 5e-3, worst
+assert calls["all_reduce_avg"] == 2 * len(tr.buckets.buckets), calls      # every bucket of both steps went through all_reduce(AVG)
 
 # 3. validation: one all-reduce per batch on the device
 out = engine.validate(model, build_loss(loss_cfg), {"v": [bt, bt]}, dev)
@@ -362,6 +375,7 @@ assert l0[0] == l1[0], (l0, l1)
 assert abs(l0[1] - l1[1]) < 5e-3, (l0, l1)
 worst = max(float((s0[k].float() - s1[k].float()).abs().max()) for k in s0)
 assert worst < 5e-3, worst
+assert calls["all_reduce_avg"] == 2 * len(tr.buckets.buckets), calls      # every bucket of both steps went through all_reduce(AVG)
 dist.destroy_process_group()
 print("DDP-OK", l0, l1, worst)
 '''

@@ -279,6 +279,24 @@ def _w2_worker(rank, port, ret):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=2)
+    # ONE collective code path for every backend: the list forms must never be reached, and the tensor forms /
+    # all_reduce(AVG) that tests/test_dist_gpu.py counts over RCCL are the ones counted here over gloo
+    calls = {"all_gather_into_tensor": 0, "reduce_scatter_tensor": 0, "all_reduce_avg": 0}
+    _ag, _rs, _ar = dist.all_gather_into_tensor, dist.reduce_scatter_tensor, dist.all_reduce
+
+    def ag(*a_, **k_):
+        calls["all_gather_into_tensor"] += 1
+        return _ag(*a_, **k_)
+
+    def rs(*a_, **k_):
+        calls["reduce_scatter_tensor"] += 1
+        return _rs(*a_, **k_)
+
+    def ar(t_, op=dist.ReduceOp.SUM, **k_):
+        calls["all_reduce_avg"] += int(op == dist.ReduceOp.AVG)
+        return _ar(t_, op=op, **k_)
+    dist.all_gather_into_tensor, dist.reduce_scatter_tensor, dist.all_reduce = ag, rs, ar
+    dist.all_gather = dist.reduce_scatter = None
     sys.path.insert(0, ROOT)
     import mammo_clip_amd  # noqa: F401
     from mammo_clip_amd.breastclip import util as U
@@ -362,6 +380,7 @@ def _w2_worker(rank, port, ret):
     from mammo_clip_amd.engine import validate
     res = validate(_ToyModel(), _ToyLoss(), {"d": [{"x": torch.tensor(float(rank + 1 + i))} for i in range(3)]})
     ok = ok and abs(res["d"]["total"] - (1.5 + 2.5 + 3.5) / 3) < 1e-6
+    ok = ok and calls["all_gather_into_tensor"] >= 2 and calls["reduce_scatter_tensor"] >= 2 and calls["all_reduce_avg"] >= 1
     ret[rank] = bool(ok)
     dist.destroy_process_group()
 
@@ -394,3 +413,69 @@ def test_grad_sink_sums_like_autograd():
     assert not sk.acc and not sk.pending
     # no sink installed: the backward functions return their gradients to autograd unchanged
     assert ops.GRAD_SINK is None and ops.deliver_param_grads([p1], [p1.grad]) == (p1.grad,)
+
+
+def test_trainer_step_failure_leaves_no_gradient_sink_behind():
+    """a step that raises (OOM, a data error in a re-forward) must not leave the module-level gradient sink
+    installed or carry partial gradients into the next step; a backward outside the Trainer sees plain autograd."""
+    import torch
+    from mammo_clip_amd import engine, ops
+
+    class Toy(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.ones(3))
+            self.fail = False
+
+        def forward(self, batch, device=None):
+            if self.fail:
+                raise RuntimeError("data error")
+
+            class F_(torch.autograd.Function):            # hands its parameter gradient to the sink like the HIP functions
+                @staticmethod
+                def forward(ctx, x, w):
+                    ctx.save_for_backward(x)
+                    return x * w
+
+                @staticmethod
+                def backward(ctx, g):
+                    (x,) = ctx.saved_tensors
+                    (gw,) = ops.deliver_param_grads([self.w], [(g * x).clone()])
+                    return None, gw
+            return {"y": F_.apply(batch["x"], self.w)}
+
+    def loss(y, is_train):
+        return {"total": y.sum()}
+    m = Toy()
+    opt = torch.optim.SGD(m.parameters(), lr=0.0)
+    tr = engine.Trainer(m, loss, opt, None, None)
+    tr.step({"x": torch.tensor([1.0, 2.0, 3.0])})
+    assert ops.GRAD_SINK is None and tr._sink is None and torch.equal(m.w.grad, torch.tensor([1.0, 2.0, 3.0]))
+    m.fail = True
+    with pytest.raises(RuntimeError, match="data error"):
+        tr.step({"x": torch.ones(3)})
+    assert ops.GRAD_SINK is None and tr._sink is None
+    # a failure INSIDE a backward call (sink installed at that moment)
+    m.fail = False
+
+    def bad_loss(y, is_train):
+        class G_(torch.autograd.Function):
+            @staticmethod
+            def forward(ctx, v):
+                return v.sum()
+
+            @staticmethod
+            def backward(ctx, g):
+                raise RuntimeError("backward error")
+        return {"total": G_.apply(y)}
+    tr.loss_func = bad_loss
+    with pytest.raises(RuntimeError, match="backward error"):
+        tr.step({"x": torch.ones(3)})
+    assert ops.GRAD_SINK is None and tr._sink is None
+    # the next good step starts clean, and a backward outside the Trainer delivers through autograd
+    tr.loss_func = loss
+    tr.step({"x": torch.tensor([2.0, 2.0, 2.0])})
+    assert torch.equal(m.w.grad, torch.tensor([2.0, 2.0, 2.0]))
+    m.zero_grad(set_to_none=True)
+    m({"x": torch.ones(3)})["y"].sum().backward()
+    assert torch.equal(m.w.grad, torch.ones(3))

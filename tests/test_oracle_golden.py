@@ -160,6 +160,22 @@ def test_e2e_eval(golden_dir, tag, arch_name):
         np.testing.assert_allclose([float(t.mean()), float(t.abs().max())], ref_taps[i], rtol=1e-3, atol=1e-4)
 
 
+def test_e2e_eval_further_seeds(golden_dir):
+    """config #1, eval mode, on the two further (weights, inputs) seeds of e2e_b2_cfg1_eval_seeds.npz (reference-generated)"""
+    z = np.load(os.path.join(golden_dir, "e2e_b2_cfg1_eval_seeds.npz"))
+    b, H, W, T = [int(v) for v in z["meta"]]
+    arch, cfg = oarch.build_arch("efficientnet-b2"), obert.BertShape()
+    for s_ in [int(v) for v in z["seeds"]]:
+        sd = ow.synth_state_dict(ow.clip_shapes(arch, cfg), seed=s_)
+        batch = ow.synth_batch(b, H, W, T, seed=s_)
+        with torch.no_grad():
+            out = oclip.forward(sd, batch, arch, cfg, train=False)
+            loss = _loss_from(out, b)
+        for k in ("image_embeddings", "text_embeddings", "text_embeddings2", "image_view_embeddings"):
+            np.testing.assert_allclose(out[k].numpy(), z[f"s{s_}/eval/{k}"], rtol=1e-3, atol=2e-5, err_msg=f"seed {s_} {k}")
+        np.testing.assert_allclose(float(loss), float(z[f"s{s_}/eval/total"]), rtol=0, atol=1e-5)
+
+
 def test_e2e_train_b2_cfg1(golden_dir):
     z, arch, cfg, sd, batch, b = _e2e(golden_dir, "e2e_b2_cfg1", "efficientnet-b2")
     sdg = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v)
