@@ -355,8 +355,9 @@ def test_hot_loop_trajectory_vs_reference():
     for k, (cos, ratio) in rep.items():
         # Adam's early updates are ~ lr * sign(g): elements whose gradient is below the bf16 noise floor flip sign, so the
         # direction agrees on the bulk (cos) and the step LENGTH (set by lr, weight decay and the schedule) is exact
-        assert cos >= 0.5, (k, cos)
-        assert abs(ratio - 1.0) <= 0.2, (k, ratio)
+        # (measured on MI355X, round 4: cosines 0.61 (_bn0.weight) .. 1.0, length ratios 0.98 .. 1.021)
+        assert cos >= 0.55, (k, cos)
+        assert abs(ratio - 1.0) <= 0.08, (k, ratio)
 
 
 def test_evaluator_entry_points(tmp_path):
