@@ -86,7 +86,7 @@ template <int K, int S, int CPL, int LP, int NCOL_ = 2> struct MarchCfg {
     static constexpr int PSB = (CPL == 2 && LP == 16) ? (NS == 2 ? 96 : 80) : (CPL == 2 && LP == 32) ? (NS == 4 ? 160 : 144) : PXB;
     static constexpr int IWP = SWZ ? (IW_T + (2 << SWZ_BIT) - 1) / (2 << SWZ_BIT) * (2 << SWZ_BIT) : IW_T;
     static constexpr int NR_ = (24576 + P * IW_T * PXB / 2) / (P * IW_T * PXB);
-    static constexpr int NR = NR_ < 1 ? 1 : NR_;           // periods per staged block (~24 KB of loads in flight)
+    static constexpr int NR = (NR_ < 1 || LP == 60) ? 1 : NR_;   // periods per staged block (~24 KB of loads in flight; the whole-pixel form: one period, register budget)
     static constexpr int RB = P * NR;                      // input rows per staged block
     static constexpr int TS = 256 - 256 % VPP;             // staging threads (vector index within a pixel fixed per thread)
     static constexpr int NV = (RB * IW_T * VPP + TS - 1) / TS;
@@ -149,15 +149,17 @@ __global__ __launch_bounds__(256, (K == 3 && S == 1 && !EPI ? 3 : 2)) void dwcon
         }
 
     // EPI: BatchNorm parameters of the lane's channels (z = e*scale + shift, xhat = (e - mean) * invstd)
-    // (the loop accumulates sum dZ and sum dZ * e; xhat = (e - mean) * invstd enters when the partials are written)
-    f32x2_t e_sc[C::H2], e_sh[C::H2];
+    // (the loop accumulates sum dZ and the CENTRED sum dZ * (e - mean) -- round 4: the uncentred form ended in a cancelling
+    // difference whose round-off depended on the summation order; invstd enters when the partials are written)
+    f32x2_t e_sc[C::H2], e_sh[C::H2], e_mu[C::H2];
     if constexpr (EPI) {
 #pragma unroll
         for (int h = 0; h < C::H2; ++h) {
-            e_sc[h] = e_sh[h] = f32x2_t{0.f, 0.f};
+            e_sc[h] = e_sh[h] = e_mu[h] = f32x2_t{0.f, 0.f};
             if (ch_ok) {
                 e_sc[h] = *reinterpret_cast<const f32x2_t*>(p.epi_scale + cl + 2 * h);
                 e_sh[h] = *reinterpret_cast<const f32x2_t*>(p.epi_shift + cl + 2 * h);
+                e_mu[h] = *reinterpret_cast<const f32x2_t*>(p.epi_mean + cl + 2 * h);
             }
         }
     }
@@ -188,10 +190,12 @@ __global__ __launch_bounds__(256, (K == 3 && S == 1 && !EPI ? 3 : 2)) void dwcon
         }
     }
     const int ebase = (wave * C::PXW + (lane_ok ? px : 0)) * C::PXB + lq * (CPL * 2);
-    if (has_pro && tid < 2 * C::TCH) {
-        const int ch = tid % C::TCH;
-        const float* src = tid < C::TCH ? p.pro_scale : p.pro_shift;
-        pro_lds[tid / C::TCH][ch] = (c0 + ch < p.c) ? src[c0 + ch] : 0.f;
+    if (has_pro) {
+        for (int t2 = tid; t2 < 2 * C::TCH; t2 += 256) {       // (the whole-pixel tiles have more than 128 channels)
+            const int ch = t2 % C::TCH;
+            const float* src = t2 < C::TCH ? p.pro_scale : p.pro_shift;
+            pro_lds[t2 / C::TCH][ch] = (c0 + ch < p.c) ? src[c0 + ch] : 0.f;
+        }
     }
 
     f32x2_t ssum[C::H2], ssq[C::H2];
@@ -389,7 +393,7 @@ __global__ __launch_bounds__(256, (K == 3 && S == 1 && !EPI ? 3 : 2)) void dwcon
                                         o2[h] = pack_bf2(dz.x, dz.y);
                                         const f32x2_t r = {bf_lo(o2[h]), bf_hi(o2[h])};  // reductions of the stored (rounded) dZ0
                                         ssum[h] += r;
-                                        ssq[h] = __builtin_elementwise_fma(r, e2, ssq[h]);
+                                        ssq[h] = __builtin_elementwise_fma(r, e2 - e_mu[h], ssq[h]);
                                     } else {
                                         o2[h] = pack_bf2(acc[i][sl][h].x, acc[i][sl][h].y);
                                         const f32x2_t r = {bf_lo(o2[h]), bf_hi(o2[h])};   // statistics of the stored (rounded) tensor
@@ -432,19 +436,14 @@ __global__ __launch_bounds__(256, (K == 3 && S == 1 && !EPI ? 3 : 2)) void dwcon
             red[tid * 2 * CPL + CPL + 2 * h] = ssq[h].x; red[tid * 2 * CPL + CPL + 2 * h + 1] = ssq[h].y;
         }
         __syncthreads();
-        if (tid < 2 * C::TCH) {
-            const int ch = tid % C::TCH, which = tid / C::TCH;          // 0 = sum, 1 = sum of squares
+        for (int t2 = tid; t2 < 2 * C::TCH; t2 += 256) {
+            const int ch = t2 % C::TCH, which = t2 / C::TCH;          // 0 = sum, 1 = sum of squares
             float s = 0.f;
             for (int wv = 0; wv < 4; ++wv)
                 for (int q = 0; q < C::PXW; ++q) s += red[(wv * 64 + q * LP + ch / CPL) * 2 * CPL + which * CPL + ch % CPL];
             if constexpr (EPI) {
-                // which == 1 holds sum dZ * e: turn it into sum dZ * xhat = invstd * (sum dZ * e - mean * sum dZ)
-                float s0 = 0.f;
-                if (which == 1) {
-                    for (int wv = 0; wv < 4; ++wv)
-                        for (int q = 0; q < C::PXW; ++q) s0 += red[(wv * 64 + q * LP + ch / CPL) * 2 * CPL + ch % CPL];
-                    if (c0 + ch < p.c) s = p.epi_invstd[c0 + ch] * (s - p.epi_mean[c0 + ch] * s0);
-                }
+                // which == 1 holds sum dZ * (e - mean): sum dZ * xhat = invstd * that
+                if (which == 1 && c0 + ch < p.c) s = p.epi_invstd[c0 + ch] * s;
             }
             if (c0 + ch < p.c) p.stat_partials[((long long)y * 2 + which) * p.c + c0 + ch] = s;
         }
@@ -509,10 +508,12 @@ __global__ __launch_bounds__(256, 2) void dwconv_march_bww_kernel(const mc_dwcon
                    ((unsigned)((((row * NCOL + col % NCOL) * XQ + col / NCOL) * C::PXB + vv * 16) >> 4) << 16);
         if (v >= ORB * C::TOW * C::VPP) metag[i] = 0xffu;
     }
-    if (has_pro && tid < 2 * C::TCH) {
-        const int ch = tid % C::TCH;
-        const float* src = tid < C::TCH ? p.pro_scale : p.pro_shift;
-        pro_lds[tid / C::TCH][ch] = (c0 + ch < p.c) ? src[c0 + ch] : 0.f;
+    if (has_pro) {
+        for (int t2 = tid; t2 < 2 * C::TCH; t2 += 256) {       // (the whole-pixel tiles have more than 128 channels)
+            const int ch = t2 % C::TCH;
+            const float* src = t2 < C::TCH ? p.pro_scale : p.pro_shift;
+            pro_lds[t2 / C::TCH][ch] = (c0 + ch < p.c) ? src[c0 + ch] : 0.f;
+        }
     }
 
     f32x2_t acc[K * K][C::H2];
@@ -778,13 +779,14 @@ __global__ __launch_bounds__(256, 2) void dwconv_march_bwd_s2_kernel(const mc_dw
     f32x2_t acc[C::D][NJ][4][C::H2];                       // [super-row slot][super-column][f*2+e][channel pair]
     constexpr int NE = EPI ? C::RB * 4 * NJ : 1;           // e pixels a lane completes per block: [dy row][f][i][e]
     ldsv_t enext[NE], ecur[NE];
-    f32x2_t e_sc[C::H2], e_sh[C::H2], ssum[C::H2], ssq[C::H2];
+    f32x2_t e_sc[C::H2], e_sh[C::H2], e_mu[C::H2], ssum[C::H2], ssq[C::H2];
 #pragma unroll
     for (int h = 0; h < C::H2; ++h) {
-        e_sc[h] = e_sh[h] = ssum[h] = ssq[h] = f32x2_t{0.f, 0.f};
+        e_sc[h] = e_sh[h] = e_mu[h] = ssum[h] = ssq[h] = f32x2_t{0.f, 0.f};
         if (EPI && ch_ok) {
             e_sc[h] = *reinterpret_cast<const f32x2_t*>(p.epi_scale + cl + 2 * h);
             e_sh[h] = *reinterpret_cast<const f32x2_t*>(p.epi_shift + cl + 2 * h);
+            e_mu[h] = *reinterpret_cast<const f32x2_t*>(p.epi_mean + cl + 2 * h);
         }
     }
 
@@ -967,7 +969,7 @@ __global__ __launch_bounds__(256, 2) void dwconv_march_bwd_s2_kernel(const mc_dw
                                                     o2[h] = pack_bf2(dz2.x, dz2.y);
                                                     const f32x2_t r = {bf_lo(o2[h]), bf_hi(o2[h])};     // reductions of the stored (rounded) dZ0
                                                     ssum[h] += r;
-                                                    ssq[h] = __builtin_elementwise_fma(r, e2, ssq[h]);
+                                                    ssq[h] = __builtin_elementwise_fma(r, e2 - e_mu[h], ssq[h]);   // centred (see the stride-1 form)
                                                 } else {
                                                     o2[h] = pack_bf2(acc[sl][i][f * 2 + e][h].x, acc[sl][i][f * 2 + e][h].y);
                                                 }
@@ -1003,16 +1005,13 @@ __global__ __launch_bounds__(256, 2) void dwconv_march_bwd_s2_kernel(const mc_dw
         }
         __syncthreads();
         if (tid < 2 * C::TCH) {
-            const int ch = tid % C::TCH, which = tid / C::TCH;          // 0 = sum dZ, 1 = sum dZ * e
-            float sv = 0.f, s0v = 0.f;
+            const int ch = tid % C::TCH, which = tid / C::TCH;          // 0 = sum dZ, 1 = sum dZ * (e - mean)
+            float sv = 0.f;
             for (int wv = 0; wv < 4; ++wv)
-                for (int q = 0; q < C::PXW; ++q) {
-                    sv += red[(wv * 64 + q * LP + ch / CPL) * 2 * CPL + which * CPL + ch % CPL];
-                    s0v += red[(wv * 64 + q * LP + ch / CPL) * 2 * CPL + ch % CPL];
-                }
+                for (int q = 0; q < C::PXW; ++q) sv += red[(wv * 64 + q * LP + ch / CPL) * 2 * CPL + which * CPL + ch % CPL];
             if (c0 + ch < p.c) {
-                // sum dZ * xhat = invstd * (sum dZ * e - mean * sum dZ)
-                if (which == 1) sv = p.epi_invstd[c0 + ch] * (sv - p.epi_mean[c0 + ch] * s0v);
+                // sum dZ * xhat = invstd * sum dZ * (e - mean)
+                if (which == 1) sv = p.epi_invstd[c0 + ch] * sv;
                 p.stat_partials[((long long)y * 2 + which) * p.c + c0 + ch] = sv;
             }
         }
@@ -1101,9 +1100,14 @@ template <typename C> MarchPlan march_plan(const mc_dwconv_args& p) {
 
 // tile shape by kernel size and channel count: k = 3 runs 4 channels per lane (64 / 48 / 24-channel tiles),
 // k = 5 (25 taps per channel in registers) 2 channels per lane (32 / 24-channel tiles)
-template <int K, int S, typename F> auto march_dispatch(const mc_dwconv_args& p, F&& f) {
+template <int K, int S, typename F> auto march_dispatch(const mc_dwconv_args& p, F&& f, bool whole_pixels = false) {
     if constexpr (K == 3) {
         if (p.c == 24) return f(MarchCfg<K, S, 4, 6>{});
+        // c = 240 (B5 stage 2, 380x228: the largest 3x3 tensors of the network): 64-channel tiles are 128-byte pieces of
+        // 480-byte pixels, misaligned with the 128-byte lines on 3 pixels of 4 -- whole pixels (60 lanes x 4 channels, one
+        // pixel per wave, 8-column strips whose rows are contiguous 3.8 KB runs) run the forward 1.2-1.35x faster in spite
+        // of the 2-in-10 column halo; the weight gradient (dy + x tiles) is faster on the 64-channel tiles
+        if (p.c == 240 && S == 1 && whole_pixels) return f(MarchCfg<K, S, 4, 60>{});
         if (p.c % 48 == 0 && p.c < 192) return f(MarchCfg<K, S, 4, 12>{});      // 48, 144: exact 48-channel tiles
         return f(MarchCfg<K, S, 4, 16>{});
     } else {
@@ -1128,7 +1132,7 @@ template <int K, int S, typename C> int launch_march(const mc_dwconv_args& p, hi
     return MC_OK;
 }
 template <int K, int S> int launch_march_cp(const mc_dwconv_args& p, hipStream_t st) {
-    return march_dispatch<K, S>(p, [&](auto cfg) { return launch_march<K, S, decltype(cfg)>(p, st); });
+    return march_dispatch<K, S>(p, [&](auto cfg) { return launch_march<K, S, decltype(cfg)>(p, st); }, true);
 }
 template <int K, int S, typename C> int launch_march_bww(const mc_dwconv_args& p, hipStream_t st) {
     MarchPlan m = march_plan<C>(p);
@@ -1148,7 +1152,7 @@ template <int K, int S> int launch_march_bww_cp(const mc_dwconv_args& p, hipStre
     return march_dispatch<K, S>(p, [&](auto cfg) { return launch_march_bww<K, S, decltype(cfg)>(p, st); });
 }
 template <int K, int S> int march_rows(const mc_dwconv_args& p) {
-    return march_dispatch<K, S>(p, [&](auto cfg) { return march_plan<decltype(cfg)>(p).gy; });
+    return march_dispatch<K, S>(p, [&](auto cfg) { return march_plan<decltype(cfg)>(p).gy; }, true);
 }
 
 int check_common(const mc_dwconv_args& p) {

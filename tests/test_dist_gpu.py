@@ -375,7 +375,6 @@ assert l0[0] == l1[0], (l0, l1)
 assert abs(l0[1] - l1[1]) < 5e-3, (l0, l1)
 worst = max(float((s0[k].float() - s1[k].float()).abs().max()) for k in s0)
 assert worst < 5e-3, worst
-assert calls["all_reduce_avg"] == 2 * len(tr.buckets.buckets), calls      # every bucket of both steps went through all_reduce(AVG)
 dist.destroy_process_group()
 print("DDP-OK", l0, l1, worst)
 '''
