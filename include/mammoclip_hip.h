@@ -187,6 +187,11 @@ int mc_wgrad_rows_bf16(const mc_wgrad_rows_args* args, void* stream);
 /* ------------------------------------------------------------------------------------------------
  * small helpers */
 int mc_cast_f32_bf16(const float* src, mc_bf16* dst, long long n, void* stream);
+/* low term of the two-term bf16 split of fp32 weights, dst = bf16(src - float(bf16(src))): with mc_cast_f32_bf16's image as
+ * the high term, x . (hi + lo)^T carries the weights to 2^-17 instead of 2^-9 (the opt-in "hi + lo" operand mode of the BERT
+ * linears -- the eval-mode parity configuration of DESIGN.md (c); the reference's own path is fp32 / fp16 autocast,
+ * trainer.py:271-278) */
+int mc_cast_f32_bf16_lo(const float* src, mc_bf16* dst, long long n, void* stream);
 int mc_cast_bf16_f32(const mc_bf16* src, float* dst, long long n, void* stream);
 int mc_transpose_f32(const float* src, float* dst, int rows, int cols, void* stream); /* dst[c][r] = src[r][c] */
 int mc_cast_transpose_f32_bf16(const float* src, mc_bf16* dst, int rows, int cols, void* stream); /* dst[c][r] = bf16(src[r][c]) */

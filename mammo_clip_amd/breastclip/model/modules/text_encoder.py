@@ -63,7 +63,7 @@ class _LayerFn(torch.autograd.Function):
         sq, sk, sv = att.self.query, att.self.key, att.self.value
         # fused QKV operand: [3H, H] bf16 weight image + [3H] fp32 bias, rebuilt only when one of the six parameters
         # changed (version counters: bumped by the optimizer step / load_state_dict), not on every layer call
-        ver = tuple(p_._version for p_ in (sq.weight, sk.weight, sv.weight, sq.bias, sk.bias, sv.bias)) + (sq.weight.data_ptr(),)
+        ver = tuple(p_._version for p_ in (sq.weight, sk.weight, sv.weight, sq.bias, sk.bias, sv.bias)) + (sq.weight.data_ptr(), bool(lyr.hilo))
         cache = getattr(lyr, "_qkv_cache", None)
         if cache is None or cache[0] != ver or cache[1].device != x.device:
             wqkv = torch.empty((3 * H, H), dtype=torch.bfloat16, device=x.device)
@@ -71,9 +71,24 @@ class _LayerFn(torch.autograd.Function):
             ops.cast_bf16(sk.weight, out=wqkv[H:2 * H])
             ops.cast_bf16(sv.weight, out=wqkv[2 * H:])
             bqkv = torch.cat([sq.bias.detach(), sk.bias.detach(), sv.bias.detach()]).float().contiguous()
-            lyr._qkv_cache = cache = (ver, wqkv, bqkv)
-        _, wqkv, bqkv = cache
-        qkv = ops.linear_fwd(x, wqkv, bias=bqkv)
+            wlo = None
+            if lyr.hilo:                                   # low terms of the two-term bf16 split (set_hilo_weights)
+                wlo = torch.empty((3 * H, H), dtype=torch.bfloat16, device=x.device)
+                ops.cast_bf16_lo(sq.weight, out=wlo[:H])
+                ops.cast_bf16_lo(sk.weight, out=wlo[H:2 * H])
+                ops.cast_bf16_lo(sv.weight, out=wlo[2 * H:])
+            lyr._qkv_cache = cache = (ver, wqkv, bqkv, wlo)
+        _, wqkv, bqkv, wqkv_lo = cache
+        hilo = bool(lyr.hilo)
+
+        def lin(inp, w_hi, bias, w_src, w_lo=None):
+            """y = inp . W^T + bias; hi + lo operand mode: a second GEMM adds inp . W_lo^T (the weights then carry 16
+            mantissa bits instead of 8: forward-only parity option, the backward uses the high terms)"""
+            y_ = ops.linear_fwd(inp, w_hi, bias=bias)
+            if hilo:
+                y_ = ops.linear_fwd(inp, w_lo if w_lo is not None else ops.cast_bf16_lo(w_src), residual=y_)
+            return y_
+        qkv = lin(x, wqkv, bqkv, None, wqkv_lo)
         fused = ops.attn_supported(t, hd)
         if fused:
             # one kernel: scores, mask, softmax, dropout and context; only (row max, 1/row sum) are kept for backward
@@ -91,14 +106,14 @@ class _LayerFn(torch.autograd.Function):
             ops.gemm(pd, qkv[:, 2 * H:], ctxv, t, hd, t, t, 3 * H, H, b_kmajor=1, batch=b * nh, nb2=nh,
                      sA=(nh * t * t, t * t), sB=(t * 3 * H, hd), sC=(t * H, hd))
         wo = ops.cast_bf16(att.output.dense.weight)
-        ao = ops.linear_fwd(ctxv, wo, bias=att.output.dense.bias)
+        ao = lin(ctxv, wo, att.output.dense.bias, att.output.dense.weight)
         a, mean1, rstd1 = ops.add_ln_fwd(ao, x, att.output.LayerNorm.weight, att.output.LayerNorm.bias, lyr.eps, ph, seed,
                                          sid + 1)
         wi = ops.cast_bf16(lyr.intermediate.dense.weight)
-        h1 = ops.linear_fwd(a, wi, bias=lyr.intermediate.dense.bias)
+        h1 = lin(a, wi, lyr.intermediate.dense.bias, lyr.intermediate.dense.weight)
         hg = ops.gelu_fwd(h1)
         w2 = ops.cast_bf16(lyr.output.dense.weight)
-        o = ops.linear_fwd(hg, w2, bias=lyr.output.dense.bias)
+        o = lin(hg, w2, lyr.output.dense.bias, lyr.output.dense.weight)
         y, mean2, rstd2 = ops.add_ln_fwd(o, a, lyr.output.LayerNorm.weight, lyr.output.LayerNorm.bias, lyr.eps, ph, seed,
                                          sid + 2)
         ctx.lyr, ctx.cfg = lyr, (b, t, seed, pa, ph, sid)
@@ -216,6 +231,7 @@ class BertLayerHIP(nn.Module):
         self.output = _Output(H, I, cfg.layer_norm_eps)
         self.hidden, self.heads, self.eps, self.index = H, cfg.num_attention_heads, cfg.layer_norm_eps, index
         self.p_attn, self.p_hidden = cfg.attention_probs_dropout_prob, cfg.hidden_dropout_prob
+        self.hilo = False                  # two-term bf16 weight operands in the forward (BertModelHIP.set_hilo_weights)
         self._param_names = [n for n, _ in self.named_parameters()]
 
     def _params(self):
@@ -282,6 +298,17 @@ class BertModelHIP(nn.Module):
         self._calls = 0
         self.rng_seed = 0xBE27
 
+    def set_hilo_weights(self, on: bool = True):
+        """Opt-in precision mode of the encoder's linear layers: every weight matrix enters its MFMA GEMM as TWO bf16 operands
+        (high term = the usual bf16 image, low term = bf16 of the remainder; ``mc_cast_f32_bf16_lo``), i.e. two GEMMs per
+        layer and the weights carried to 2^-17.  Purpose: the eval-mode parity configuration of DESIGN.md (c) -- with plain
+        bf16 weight operands the text side alone moves the eval loss of the reference's bn8k fixture by -1.1e-3 (measured on
+        the oracle), above north_star's 1e-3; the reference itself runs these GEMMs in fp32 / fp16 autocast
+        [ref: trainer.py:271-278].  Forward only: the backward keeps the high terms.  Default off (2x the BERT GEMM time)."""
+        for lyr in self.encoder.layer:
+            lyr.hilo = bool(on)
+        return self
+
     def forward(self, input_ids=None, attention_mask=None, token_type_ids=None, **_):
         if not input_ids.is_cuda:
             raise RuntimeError("mammo_clip_amd.BertModelHIP runs only on a HIP device (no CPU fallback)")
@@ -325,6 +352,10 @@ class HuggingfaceTextEncoder(nn.Module):
         self.text_encoder = BertModelHIP(BertConfigLite(**(config or {})))
         self.name, self.pretrained = name, pretrained
         self.out_dim = self.text_encoder.config.hidden_size
+
+    def set_hilo_weights(self, on: bool = True):
+        self.text_encoder.set_hilo_weights(on)
+        return self
 
     def forward(self, x):
         out = self.text_encoder(**x)

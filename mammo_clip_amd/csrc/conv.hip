@@ -1108,6 +1108,8 @@ template <int K, int S, typename F> auto march_dispatch(const mc_dwconv_args& p,
         // pixel per wave, 8-column strips whose rows are contiguous 3.8 KB runs) run the forward 1.2-1.35x faster in spite
         // of the 2-in-10 column halo; the weight gradient (dy + x tiles) is faster on the 64-channel tiles
         if (p.c == 240 && S == 1 && whole_pixels) return f(MarchCfg<K, S, 4, 60>{});
+        // (c = 144, 288-byte pixels: whole-pixel tiles of 36 lanes leave 28 lanes of a wave idle -- 0.85 vs 0.96 ms without the
+        // prologue, 1.18 vs 1.07 ms with it: not used)
         if (p.c % 48 == 0 && p.c < 192) return f(MarchCfg<K, S, 4, 12>{});      // 48, 144: exact 48-channel tiles
         return f(MarchCfg<K, S, 4, 16>{});
     } else {

@@ -26,6 +26,12 @@ __global__ void cast_f32_bf16_k(const float* __restrict__ s, bf16_t* __restrict_
         }
     }
 }
+// low part of the two-term bf16 split of an fp32 value: d = bf16(s - float(bf16(s)))  (s ~ hi + lo to 2^-17 relative)
+__global__ void cast_f32_bf16_lo_k(const float* __restrict__ s, bf16_t* __restrict__ d, long long n) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) d[i] = f2bf(s[i] - bf2f(f2bf(s[i])));
+}
 __global__ void cast_bf16_f32_k(const bf16_t* __restrict__ s, float* __restrict__ d, long long n) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long stride = (long long)gridDim.x * blockDim.x;
@@ -287,6 +293,15 @@ extern "C" int mc_cast_f32_bf16(const float* src, mc_bf16* dst, long long n, voi
     int blocks = mc_div_up(n, 256 * 8);
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(cast_f32_bf16_k, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, dst, n);
+    MC_LAUNCH_CHECK();
+    return MC_OK;
+}
+extern "C" int mc_cast_f32_bf16_lo(const float* src, mc_bf16* dst, long long n, void* stream) {
+    if (n <= 0) return MC_OK;
+    MC_CHECK(src && dst, "cast: null pointer");
+    int blocks = mc_div_up(n, 256);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(cast_f32_bf16_lo_k, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, dst, n);
     MC_LAUNCH_CHECK();
     return MC_OK;
 }

@@ -107,6 +107,7 @@ _SIGS = {
     "mc_wgrad_rows_bf16": ([C.POINTER(WgradRowsArgs), P], I),
     "mc_cast_f32_bf16": ([P, P, LL, P], I),
     "mc_cast_bf16_f32": ([P, P, LL, P], I),
+    "mc_cast_f32_bf16_lo": ([P, P, LL, P], I),
     "mc_transpose_f32": ([P, P, I, I, P], I),
     "mc_stem_weight_prep": ([P, P, I, P], I),
     "mc_stem_im2col": ([P, LL, LL, LL, LL, I, I, I, I, I, I, I, P, P], I),

@@ -438,6 +438,16 @@ def cast_bf16(src, out=None):
     return make() if out is not None else _cached("c", src, make)
 
 
+def cast_bf16_lo(src, out=None):
+    """low term of the two-term bf16 split: bf16(src - float(bf16(src)))  (cached like ``cast_bf16``)"""
+    def make():
+        s_ = src.contiguous()
+        dst = out if out is not None else empty(s_.shape, BF16, s_)
+        L.call("mc_cast_f32_bf16_lo", _p(s_), _p(dst), s_.numel(), _st())
+        return dst
+    return make() if out is not None else _cached("clo", src, make)
+
+
 def cast_f32(src):
     src = src.contiguous()
     dst = empty(src.shape, torch.float32, src)
