@@ -23,6 +23,7 @@
 // The accumulator rotation is static: a block is RB = 4 input rows, the rotation period P = A*S rows, and the interval
 // body is unrolled over the U = P / gcd(RB, P) phases.
 #include "common_hip.h"
+#include <cstdlib>
 #include "../../include/mammoclip_hip.h"
 
 namespace lane {
@@ -31,19 +32,27 @@ constexpr int pmod_c(int a, int m) { return ((a % m) + m) % m; }
 constexpr int fdiv_c(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
 constexpr int gcd_c(int a, int b) { return b == 0 ? a : gcd_c(b, a % b); }
 
-template <int K, int S, int NCOL> struct Cfg {
+// G > 1 ("several images per wave", narrow maps): the 64 lanes of a wave are G groups of LPI = 64 / G lanes, group g works on
+// image g of a group of G consecutive images -- a 57- or 29-column map then still fills the wave with two output columns per
+// lane.  A staged row is G segments (one per image, each with its own K-1 column halo); the work unit is (image group, row).
+template <int K, int S, int NCOL, int G = 1> struct Cfg {
+    static constexpr int K_ = K, S_ = S, NCOL_ = NCOL, G_ = G;
     static constexpr int WAVES = 16;
     static constexpr int NT = WAVES * 64;
     static constexpr int TCH = 2 * WAVES;               // channels per tile: one channel pair per wave
     static constexpr int VPP = TCH / 8;                 // 16-byte vectors per staged pixel
     static constexpr int PXD = TCH / 2 + 1;             // dwords per LDS pixel (odd: lane = column reads are conflict-free)
     static constexpr int NS = NCOL * S;                 // input-pixel distance between neighbouring lanes
-    static constexpr int IWMAX = 64 * NCOL * S;         // staged input columns: RB * IWMAX * VPP = a multiple of NT vectors
-    static constexpr int TOW = (IWMAX - K) / S + 1;     // output columns per strip (the last K-1 column slots of a wave idle)
-    static constexpr int IW_T = (TOW - 1) * S + K;      // staged input columns
+    static constexpr int LPI = 64 / G;                  // lanes per image
+    static constexpr int IWMAX = 64 * NCOL * S;         // staged input columns per row: RB * IWMAX * VPP = a multiple of NT vectors
+    // staged input columns per segment (32-column segments of a 5-tap kernel get one more: the 29-column maps need 33)
+    static constexpr int SEGI = IWMAX / G + ((G > 1 && IWMAX / G == 32 && K == 5) ? 1 : 0);
+    static constexpr int TOW = (SEGI - K) / S + 1;      // output columns per segment / strip (the last column slots of a group idle)
+    static constexpr int IW_T = (TOW - 1) * S + K;      // staged input columns per segment
     static constexpr int NIN = (NCOL - 1) * S + K;      // input pixels a lane reads per row
     static constexpr int HQ = (IW_T + NS - 1) / NS;     // positions per residue class
-    static constexpr int IWP = HQ * NS;
+    static constexpr int SEGP = HQ * NS;                // positions per segment
+    static constexpr int IWP = G * SEGP;
     static constexpr int A = (K + S - 1) / S;           // output rows in flight per lane
     static constexpr int P = A * S;                     // accumulator rotation period (input rows)
     static constexpr int RB = 4;                        // input rows per block
@@ -52,17 +61,18 @@ template <int K, int S, int NCOL> struct Cfg {
     static constexpr int IN_DW = RB * IWP * PXD;
     static constexpr int TOWP = 64 * NCOL;              // output-tile positions per row (lane x, column i -> i * 64 + x)
     static constexpr int OUT_DW = ORB * TOWP * PXD;
-    static constexpr int NV = (RB * IW_T * VPP + NT - 1) / NT;
-    static constexpr int NVO = (ORB * TOW * VPP + NT - 1) / NT;
-    static constexpr int LDS_BYTES = (2 * IN_DW + 2 * OUT_DW) * 4 + 2 * TCH * 4 + (128 * 16 + 20) * 4;
+    static constexpr int NV = (RB * G * IW_T * VPP + NT - 1) / NT;
+    static constexpr int NVO = (ORB * G * TOW * VPP + NT - 1) / NT;
+    static constexpr int LDS_BYTES = (2 * IN_DW + 2 * OUT_DW) * 4 + 2 * TCH * 4 + (128 * 16 + 24) * 4;
     static_assert(RB % S == 0 && (K - 1) % S == 0, "block / tap geometry");
+    static_assert(TOW <= LPI * NCOL, "a group's lanes cover its segment");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 };
 
 // Block descriptors live in LDS (a ring of 128, refilled 64 at a time by the lanes of wave 0 from a closed form of
 // block index -> (item, block)); everybody reads the few fields a pipeline stage needs when it needs them -- no long-lived
 // scalar state besides the filter taps (50 SGPRs for 5x5), no per-block cursor arithmetic on any wave's critical path.
-enum { D_FLAGS = 0, D_INB_LO, D_INB_HI, D_RLO, D_RHI, D_CLO, D_CHI, D_OUTB_LO, D_OUTB_HI, D_ORLO, D_ORHI, D_OCHI, D_WORDS = 16 };
+enum { D_FLAGS = 0, D_INB_LO, D_INB_HI, D_RLO, D_RHI, D_CLO, D_CHI, D_OUTB_LO, D_OUTB_HI, D_ORLO, D_ORHI, D_OCHI, D_NSEG, D_WORDS = 16 };
 constexpr int NDESC = 128;
 
 // EPI (stride 1): the launch is the DATA GRADIENT of a depthwise conv whose input was silu(bn0(e)); the kernel reads e at
@@ -72,10 +82,10 @@ constexpr int NDESC = 128;
 // the "output" tile (dy row o enters when input row o*S is processed); the registers hold the K*K tap accumulators of the
 // wave's channel pair and an A-deep window of unpacked dy rows; one butterfly sum per tap + one atomic per (tap, channel)
 // and workgroup at the end.
-template <int K, int S, int NCOL, int MODE>
+template <int K, int S, int NCOL, int MODE, int G>
 __global__ __launch_bounds__(1024, 4) void dwconv_lane_fwd_kernel(const mc_dwconv_args p, int strips, int nunits, int cpairs,
                                                                   int ctiles, int ymax) {
-    using C = Cfg<K, S, NCOL>;
+    using C = Cfg<K, S, NCOL, G>;
     constexpr bool EPI = MODE == 1, BWW = MODE == 2, ETILE = EPI || BWW;       // ETILE: a second global tensor staged in the output tile
     static_assert(!EPI || S == 1, "the BatchNorm-backward epilogue is provided for stride 1");
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
@@ -127,31 +137,6 @@ __global__ __launch_bounds__(1024, 4) void dwconv_lane_fwd_kernel(const mc_dwcon
         pro_lds[tid] = (c0 + ch < p.c) ? src[c0 + ch] : 0.f;
     }
 
-    // ---- per-thread staging geometry (constant for the whole kernel)
-    const int vv = tid % C::VPP;
-    const bool st_ch = c0 + vv * 8 < p.c;
-    unsigned meta[C::NV];                                  // row | col << 8 | LDS dword offset << 16
-#pragma unroll
-    for (int i = 0; i < C::NV; ++i) {
-        const int v = tid + i * C::NT;
-        const int row = v / (C::IW_T * C::VPP), col = (v / C::VPP) % C::IW_T;
-        const int pos = (col % C::NS) * C::HQ + col / C::NS;
-        meta[i] = (unsigned)row | ((unsigned)col << 8) | ((unsigned)((row * C::IWP + pos) * C::PXD + vv * 4) << 16);
-        if (v >= C::RB * C::IW_T * C::VPP || !st_ch) meta[i] = 0xffffu;   // row 255, col 255: never valid
-    }
-    unsigned metao[C::NVO];                                // out row | col << 8 | LDS dword offset << 16
-#pragma unroll
-    for (int i = 0; i < C::NVO; ++i) {
-        const int v = tid + i * C::NT;
-        const int row = v / (C::TOW * C::VPP), col = (v / C::VPP) % C::TOW;
-        const int pos = (col % NCOL) * 64 + col / NCOL;
-        metao[i] = (unsigned)row | ((unsigned)col << 8) | ((unsigned)((row * C::TOWP + pos) * C::PXD + vv * 4) << 16);
-        if (v >= C::ORB * C::TOW * C::VPP || !st_ch) metao[i] = 0xffffu;
-    }
-    const int in_row_pitch = p.w * p.c, out_row_pitch = p.ow * p.c;      // elements (< 2^31: one image row)
-
-    // ---- block descriptors: closed form of (block index -> item, block of the item), 64 blocks at a time by the lanes
-    // of wave 0.  A range is: rest of the first (image, strip) unit, whole units, head of the last unit.
     // (plain local copies: lambdas that capture the by-value argument struct by reference make the compiler keep a
     // private-memory image of it)
     const int a_h = p.h, a_w = p.w, a_c = p.c, a_oh = p.oh, a_ow = p.ow, a_pad_t = p.pad_t, a_pad_l = p.pad_l, a_n = p.n;
@@ -159,8 +144,36 @@ __global__ __launch_bounds__(1024, 4) void dwconv_lane_fwd_kernel(const mc_dwcon
     const bf16_t* const a_epi_x = p.epi_x;
     const bf16_t* const a_dy = p.dy;
     bf16_t* const a_out = reinterpret_cast<bf16_t*>(p.out);
+    // ---- per-thread staging geometry (constant for the whole kernel)
+    const int in_row_pitch = a_w * a_c, out_row_pitch = a_ow * a_c;      // elements (< 2^31: one image row)
+    const int in_img_pitch = G > 1 ? a_h * in_row_pitch : 0, out_img_pitch = G > 1 ? a_oh * out_row_pitch : 0;   // (G > 1: small maps)
+    const int vv = tid % C::VPP;
+    const bool st_ch = c0 + vv * 8 < p.c;
+    unsigned meta[C::NV];                                  // row | segment << 4 | col << 8 | LDS dword offset << 16
+#pragma unroll
+    for (int i = 0; i < C::NV; ++i) {
+        const int v = tid + i * C::NT;
+        const int pidx = v / C::VPP;
+        const int row = pidx / (G * C::IW_T), seg = (pidx % (G * C::IW_T)) / C::IW_T, col = pidx % C::IW_T;
+        const int pos = seg * C::SEGP + (col % C::NS) * C::HQ + col / C::NS;
+        meta[i] = (unsigned)row | ((unsigned)seg << 4) | ((unsigned)col << 8) | ((unsigned)((row * C::IWP + pos) * C::PXD + vv * 4) << 16);
+        if (v >= C::RB * G * C::IW_T * C::VPP || !st_ch) meta[i] = 0xffffu;   // row 15, segment 15, col 255: never valid
+    }
+    unsigned metao[C::NVO];                                // out row | segment << 4 | col << 8 | LDS dword offset << 16
+#pragma unroll
+    for (int i = 0; i < C::NVO; ++i) {
+        const int v = tid + i * C::NT;
+        const int pidx = v / C::VPP;
+        const int row = pidx / (G * C::TOW), seg = (pidx % (G * C::TOW)) / C::TOW, col = pidx % C::TOW;
+        const int pos = (col % NCOL) * 64 + seg * C::LPI + col / NCOL;
+        metao[i] = (unsigned)row | ((unsigned)seg << 4) | ((unsigned)col << 8) | ((unsigned)((row * C::TOWP + pos) * C::PXD + vv * 4) << 16);
+        if (v >= C::ORB * G * C::TOW * C::VPP || !st_ch) metao[i] = 0xffffu;
+    }
+
+    // ---- block descriptors: closed form of (block index -> item, block of the item), 64 blocks at a time by the lanes
+    // of wave 0.  A range is: rest of the first (image, strip) unit, whole units, head of the last unit.
     int* const s_gen = s_desc + NDESC * D_WORDS;                      // range parameters (thread 0 computes them once)
-    enum { G_U0 = 0, G_U1, G_O0, G_O1, G_NR0, G_NB0, G_NBF, G_NFULL, G_NBTOT, G_H, G_W, G_C, G_OH, G_OW, G_PT, G_PL, G_STRIPS, G_C0, G_WORDS = 20 };
+    enum { G_U0 = 0, G_U1, G_O0, G_O1, G_NR0, G_NB0, G_NBF, G_NFULL, G_NBTOT, G_H, G_W, G_C, G_OH, G_OW, G_PT, G_PL, G_STRIPS, G_C0, G_N, G_WORDS = 24 };
     auto nblk_of = [&](int nrows) { return ((nrows - 1) * S + K + C::RB - 1) / C::RB; };
     if (tid == 0) {
         const long long vt = (long long)a_n * strips * a_oh;
@@ -174,7 +187,7 @@ __global__ __launch_bounds__(1024, 4) void dwconv_lane_fwd_kernel(const mc_dwcon
         s_gen[G_U0] = u0; s_gen[G_U1] = u1; s_gen[G_O0] = o0; s_gen[G_O1] = o1; s_gen[G_NR0] = nr0; s_gen[G_NB0] = nb0;
         s_gen[G_NBF] = nbf; s_gen[G_NFULL] = nfull; s_gen[G_NBTOT] = nb0 + nfull * nbf + nbl;   // blocks of this workgroup
         s_gen[G_H] = a_h; s_gen[G_W] = a_w; s_gen[G_C] = a_c; s_gen[G_OH] = a_oh; s_gen[G_OW] = a_ow; s_gen[G_PT] = a_pad_t;
-        s_gen[G_PL] = a_pad_l; s_gen[G_STRIPS] = strips; s_gen[G_C0] = c0;
+        s_gen[G_PL] = a_pad_l; s_gen[G_STRIPS] = strips; s_gen[G_C0] = c0; s_gen[G_N] = a_n;
     }
     __syncthreads();
     const int nbtot = __builtin_amdgcn_readfirstlane(s_gen[G_NBTOT]);
@@ -185,7 +198,7 @@ __global__ __launch_bounds__(1024, 4) void dwconv_lane_fwd_kernel(const mc_dwcon
         const int u0 = s_gen[G_U0], u1 = s_gen[G_U1], o0 = s_gen[G_O0], o1 = s_gen[G_O1], nr0 = s_gen[G_NR0], nb0 = s_gen[G_NB0],
                   nbf = s_gen[G_NBF], nfull = s_gen[G_NFULL];
         const int g_h = s_gen[G_H], g_w = s_gen[G_W], g_c = s_gen[G_C], g_oh = s_gen[G_OH], g_ow = s_gen[G_OW], g_pt = s_gen[G_PT],
-                  g_pl = s_gen[G_PL], g_strips = s_gen[G_STRIPS], g_c0 = s_gen[G_C0];
+                  g_pl = s_gen[G_PL], g_strips = s_gen[G_STRIPS], g_c0 = s_gen[G_C0], g_n = s_gen[G_N];
         int u, oy0, nrows, b;
         if (t < nb0) { u = u0; oy0 = o0; nrows = nr0; b = t; }
         else {
@@ -193,7 +206,8 @@ __global__ __launch_bounds__(1024, 4) void dwconv_lane_fwd_kernel(const mc_dwcon
             if (k < nfull) { u = u0 + 1 + k; oy0 = 0; nrows = g_oh; b = t2 - k * nbf; }
             else { u = u1; oy0 = 0; nrows = o1; b = t2 - nfull * nbf; }
         }
-        const int img = u / g_strips, strip = u - img * g_strips;
+        const int grp = u / g_strips, strip = u - grp * g_strips;
+        const int img = grp * G;                                        // first image of the group
         const int ox0 = strip * C::TOW;
         const int iy0 = oy0 * S - g_pt + b * C::RB, ix0 = ox0 * S - g_pl;
         const long long inb = (((long long)img * g_h + iy0) * g_w + ix0) * (long long)g_c + g_c0;
@@ -211,6 +225,7 @@ __global__ __launch_bounds__(1024, 4) void dwconv_lane_fwd_kernel(const mc_dwcon
         d[D_OUTB_LO] = (int)(unsigned)outb; d[D_OUTB_HI] = (int)(outb >> 32);
         d[D_ORLO] = o_first < 0 ? -o_first : 0; d[D_ORHI] = orhi;
         d[D_OCHI] = ochi;
+        d[D_NSEG] = g_n - img < G ? g_n - img : G;                     // images of the group that exist
     };
     if (wv == 0) { gen_desc(0); gen_desc(64); }            // blocks 0 .. 127
     // the output tile doubles as the e tile of the epilogue form: slots no stage ever writes (columns >= TOW) must not
@@ -224,18 +239,20 @@ __global__ __launch_bounds__(1024, 4) void dwconv_lane_fwd_kernel(const mc_dwcon
     uint4 evals[ETILE ? C::NVO : 1];
     unsigned einb = 0;
     // global -> registers for block q
-    auto stage_load = [&](int q) {
+    // (always executed -- `live` = the block exists: straight-line loads keep the compiler from treating the prefetch registers as
+    // conditionally defined, which costs copies of in-flight registers and a forced wait)
+    auto stage_load = [&](int q, bool live) {
         const int* d = s_desc + (q & (NDESC - 1)) * D_WORDS;
         const long long base = ((long long)d[D_INB_HI] << 32) | (unsigned)d[D_INB_LO];
-        const int rlo = d[D_RLO], rhi = d[D_RHI], clo = d[D_CLO], chi = d[D_CHI];
+        const int rlo = d[D_RLO], rhi = d[D_RHI], clo = d[D_CLO], chi = d[D_CHI], nseg = d[D_NSEG];
         const bf16_t* org = a_x + base + vv * 8;
         inb = 0;
 #pragma unroll
         for (int i = 0; i < C::NV; ++i) {
-            const int row = (int)(meta[i] & 0xffu), col = (int)((meta[i] >> 8) & 0xffu);
-            const bool ok = row >= rlo && row < rhi && col >= clo && col < chi;
-            const int goff = row * in_row_pitch + col * a_c;
-            vals[i] = *reinterpret_cast<const uint4*>(ok ? org + goff : a_x);       // unconditional load, clamped address
+            const int row = (int)(meta[i] & 0xfu), seg = (int)((meta[i] >> 4) & 0xfu), col = (int)((meta[i] >> 8) & 0xffu);
+            const bool ok = live && row >= rlo && row < rhi && col >= clo && col < chi && seg < nseg;
+            const int goff = seg * in_img_pitch + row * in_row_pitch + col * a_c;
+            vals[i] = *reinterpret_cast<const uint4*>(ok ? org + goff : a_x);        // unconditional load, clamped address
             inb |= (ok ? 1u : 0u) << i;
         }
         if constexpr (ETILE) {                             // e rows of the output rows block q completes / its dy rows
@@ -246,9 +263,9 @@ __global__ __launch_bounds__(1024, 4) void dwconv_lane_fwd_kernel(const mc_dwcon
             einb = 0;
 #pragma unroll
             for (int i = 0; i < C::NVO; ++i) {
-                const int row = (int)(metao[i] & 0xffu), col = (int)((metao[i] >> 8) & 0xffu);
-                const bool ok = row >= orlo && row < orhi && col < ochi;
-                const int goff = row * out_row_pitch + col * a_c;
+                const int row = (int)(metao[i] & 0xfu), seg = (int)((metao[i] >> 4) & 0xfu), col = (int)((metao[i] >> 8) & 0xffu);
+                const bool ok = live && row >= orlo && row < orhi && col < ochi && seg < nseg;
+                const int goff = seg * out_img_pitch + row * out_row_pitch + col * a_c;
                 evals[i] = *reinterpret_cast<const uint4*>(ok ? eorg + goff : esrc);
                 einb |= (ok ? 1u : 0u) << i;
             }
@@ -261,7 +278,7 @@ __global__ __launch_bounds__(1024, 4) void dwconv_lane_fwd_kernel(const mc_dwcon
         if (has_pro) { load8f(&pro_lds[vv * 8], ps); load8f(&pro_lds[C::TCH + vv * 8], pt); }
 #pragma unroll
         for (int i = 0; i < C::NV; ++i) {
-            if ((meta[i] & 0xffu) != 0xffu) {
+            if ((meta[i] & 0xffffu) != 0xffffu) {
                 const bool real = (inb >> i) & 1u;
                 uint4 val = real ? vals[i] : make_uint4(0u, 0u, 0u, 0u);
                 if (has_pro && real) {
@@ -279,16 +296,16 @@ __global__ __launch_bounds__(1024, 4) void dwconv_lane_fwd_kernel(const mc_dwcon
     auto flush_out = [&](int q, int buf) {
         const int* d = s_desc + (q & (NDESC - 1)) * D_WORDS;
         const long long obase = ((long long)d[D_OUTB_HI] << 32) | (unsigned)d[D_OUTB_LO];
-        const int orlo = d[D_ORLO], orhi = d[D_ORHI], ochi = d[D_OCHI];
+        const int orlo = d[D_ORLO], orhi = d[D_ORHI], ochi = d[D_OCHI], nseg = d[D_NSEG];
         const uint32_t* src = s_out + buf * C::OUT_DW;
         bf16_t* org = a_out + obase + vv * 8;
 #pragma unroll
         for (int i = 0; i < C::NVO; ++i) {
-            const int row = (int)(metao[i] & 0xffu), col = (int)((metao[i] >> 8) & 0xffu);
-            if (row >= orlo && row < orhi && col < ochi) {
+            const int row = (int)(metao[i] & 0xfu), seg = (int)((metao[i] >> 4) & 0xfu), col = (int)((metao[i] >> 8) & 0xffu);
+            if (row >= orlo && row < orhi && col < ochi && seg < nseg) {
                 const uint32_t* sp = src + (metao[i] >> 16);
                 const uint4 val = make_uint4(sp[0], sp[1], sp[2], sp[3]);
-                *reinterpret_cast<uint4*>(org + (row * out_row_pitch + col * a_c)) = val;
+                *reinterpret_cast<uint4*>(org + (seg * out_img_pitch + row * out_row_pitch + col * a_c)) = val;
             }
         }
     };
@@ -297,7 +314,7 @@ __global__ __launch_bounds__(1024, 4) void dwconv_lane_fwd_kernel(const mc_dwcon
             uint32_t* dst = s_out + buf * C::OUT_DW;
 #pragma unroll
             for (int i = 0; i < C::NVO; ++i) {
-                if ((metao[i] & 0xffu) != 0xffu) {
+                if ((metao[i] & 0xffffu) != 0xffffu) {
                     const uint4 val = ((einb >> i) & 1u) ? evals[i] : make_uint4(0u, 0u, 0u, 0u);
                     uint32_t* dd = dst + (metao[i] >> 16);
                     dd[0] = val.x; dd[1] = val.y; dd[2] = val.z; dd[3] = val.w;
@@ -318,7 +335,7 @@ __global__ __launch_bounds__(1024, 4) void dwconv_lane_fwd_kernel(const mc_dwcon
 
     // interval q: store block q (loaded in interval q-1), flush block q-2, load block q+1, compute block q-1.
     // in-buffer of block q: q & 1; out-buffer of block q: q & 1.  nbtot + 2 intervals.
-    if (nbtot > 0) stage_load(0);
+    stage_load(0, nbtot > 0);
     int q = 0;
     while (true) {
 #pragma unroll
@@ -330,8 +347,8 @@ __global__ __launch_bounds__(1024, 4) void dwconv_lane_fwd_kernel(const mc_dwcon
             if (v_st) stage_store(q & 1);
             if (v_fl) flush_out(q - 2, q & 1);
             if (ETILE && v_st) estore(q & 1);
-            // (2) prefetch block q+1
-            if (v_ld) stage_load(q + 1);
+            // (2) prefetch block q+1  (issuing it BEFORE the output stores was measured slower: 0.272 -> 0.318 ms at c = 384)
+            stage_load(q + 1, v_ld);
             // (3) compute block q-1
             if (v_cp) {
                 if constexpr (BWW) {
@@ -342,7 +359,7 @@ __global__ __launch_bounds__(1024, 4) void dwconv_lane_fwd_kernel(const mc_dwcon
 #pragma unroll
                             for (int a = 0; a < C::A; ++a) acc[i][a] = f32x2_t{0.f, 0.f};
                     }
-                    const uint32_t* lin = s_in + ((q - 1) & 1) * C::IN_DW + x * C::PXD + wv;
+                    const uint32_t* lin = s_in + ((q - 1) & 1) * C::IN_DW + ((x / C::LPI) * C::SEGP + x % C::LPI) * C::PXD + wv;
                     const uint32_t* lg = s_out + ((q - 1) & 1) * C::OUT_DW + x * C::PXD + wv;
 #pragma unroll
                     for (int j = 0; j < C::RB; ++j) {
@@ -375,12 +392,12 @@ __global__ __launch_bounds__(1024, 4) void dwconv_lane_fwd_kernel(const mc_dwcon
                 } else {
                 const int* d = s_desc + ((q - 1) & (NDESC - 1)) * D_WORDS;
                 const int orlo = __builtin_amdgcn_readfirstlane(d[D_ORLO]), orhi = __builtin_amdgcn_readfirstlane(d[D_ORHI]);
-                const int ochi = d[D_OCHI];
-                const uint32_t* lin = s_in + ((q - 1) & 1) * C::IN_DW + x * C::PXD + wv;
+                const int ochi = d[D_OCHI], nseg = d[D_NSEG];
+                const uint32_t* lin = s_in + ((q - 1) & 1) * C::IN_DW + ((x / C::LPI) * C::SEGP + x % C::LPI) * C::PXD + wv;
                 uint32_t* lout = s_out + ((q - 1) & 1) * C::OUT_DW + x * C::PXD + wv;
                 uint32_t cm[NCOL];                                     // all ones where the lane's i-th column exists
 #pragma unroll
-                for (int i = 0; i < NCOL; ++i) cm[i] = (ch_ok && x * NCOL + i < ochi) ? 0xffffffffu : 0u;
+                for (int i = 0; i < NCOL; ++i) cm[i] = (ch_ok && (x % C::LPI) * NCOL + i < ochi && x / C::LPI < nseg) ? 0xffffffffu : 0u;
 #pragma unroll
                 for (int j = 0; j < C::RB; ++j) {
                     const int jr = (ph * C::RB + j) % C::P;            // rotation index of this input row (static)
@@ -476,10 +493,10 @@ done:
 struct Plan { int strips, nunits, cpairs, ctiles, ymax, grid; };
 template <typename C> Plan plan(const mc_dwconv_args& p) {
     Plan m;
-    m.strips = mc_div_up(p.ow, C::TOW);
+    m.strips = C::G_ > 1 ? 1 : mc_div_up(p.ow, C::TOW);             // (image groups: the map fits one segment)
     m.ctiles = mc_div_up(p.c, C::TCH);
     m.cpairs = (m.ctiles + 1) / 2;
-    const long long vt = (long long)p.n * m.strips * p.oh;
+    const long long vt = (long long)((p.n + C::G_ - 1) / C::G_) * m.strips * p.oh;
     long long ycap = vt / 8;                                          // at least 8 output rows per workgroup
     if (ycap < 1) ycap = 1;
     long long nunits = ycap * m.cpairs;
@@ -491,15 +508,39 @@ template <typename C> Plan plan(const mc_dwconv_args& p) {
     return m;
 }
 
-template <int K, int S, int NCOL, int MODE> int launch(const mc_dwconv_args& p, hipStream_t st) {
-    using C = Cfg<K, S, NCOL>;
+template <typename C, int MODE> int launch(const mc_dwconv_args& p, hipStream_t st) {
     static unsigned long long attr_done = 0;
-    auto kern = dwconv_lane_fwd_kernel<K, S, NCOL, MODE>;
+    auto kern = dwconv_lane_fwd_kernel<C::K_, C::S_, C::NCOL_, MODE, C::G_>;
     MC_SET_MAX_LDS(attr_done, kern, C::LDS_BYTES);
     const Plan m = plan<C>(p);
     hipLaunchKernelGGL(kern, dim3(m.grid), dim3(C::NT), C::LDS_BYTES, st, p, m.strips, m.nunits, m.cpairs, m.ctiles, m.ymax);
     MC_LAUNCH_CHECK();
     return MC_OK;
+}
+
+// configuration by map width and image count: two output columns per lane wherever the registers allow it (not: stride 2,
+// the 5x5 weight gradient), and as many images per wave (4 / 2 / 1) as fit the map into a lane group
+template <int K, int S, int MODE, typename F> auto pick(const mc_dwconv_args& p, F&& f) {
+    constexpr bool one_col = (S == 2) || (MODE == 2 && K == 5);
+    if constexpr (one_col) {
+        return f(Cfg<K, S, 1, 1>{});
+    } else {
+        // EXPERIMENTAL, off by default (MC_DW_LANE_G=2|4 enables it for measurements): several images per wave.  Measured on
+        // MI355X (round 4): with all 64 lanes busy on 57- / 29-column maps the interval time DOUBLES against the one-image
+        // form (c = 1056: 0.39 vs 0.24 ms; c = 1824: 0.37 vs 0.22 ms) although the instruction streams are identical -- the
+        // blocks then carry twice the bytes and the kernel turns out to be bound by per-CU memory throughput (one 32 KB block
+        // in flight per CU), not by VALU issue.  Not used by the product path; not covered by the parity tests.
+        static const int gmax = [] { const char* e = getenv("MC_DW_LANE_G"); return e ? atoi(e) : 1; }();
+        if (gmax >= 4 && p.n >= 4 && p.ow <= Cfg<K, S, 2, 4>::TOW) return f(Cfg<K, S, 2, 4>{});
+        if (gmax >= 2 && p.n >= 2 && p.ow <= Cfg<K, S, 2, 2>::TOW) return f(Cfg<K, S, 2, 2>{});
+        if (gmax == 0 && p.ow <= Cfg<K, S, 2, 1>::TOW) return f(Cfg<K, S, 2, 1>{});
+        if (p.ow <= Cfg<K, S, 1, 1>::TOW) return f(Cfg<K, S, 1, 1>{});
+        return f(Cfg<K, S, 2, 1>{});
+    }
+}
+template <int MODE, typename F> auto pick_ks(const mc_dwconv_args& p, F&& f) {
+    if (p.k == 3) return p.stride == 1 ? pick<3, 1, MODE>(p, f) : pick<3, 2, (MODE == 1 ? 0 : MODE)>(p, f);
+    return p.stride == 1 ? pick<5, 1, MODE>(p, f) : pick<5, 2, (MODE == 1 ? 0 : MODE)>(p, f);
 }
 
 }  // namespace lane
@@ -516,13 +557,11 @@ extern "C" int mc_dwconv_lane_supported(const mc_dwconv_args* a) {
 
 extern "C" int mc_dwconv_lane_stat_rows(const mc_dwconv_args* a) {
     const mc_dwconv_args& p = *a;
-    const bool wide = p.stride == 1 && p.ow > (p.k == 3 ? lane::Cfg<3, 1, 1>::TOW : lane::Cfg<5, 1, 1>::TOW);
-    if (p.k == 3) {
-        if (p.stride == 2) return lane::plan<lane::Cfg<3, 2, 1>>(p).ymax;
-        return wide ? lane::plan<lane::Cfg<3, 1, 2>>(p).ymax : lane::plan<lane::Cfg<3, 1, 1>>(p).ymax;
+    if (p.epi_x) {
+        if (p.k == 3) return lane::pick<3, 1, 1>(p, [&](auto cfg) { return lane::plan<decltype(cfg)>(p).ymax; });
+        return lane::pick<5, 1, 1>(p, [&](auto cfg) { return lane::plan<decltype(cfg)>(p).ymax; });
     }
-    if (p.stride == 2) return lane::plan<lane::Cfg<5, 2, 1>>(p).ymax;
-    return wide ? lane::plan<lane::Cfg<5, 1, 2>>(p).ymax : lane::plan<lane::Cfg<5, 1, 1>>(p).ymax;
+    return lane::pick_ks<0>(p, [&](auto cfg) { return lane::plan<decltype(cfg)>(p).ymax; });
 }
 
 extern "C" int mc_dwconv_fwd_lane(const mc_dwconv_args* a, void* stream) {
@@ -532,15 +571,11 @@ extern "C" int mc_dwconv_fwd_lane(const mc_dwconv_args* a, void* stream) {
     MC_CHECK(!p.epi_x || (p.epi_scale && p.epi_shift && p.epi_mean && p.epi_invstd && p.stat_partials),
              "dwconv_fwd_lane: the BatchNorm-backward epilogue needs scale/shift/mean/invstd and stat_partials");
     hipStream_t st = (hipStream_t)stream;
-    const bool wide = p.stride == 1 && p.ow > (p.k == 3 ? lane::Cfg<3, 1, 1>::TOW : lane::Cfg<5, 1, 1>::TOW);
-    if (p.k == 3) {
-        if (p.stride == 2) return lane::launch<3, 2, 1, 0>(p, st);
-        if (p.epi_x) return wide ? lane::launch<3, 1, 2, 1>(p, st) : lane::launch<3, 1, 1, 1>(p, st);
-        return wide ? lane::launch<3, 1, 2, 0>(p, st) : lane::launch<3, 1, 1, 0>(p, st);
+    if (p.epi_x) {
+        if (p.k == 3) return lane::pick<3, 1, 1>(p, [&](auto cfg) { return lane::launch<decltype(cfg), 1>(p, st); });
+        return lane::pick<5, 1, 1>(p, [&](auto cfg) { return lane::launch<decltype(cfg), 1>(p, st); });
     }
-    if (p.stride == 2) return lane::launch<5, 2, 1, 0>(p, st);
-    if (p.epi_x) return wide ? lane::launch<5, 1, 2, 1>(p, st) : lane::launch<5, 1, 1, 1>(p, st);
-    return wide ? lane::launch<5, 1, 2, 0>(p, st) : lane::launch<5, 1, 1, 0>(p, st);
+    return lane::pick_ks<0>(p, [&](auto cfg) { return lane::launch<decltype(cfg), 0>(p, st); });
 }
 
 extern "C" int mc_dwconv_bwd_weight_lane(const mc_dwconv_args* a, void* stream) {
@@ -548,11 +583,5 @@ extern "C" int mc_dwconv_bwd_weight_lane(const mc_dwconv_args* a, void* stream) 
     MC_CHECK(mc_dwconv_lane_supported(a) && !p.epi_x, "dwconv_bwd_weight_lane: unsupported shape");
     MC_CHECK(p.x && p.dy && p.out, "dwconv_bwd_weight_lane: null x / dy / out");
     hipStream_t st = (hipStream_t)stream;
-    const bool wide = p.stride == 1 && p.ow > (p.k == 3 ? lane::Cfg<3, 1, 1>::TOW : lane::Cfg<5, 1, 1>::TOW);
-    if (p.k == 3) {
-        if (p.stride == 2) return lane::launch<3, 2, 1, 2>(p, st);
-        return wide ? lane::launch<3, 1, 2, 2>(p, st) : lane::launch<3, 1, 1, 2>(p, st);
-    }
-    if (p.stride == 2) return lane::launch<5, 2, 1, 2>(p, st);
-    return lane::launch<5, 1, 1, 2>(p, st);         // (two columns per lane: 50 tap accumulators + a 20-register dy window spill)
+    return lane::pick_ks<2>(p, [&](auto cfg) { return lane::launch<decltype(cfg), 2>(p, st); });
 }
