@@ -1106,7 +1106,7 @@ template <int K, int S, typename F> auto march_dispatch(const mc_dwconv_args& p,
         // c = 240 (B5 stage 2, 380x228: the largest 3x3 tensors of the network): 64-channel tiles are 128-byte pieces of
         // 480-byte pixels, misaligned with the 128-byte lines on 3 pixels of 4 -- whole pixels (60 lanes x 4 channels, one
         // pixel per wave, 8-column strips whose rows are contiguous 3.8 KB runs) run the forward 1.2-1.35x faster in spite
-        // of the 2-in-10 column halo; the weight gradient (dy + x tiles) is faster on the 64-channel tiles
+        // of the 2-in-10 column halo; the weight gradient gains 1.2x once it runs three workgroups per CU (0.725 -> 0.597 ms)
         if (p.c == 240 && S == 1 && whole_pixels) return f(MarchCfg<K, S, 4, 60>{});
         // (c = 144, 288-byte pixels: whole-pixel tiles of 36 lanes leave 28 lanes of a wave idle -- 0.85 vs 0.96 ms without the
         // prologue, 1.18 vs 1.07 ms with it: not used)
@@ -1139,7 +1139,7 @@ template <int K, int S> int launch_march_cp(const mc_dwconv_args& p, hipStream_t
 template <int K, int S, typename C> int launch_march_bww(const mc_dwconv_args& p, hipStream_t st) {
     MarchPlan m = march_plan<C>(p);
     long long nitems = (long long)p.n * m.strips * m.segs;      // 2 workgroups per CU here; capped per XCD (see march_plan)
-    long long per_xcd = 64 / m.ctiles;
+    long long per_xcd = (C::TCH == 240 ? 96 : 64) / m.ctiles;    // (the whole-pixel form fits three workgroups per CU: 156 VGPRs)
     if (per_xcd < 1) per_xcd = 1;
     long long cap = 8 * per_xcd;
     long long per = (nitems + cap - 1) / cap;
@@ -1151,7 +1151,7 @@ template <int K, int S, typename C> int launch_march_bww(const mc_dwconv_args& p
     return MC_OK;
 }
 template <int K, int S> int launch_march_bww_cp(const mc_dwconv_args& p, hipStream_t st) {
-    return march_dispatch<K, S>(p, [&](auto cfg) { return launch_march_bww<K, S, decltype(cfg)>(p, st); });
+    return march_dispatch<K, S>(p, [&](auto cfg) { return launch_march_bww<K, S, decltype(cfg)>(p, st); }, true);
 }
 template <int K, int S> int march_rows(const mc_dwconv_args& p) {
     return march_dispatch<K, S>(p, [&](auto cfg) { return march_plan<decltype(cfg)>(p).gy; }, true);
