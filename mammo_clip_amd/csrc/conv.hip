@@ -1109,7 +1109,7 @@ template <int K, int S, typename F> auto march_dispatch(const mc_dwconv_args& p,
         // of the 2-in-10 column halo; the weight gradient gains 1.2x once it runs three workgroups per CU (0.725 -> 0.597 ms)
         if (p.c == 240 && S == 1 && whole_pixels) return f(MarchCfg<K, S, 4, 60>{});
         // (c = 144, 288-byte pixels: whole-pixel tiles of 36 lanes leave 28 lanes of a wave idle -- 0.85 vs 0.96 ms without the
-        // prologue, 1.18 vs 1.07 ms with it: not used)
+        // prologue, 1.18 vs 1.07 ms with it; 72-channel tiles of 18 lanes: 0.90 / 1.13 ms: not used)
         if (p.c % 48 == 0 && p.c < 192) return f(MarchCfg<K, S, 4, 12>{});      // 48, 144: exact 48-channel tiles
         return f(MarchCfg<K, S, 4, 16>{});
     } else {
