@@ -546,27 +546,27 @@ __global__ __launch_bounds__(256) void se_gate_k(const float* __restrict__ r, co
 }
 
 // ws layout per image: ds[c] | r[cs] | du[cs] ; u is staged in the du slot between the two hidden kernels
-__global__ __launch_bounds__(256) void se_bwd_ds_k(const float* __restrict__ gate, const float* __restrict__ dgate, int c,
-                                                   int cs, float* __restrict__ ws) {
-    const int img = blockIdx.y;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= c) return;
-    float g = gate[(long long)img * c + i];
-    ws[(long long)img * (c + 2 * cs) + i] = dgate[(long long)img * c + i] * g * (1.f - g);
-}
+// (round 4: the elementwise ds = dgate * g * (1 - g) pass is folded in here -- every wave needs the whole ds row of its image
+// for its dot product anyway; the wave of hidden unit 0 stores it for the weight-gradient kernel)
 __global__ __launch_bounds__(256) void se_bwd_hidden_k(const float* __restrict__ pooled, const float* __restrict__ w1,
-                                                       const float* __restrict__ b1, const float* __restrict__ w2, int c,
+                                                       const float* __restrict__ b1, const float* __restrict__ w2,
+                                                       const float* __restrict__ gate, const float* __restrict__ dgate, int c,
                                                        int cs, float* __restrict__ ws) {
     const int img = blockIdx.y, lane = threadIdx.x & 63;
     const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (j >= cs) return;
     const float* pv = pooled + (long long)img * c;
+    const float* gv = gate + (long long)img * c;
+    const float* dgv = dgate + (long long)img * c;
     float* wsi = ws + (long long)img * (c + 2 * cs);
     float s = 0.f, d = 0.f;
 #pragma unroll 4
     for (int i = lane; i < c; i += 64) {
+        const float g = gv[i];
+        const float ds = dgv[i] * g * (1.f - g);
+        if (j == 0) wsi[i] = ds;
         s += w1[(long long)j * c + i] * pv[i];
-        d += w2[(long long)i * cs + j] * wsi[i];
+        d += w2[(long long)i * cs + j] * ds;
     }
     s = wave_sum(s);
     d = wave_sum(d);
@@ -576,14 +576,12 @@ __global__ __launch_bounds__(256) void se_bwd_hidden_k(const float* __restrict__
         wsi[c + cs + j] = d * silu_grad_f(u);
     }
 }
-__global__ __launch_bounds__(256) void se_bwd_dpool_k(const float* __restrict__ w1, int c, int cs,
-                                                      const float* __restrict__ ws, float* __restrict__ dpooled) {
-    extern __shared__ float sh[];
-    const int img = blockIdx.y;
+__device__ __forceinline__ void se_bwd_dpool_body(const float* __restrict__ w1, int c, int cs, const float* __restrict__ ws,
+                                                  float* __restrict__ dpooled, int bx, int img, float* sh) {
     const float* wsi = ws + (long long)img * (c + 2 * cs);
     for (int j = threadIdx.x; j < cs; j += 256) sh[j] = wsi[c + cs + j];
     __syncthreads();
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int i = bx * 256 + threadIdx.x;
     if (i >= c) return;
     float s = 0.f;
     for (int j = 0; j < cs; ++j) s += w1[(long long)j * c + i] * sh[j];
@@ -591,11 +589,20 @@ __global__ __launch_bounds__(256) void se_bwd_dpool_k(const float* __restrict__ 
 }
 
 // weight / bias gradients, reduced over the n images (no atomics)
-__global__ void se_wgrad_k(const float* __restrict__ pooled, const float* __restrict__ ws, int n, int c, int cs,
-                           float* __restrict__ dw1, float* __restrict__ db1, float* __restrict__ dw2,
-                           float* __restrict__ db2) {
+// (round 4: one launch with the d pooled kernel -- both only read what se_bwd_hidden_k left in ws: the first dpool_blocks
+// workgroups are (channel block, image) pairs of the d pooled matvec, the others the weight-gradient elements)
+__global__ __launch_bounds__(256) void se_bwd_tail_k(const float* __restrict__ pooled, const float* __restrict__ w1,
+                                                     const float* __restrict__ ws, int n, int c, int cs, int dpool_blocks,
+                                                     float* __restrict__ dpooled, float* __restrict__ dw1,
+                                                     float* __restrict__ db1, float* __restrict__ dw2, float* __restrict__ db2) {
+    extern __shared__ float sh[];
+    if ((int)blockIdx.x < dpool_blocks) {
+        const int cb = (c + 255) / 256;
+        se_bwd_dpool_body(w1, c, cs, ws, dpooled, blockIdx.x % cb, blockIdx.x / cb, sh);
+        return;
+    }
     const long long stride = c + 2 * cs;
-    long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long e = (long long)(blockIdx.x - dpool_blocks) * blockDim.x + threadIdx.x;
     const long long n1 = (long long)c * cs;
     if (e < n1) {                       // dw2[ci, j] = sum_n ds[n,ci] * r[n,j]
         int ci = (int)(e / cs), j = (int)(e % cs);
@@ -817,14 +824,13 @@ extern "C" int mc_se_bwd(const float* pooled, const float* gate, const float* dg
     MC_CHECK(n > 0 && c > 0 && cs > 0, "se_bwd: bad shape");
     (void)b2;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(se_bwd_ds_k, dim3(mc_div_up(c, 256), n), dim3(256), 0, st, gate, dgate, c, cs, ws);
+    // two launches (round 3: four): [ds + hidden-layer backward] -> [d pooled | weight gradients]
+    hipLaunchKernelGGL(se_bwd_hidden_k, dim3(mc_div_up(cs, 4), n), dim3(256), 0, st, pooled, w1, b1, w2, gate, dgate, c, cs, ws);
     MC_LAUNCH_CHECK();
-    hipLaunchKernelGGL(se_bwd_hidden_k, dim3(mc_div_up(cs, 4), n), dim3(256), 0, st, pooled, w1, b1, w2, c, cs, ws);
-    MC_LAUNCH_CHECK();
-    hipLaunchKernelGGL(se_bwd_dpool_k, dim3(mc_div_up(c, 256), n), dim3(256), cs * sizeof(float), st, w1, c, cs, ws, dpooled);
-    MC_LAUNCH_CHECK();
-    long long total = 2LL * c * cs + c + cs;
-    hipLaunchKernelGGL(se_wgrad_k, dim3(mc_div_up(total, 256)), dim3(256), 0, st, pooled, ws, n, c, cs, dw1, db1, dw2, db2);
+    const long long total = 2LL * c * cs + c + cs;
+    const int dpool_blocks = mc_div_up(c, 256) * n;
+    hipLaunchKernelGGL(se_bwd_tail_k, dim3(dpool_blocks + mc_div_up(total, 256)), dim3(256), cs * sizeof(float), st, pooled, w1, ws, n, c,
+                       cs, dpool_blocks, dpooled, dw1, db1, dw2, db2);
     MC_LAUNCH_CHECK();
     return MC_OK;
 }

@@ -1181,7 +1181,8 @@ bool use_lane_fwd(const mc_dwconv_args& p) {
     // measured (scripts/dwbench.hip, same box): the 5x5 forms win from 57 output columns up (stride 1: 1.15-1.35x with the
     // BatchNorm+SiLU prologue) and for wide stride-2 maps; the 3x3 forms and the 29-column maps stay on the marching kernels
     if (p.k == 5) return p.stride == 1 ? p.ow >= 50 : p.ow >= 100;
-    return p.stride == 2 && !p.epi_x && p.ow >= 50 && p.ow < 100;          // (3x3 stride 2 at 57 columns: 1.36x)
+    // 3x3 at 57 columns: stride 2 forward 1.3x; the stride-1 data gradient with the epilogue 1.05x (scripts/dw_form_ab.py)
+    return p.ow >= 50 && p.ow < 100 && (p.stride == 2 ? !p.epi_x : p.epi_x != nullptr);
 }
 
 bool use_lane_bww(const mc_dwconv_args& p) {
