@@ -1178,20 +1178,28 @@ bool use_lane_fwd(const mc_dwconv_args& p) {
     const int mode = g_lane_mode;
     if (mode == 0 || !mc_dwconv_lane_supported(&p)) return false;
     if (mode == 1) return true;
-    // measured (scripts/dwbench.hip, same box): the 5x5 forms win from 57 output columns up (stride 1: 1.15-1.35x with the
-    // BatchNorm+SiLU prologue) and for wide stride-2 maps; the 3x3 forms and the 29-column maps stay on the marching kernels
-    if (p.k == 5) return p.stride == 1 ? p.ow >= 50 : p.ow >= 100;
-    // 3x3 at 57 columns: stride 2 forward 1.3x; the stride-1 data gradient with the epilogue 1.05x (scripts/dw_form_ab.py)
-    return p.ow >= 50 && p.ow < 100 && (p.stride == 2 ? !p.epi_x : p.epi_x != nullptr);
+    // measured per shape on one box (scripts/dw_form_ab.py, 32 images): the lane form wins for every 5x5 map (114 / 57 columns:
+    // 1.2-1.45x; 29 columns with four images per wave: 1.1x), for the 3x3 forms at 57 columns, and for the 3x3 29-column maps
+    // whose pixels are not a multiple of 128 bytes (c = 1824: the marching kernel's 64-channel tiles are misaligned there;
+    // at c = 3072 the marching form stays ahead).  Narrow maps need enough images to fill the wave's lane groups.
+    const bool narrow = p.ow <= 30;
+    if (p.k == 5) {
+        if (p.stride == 1) return p.ow >= 50 || (p.ow <= 29 && p.n >= 4);
+        return p.ow >= 100 || (narrow && p.n >= 2);
+    }
+    if (p.stride == 2) return !p.epi_x && p.ow >= 50 && p.ow < 100;
+    return (p.ow >= 50 && p.ow < 100) || (narrow && p.n >= 4 && (p.c * 2) % 128 != 0);
 }
 
 bool use_lane_bww(const mc_dwconv_args& p) {
     if (g_lane_mode == -2) { const char* e = getenv("MC_DW_LANE"); g_lane_mode = e ? atoi(e) : -1; }
     if (g_lane_mode == 0 || p.epi_x || !mc_dwconv_lane_supported(&p)) return false;
     if (g_lane_mode == 1) return true;
-    // measured like the forward forms: 5x5 1.16-1.37x from 57 columns (stride 2: wide maps only); 3x3 at 57 columns 1.24-1.36x
-    if (p.k == 5) return p.stride == 1 ? p.ow >= 50 : p.ow >= 100;
-    return p.ow >= 50 && p.ow < 100;
+    // measured like the forward forms (scripts/dw_form_ab.py): 5x5 everywhere (29 columns: two images per wave), 3x3 at 57 and
+    // at 29 columns (1.1-1.3x)
+    const bool narrow = p.ow <= 29;
+    if (p.k == 5) return p.stride == 1 ? (p.ow >= 50 || (narrow && p.n >= 2)) : (p.ow >= 100 || (p.ow <= 30 && p.n >= 2));
+    return (p.ow >= 50 && p.ow < 100) || (p.stride == 1 && p.ow <= 30 && p.n >= 4);
 }
 
 }  // namespace

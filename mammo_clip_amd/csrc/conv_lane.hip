@@ -176,7 +176,7 @@ __global__ __launch_bounds__(1024, 4) void dwconv_lane_fwd_kernel(const mc_dwcon
     enum { G_U0 = 0, G_U1, G_O0, G_O1, G_NR0, G_NB0, G_NBF, G_NFULL, G_NBTOT, G_H, G_W, G_C, G_OH, G_OW, G_PT, G_PL, G_STRIPS, G_C0, G_N, G_WORDS = 24 };
     auto nblk_of = [&](int nrows) { return ((nrows - 1) * S + K + C::RB - 1) / C::RB; };
     if (tid == 0) {
-        const long long vt = (long long)a_n * strips * a_oh;
+        const long long vt = (long long)((a_n + G - 1) / G) * strips * a_oh;      // (image groups, strip, row)
         const long long v0 = vt * yslot / ycp, v1 = vt * (yslot + 1) / ycp;         // [v0, v1) of (image, strip, row)
         const int u0 = (int)(v0 / a_oh), u1 = (int)(v1 / a_oh);
         const int o0 = (int)(v0 - (long long)u0 * a_oh), o1 = (int)(v1 - (long long)u1 * a_oh);
@@ -250,7 +250,11 @@ __global__ __launch_bounds__(1024, 4) void dwconv_lane_fwd_kernel(const mc_dwcon
 #pragma unroll
         for (int i = 0; i < C::NV; ++i) {
             const int row = (int)(meta[i] & 0xfu), seg = (int)((meta[i] >> 4) & 0xfu), col = (int)((meta[i] >> 8) & 0xffu);
+#ifdef LANE_NO_LOAD
+            const bool ok = live && row >= rlo && row < rhi && col >= clo && col < chi && seg < nseg && a_n < 0;
+#else
             const bool ok = live && row >= rlo && row < rhi && col >= clo && col < chi && seg < nseg;
+#endif
             const int goff = seg * in_img_pitch + row * in_row_pitch + col * a_c;
             vals[i] = *reinterpret_cast<const uint4*>(ok ? org + goff : a_x);        // unconditional load, clamped address
             inb |= (ok ? 1u : 0u) << i;
@@ -305,6 +309,9 @@ __global__ __launch_bounds__(1024, 4) void dwconv_lane_fwd_kernel(const mc_dwcon
             if (row >= orlo && row < orhi && col < ochi && seg < nseg) {
                 const uint32_t* sp = src + (metao[i] >> 16);
                 const uint4 val = make_uint4(sp[0], sp[1], sp[2], sp[3]);
+#ifdef LANE_NO_STORE
+                if (a_n < 0)
+#endif
                 *reinterpret_cast<uint4*>(org + (seg * out_img_pitch + row * out_row_pitch + col * a_c)) = val;
             }
         }
@@ -427,7 +434,9 @@ __global__ __launch_bounds__(1024, 4) void dwconv_lane_fwd_kernel(const mc_dwcon
                         for (int i = 0; i < NCOL; ++i) {
                             uint32_t* slot = lout + ((j / S) * C::TOWP + i * 64) * C::PXD;
                             if constexpr (EPI) {
-                                const uint32_t ew = *slot;
+                                // (masked: the slots of columns that do not exist are never staged -- they hold what this lane
+                                // wrote there a block ago, and 0 * NaN must not reach the reductions)
+                                const uint32_t ew = *slot & cm[i];
                                 const f32x2_t e2 = {bf_lo(ew), bf_hi(ew)};
                                 const f32x2_t z = __builtin_elementwise_fma(e2, e_sc, e_sh);
                                 const f32x2_t dz = acc[i][sl] * silu_grad2_f(z);
@@ -520,17 +529,15 @@ template <typename C, int MODE> int launch(const mc_dwconv_args& p, hipStream_t 
 
 // configuration by map width and image count: two output columns per lane wherever the registers allow it (not: stride 2,
 // the 5x5 weight gradient), and as many images per wave (4 / 2 / 1) as fit the map into a lane group
+static int gmax1() { static const int g = [] { const char* e = getenv("MC_DW_LANE_G"); return e ? atoi(e) : 4; }(); return g; }
 template <int K, int S, int MODE, typename F> auto pick(const mc_dwconv_args& p, F&& f) {
     constexpr bool one_col = (S == 2) || (MODE == 2 && K == 5);
     if constexpr (one_col) {
+        if (gmax1() >= 2 && p.n >= 2 && p.ow <= Cfg<K, S, 1, 2>::TOW) return f(Cfg<K, S, 1, 2>{});
         return f(Cfg<K, S, 1, 1>{});
     } else {
-        // EXPERIMENTAL, off by default (MC_DW_LANE_G=2|4 enables it for measurements): several images per wave.  Measured on
-        // MI355X (round 4): with all 64 lanes busy on 57- / 29-column maps the interval time DOUBLES against the one-image
-        // form (c = 1056: 0.39 vs 0.24 ms; c = 1824: 0.37 vs 0.22 ms) although the instruction streams are identical -- the
-        // blocks then carry twice the bytes and the kernel turns out to be bound by per-CU memory throughput (one 32 KB block
-        // in flight per CU), not by VALU issue.  Not used by the product path; not covered by the parity tests.
-        static const int gmax = [] { const char* e = getenv("MC_DW_LANE_G"); return e ? atoi(e) : 1; }();
+        // several images per wave for maps that do not fill 64 lanes x 2 columns (MC_DW_LANE_G=1 switches it off for A/B)
+        static const int gmax = gmax1();
         if (gmax >= 4 && p.n >= 4 && p.ow <= Cfg<K, S, 2, 4>::TOW) return f(Cfg<K, S, 2, 4>{});
         if (gmax >= 2 && p.n >= 2 && p.ow <= Cfg<K, S, 2, 2>::TOW) return f(Cfg<K, S, 2, 2>{});
         if (gmax == 0 && p.ow <= Cfg<K, S, 2, 1>::TOW) return f(Cfg<K, S, 2, 1>{});
