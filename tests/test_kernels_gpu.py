@@ -896,7 +896,8 @@ def test_dwconv_dgrad_with_bn_backward_epilogue(k, n, h, w, c):
 LANE_CASES = [  # k, s, n, h, w, c: several strips per row (w > 124 / 62), several items per workgroup, ragged channel tiles
     (5, 1, 3, 150, 260, 96), (5, 1, 5, 95, 57, 72), (5, 1, 2, 61, 130, 40), (3, 1, 2, 70, 300, 48), (3, 1, 3, 33, 59, 24),
     (5, 2, 2, 120, 250, 48), (3, 2, 3, 77, 131, 40), (5, 1, 33, 48, 29, 32), (5, 1, 1, 300, 114, 64),
-    (5, 1, 70, 1100, 40, 32)]    # > 128 blocks per workgroup: the descriptor ring is refilled (twice)
+    (5, 1, 70, 1100, 40, 32),    # > 128 blocks per workgroup: the descriptor ring is refilled (twice)
+    (5, 1, 5, 6, 5, 40), (3, 1, 9, 7, 9, 24), (5, 2, 3, 9, 11, 16)]   # tiny maps, image groups with a ragged last group
 
 
 @pytest.mark.parametrize("k,s,n,h,w,c", LANE_CASES)
