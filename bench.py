@@ -334,14 +334,19 @@ def main():
     if rank == 0:
         ms = dt / args.steps * 1e3
         pairs = b * world * args.steps / dt
-        tpath = next((q for q in (os.path.join(ROOT, "profiles", f"r{r:02d}_roofline_traffic.json") for r in (4, 3)) if os.path.exists(q)), "")
+        # per-workload PMC tables: rNN_roofline_traffic_cfg4.json (the default run's launch mix) when present, else the cfg3 table
+        cands = ([os.path.join(ROOT, "profiles", f"r{r:02d}_roofline_traffic_{args.workload}.json") for r in (4,)] +
+                 [os.path.join(ROOT, "profiles", f"r{r:02d}_roofline_traffic.json") for r in (4, 3)])
+        tpath = next((q for q in cands if os.path.exists(q)), "")
+        own_mix = tpath.endswith(f"_{args.workload}.json") or args.workload == "cfg3"
         tj = json.load(open(tpath)) if tpath and args.workload in ("cfg3", "cfg4") and not args.batch else {}
         # the PMC bytes were collected on the cfg3 launch mix (32 pairs in one pass): the same 32-pair launches as cfg4's
         # micro-batches, but cfg4 adds the re-forward launches -- its per-class launch MIX differs, so the ratio of `traffic`
         # to `algorithmic_bytes_per_launch` is only meaningful for --workload cfg3
-        tsrc = (f"{os.path.basename(tpath)}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over one cfg3 step, per-launch average "
-                f"of the class's kernels on the cfg3 launch mix" + ("" if args.workload == "cfg3" else
-                "; this run's launch mix differs (micro-batch re-forwards), compare traffic with algorithmic bytes on --workload cfg3 only")) if tj else None
+        tsrc = (f"{os.path.basename(tpath)}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, per-launch average of the class's kernels "
+                + (f"on this workload's own launch mix ({args.workload})" if own_mix else
+                   "on the cfg3 launch mix; this run's launch mix differs (micro-batch re-forwards), compare traffic with "
+                   "algorithmic bytes on --workload cfg3 only")) if tj else None
         timing = "HIP events on the launch stream around every launch of this class inside the timed steps"
 
         def entry(key):

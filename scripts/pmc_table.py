@@ -1,6 +1,6 @@
 """Merge one profile_round3.sh run (gpurun_out/prof_r3/) into profiles/: per-kernel table of GPU-time share, HBM traffic
 (PMC) and MFMA-busy for every kernel of a cfg3 step, plus the per-class traffic JSON bench.py reads for `roofline.traffic`.
-usage: python scripts/pmc_table.py [gpurun_out/prof_r3] [profiles] [r03]"""
+usage: python scripts/pmc_table.py [gpurun_out/prof_r3] [profiles] [r03] [cfg3|cfg4]"""
 import csv
 import json
 import os
@@ -10,6 +10,7 @@ import sys
 src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof_r3"
 dst = sys.argv[2] if len(sys.argv) > 2 else "profiles"
 tag = sys.argv[3] if len(sys.argv) > 3 else "r03"
+wl = sys.argv[4] if len(sys.argv) > 4 else "cfg3"          # workload whose passes are merged (cfg3 | cfg4)
 
 
 def short(name):
@@ -18,11 +19,11 @@ def short(name):
     return re.sub(r"\((mc_|float|unsigned|int|long|void|\(anonymous).*$", "", name).strip()
 
 
-stats = list(csv.DictReader(open(os.path.join(src, "cfg3_kernel_stats.csv"))))
+stats = list(csv.DictReader(open(os.path.join(src, f"{wl}_kernel_stats.csv"))))
 tot = sum(float(r["TotalDurationNs"]) for r in stats)
 pmc = {}
 for grp in ("FETCH_SIZE", "WRITE_SIZE", "SQ_VALU_MFMA_BUSY_CYCLES"):
-    p = os.path.join(src, f"cfg3_pmc_{grp}.csv")
+    p = os.path.join(src, f"{wl}_pmc_{grp}.csv")
     if os.path.exists(p):
         for r in csv.DictReader(open(p)):
             pmc.setdefault(r["kernel"], {})[r["counter"]] = float(r["avg"])
@@ -36,8 +37,8 @@ for r in stats:
     busy = c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (128 * c["GRBM_GUI_ACTIVE"]) if c.get("GRBM_GUI_ACTIVE") else 0.0
     rows.append((short(k), 100 * float(r["TotalDurationNs"]) / tot, int(r["Calls"]), avg_us, rd, wr, (rd + wr) / avg_us if avg_us else 0, busy))
 os.makedirs(dst, exist_ok=True)
-with open(os.path.join(dst, f"{tag}_cfg3_pmc_by_kernel.csv"), "w") as f:
-    f.write(f'"# one cfg3 step (+1 survey step) of bench.py: rocprofv3 --kernel-trace --stats, and three separate --pmc passes (FETCH_SIZE | WRITE_SIZE | '
+with open(os.path.join(dst, f"{tag}_{wl}_pmc_by_kernel.csv"), "w") as f:
+    f.write(f'"# one {wl} step (+1 survey step) of bench.py: rocprofv3 --kernel-trace --stats, and three separate --pmc passes (FETCH_SIZE | WRITE_SIZE | '
             f'SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES), scripts/profile_round3.sh all; {tag} state"\n')
     f.write('"# hbm_read_MB = 2 x FETCH_SIZE KiB x 1024 (gfx950 counts 128-B requests of wide streaming reads as 64 B, MI355X_MICROARCH.md); '
             'hbm_write_MB = WRITE_SIZE KiB x 1024 (as reported); per launch averages"\n')
@@ -70,10 +71,10 @@ for key, kn in cls.items():
     n = sum(r[2] for r in sel)
     if n:
         traffic[key] = int(sum((r[4] + r[5]) * 1e6 * r[2] for r in sel) / n)
-traffic["_note"] = ("HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, rocprofv3 --pmc, separate passes) averaged over the launches of one cfg3 step; "
-                    "source: " + f"profiles/{tag}_cfg3_pmc_by_kernel.csv")
-json.dump(traffic, open(os.path.join(dst, f"{tag}_roofline_traffic.json"), "w"), indent=1)
+traffic["_note"] = ("HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, rocprofv3 --pmc, separate passes) averaged over the launches of one " + wl + " step; "
+                    "source: " + f"profiles/{tag}_{wl}_pmc_by_kernel.csv")
+json.dump(traffic, open(os.path.join(dst, f"{tag}_roofline_traffic.json" if wl == "cfg3" else f"{tag}_roofline_traffic_{wl}.json"), "w"), indent=1)
 for f_ in ("cfg3_kernel_stats.csv", "cfg4_kernel_stats.csv", "agent_info.csv"):
     if os.path.exists(os.path.join(src, f_)):
         open(os.path.join(dst, f"{tag}_{f_}"), "w").write(open(os.path.join(src, f_)).read())
-print(open(os.path.join(dst, f"{tag}_cfg3_pmc_by_kernel.csv")).read()[:6000])
+print(open(os.path.join(dst, f"{tag}_{wl}_pmc_by_kernel.csv")).read()[:6000])

@@ -36,6 +36,32 @@ with open(sys.argv[2], 'w') as f:
 PY
   done
 fi
+if [ "$MODE" = "pmc4" ]; then
+  # HBM traffic of the DEFAULT run's launch mix (cfg4: 32 micro-batches, re-forwards): FETCH_SIZE / WRITE_SIZE passes.
+  # NOT part of `all`: with ~300 000 dispatches per run a counter pass does not finish in 20 minutes (tried in round 4: both
+  # passes hit their timeouts) -- bench.py labels the cfg3-mix traffic instead (`roofline.traffic_source`)
+  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_c4 -- $C4 > $OUT/c4.log 2>&1
+  cp $(ls /tmp/p_c4/*/*kernel_stats.csv | head -1) $OUT/cfg4_kernel_stats.csv
+  i=0
+  for grp in "FETCH_SIZE" "WRITE_SIZE"; do
+    i=$((i+1))
+    timeout 1200 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d /tmp/p4_pmc$i -- $C4 > $OUT/pmc4_$i.log 2>&1
+    f=$(ls /tmp/p4_pmc$i/*/*counter_collection.csv 2>/dev/null | head -1)
+    [ -z "$f" ] && { echo "pass $i produced no counters"; tail -3 $OUT/pmc4_$i.log; continue; }
+    python - "$f" "$OUT/cfg4_pmc_$grp.csv" <<'PY'
+import csv, sys, collections
+agg = collections.OrderedDict()
+for r in csv.DictReader(open(sys.argv[1])):
+    k = (r['Kernel_Name'], r['Counter_Name'])
+    a = agg.setdefault(k, [0, 0.0])
+    a[0] += 1; a[1] += float(r['Counter_Value'])
+with open(sys.argv[2], 'w') as f:
+    w = csv.writer(f); w.writerow(['kernel', 'counter', 'launches', 'sum', 'avg'])
+    for (k, c), (n, s) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        w.writerow([k, c, n, s, s / n])
+PY
+  done
+fi
 if [ "$MODE" = "dw" ] || [ "$MODE" = "all" ]; then
   # SQ counters of the depthwise kernels (one launch per shape and kernel, scripts/pmc_dw.py): VALU activity, resident waves,
   # wait classes -- the evidence behind "VALU-issue bound" (marching 5x5) vs "four waves per SIMD" (lane = column form)
