@@ -372,7 +372,7 @@ def main():
             "metric": "image-text pairs/s (whole node), EN-B5+BioClinicalBERT contrastive pre-training step",
             "value": round(pairs, 3), "unit": "image-text pairs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "strong" if strong else "weak",
-            "vs_baseline": None, "dtype": "bf16" + (" + fp8 e4m3 pointwise-conv operands" if fp8 else ""), "data": "synthetic",
+            "vs_baseline": None, "dtype": os.environ.get("MC_STORAGE", "bf16").lower() + (" + fp8 e4m3 pointwise-conv operands" if fp8 else ""), "data": "synthetic",
             "config": {"workload": f"{args.workload}: {arch_name} + BioClinicalBERT(BERT-base), {b} pairs/GPU "
                                    f"(2 views + 2 reports each), {H}x{W} images, {T}-token reports, breast_clip loss, "
                                    f"AdamW; fwd+loss+bwd+optimizer; dropout/drop-connect on",

@@ -13,6 +13,10 @@
  *   - plain pointers and sizes only; all pointers are DEVICE pointers unless stated otherwise
  *   - bf16 tensors are raw uint16 bit patterns; activations are row-major [rows, channels] (NHWC),
  *     channels % 8 == 0, base pointers 16-byte aligned
+ *   - the 16-bit storage / MFMA operand type is a property of the library BUILD: libmammoclip_hip.so holds bf16
+ *     (default), libmammoclip_hip_f16.so (compiled from the same sources with -DMC_F16) holds IEEE f16 -- the
+ *     reference's AMP dtype [ref: trainer.py:271-278] -- behind the SAME symbols: wherever this header says "bf16" /
+ *     mc_bf16, the f16 build reads and writes f16 bit patterns.  mc_storage_is_f16() tells which one a process loaded.
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream); calls are asynchronous
  *   - return 0 on success, non-zero on error; mc_last_error() gives the message (thread-local)
  *   - no hidden allocation: workspaces / partial buffers are caller-provided
@@ -28,6 +32,7 @@ typedef uint16_t mc_bf16;
 
 const char* mc_last_error(void);
 int mc_version(void);
+int mc_storage_is_f16(void);   /* 0: bf16 build, 1: f16 build (see Conventions) */
 
 /* ------------------------------------------------------------------------------------------------
  * bf16 MFMA GEMM:  C[M,N] (+)= alpha * op(A)[M,K] . op(B)[K,N] + bias[N]  -> act -> + R
@@ -449,6 +454,11 @@ typedef struct {
 } mc_adamw_tensor;
 int mc_adamw_step(const mc_adamw_tensor* tensors, int n_tensors, double lr, double beta1, double beta2, double eps,
                   double weight_decay, long long step, void* stream);
+/* Loss-scaled step of the f16 storage build [ref: trainer.py:271-278: the reference's backward runs under
+ * torch.cuda.amp.GradScaler; scaler.step() unscales the gradients and skips the update when one of them is inf / nan]:
+ * grad[i] *= inv_scale in place for every tensor of the list (only .grad and .numel are read), *found_inf (a device
+ * float, zeroed by the caller) is set to 1 if any unscaled value is not finite. */
+int mc_grads_unscale(const mc_adamw_tensor* tensors, int n_tensors, float inv_scale, float* found_inf, void* stream);
 
 #ifdef __cplusplus
 }

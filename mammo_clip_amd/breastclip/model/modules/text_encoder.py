@@ -66,14 +66,14 @@ class _LayerFn(torch.autograd.Function):
         ver = tuple(p_._version for p_ in (sq.weight, sk.weight, sv.weight, sq.bias, sk.bias, sv.bias)) + (sq.weight.data_ptr(), bool(lyr.hilo))
         cache = getattr(lyr, "_qkv_cache", None)
         if cache is None or cache[0] != ver or cache[1].device != x.device:
-            wqkv = torch.empty((3 * H, H), dtype=torch.bfloat16, device=x.device)
+            wqkv = torch.empty((3 * H, H), dtype=ops.BF16, device=x.device)
             ops.cast_bf16(sq.weight, out=wqkv[:H])
             ops.cast_bf16(sk.weight, out=wqkv[H:2 * H])
             ops.cast_bf16(sv.weight, out=wqkv[2 * H:])
             bqkv = torch.cat([sq.bias.detach(), sk.bias.detach(), sv.bias.detach()]).float().contiguous()
             wlo = None
             if lyr.hilo:                                   # low terms of the two-term bf16 split (set_hilo_weights)
-                wlo = torch.empty((3 * H, H), dtype=torch.bfloat16, device=x.device)
+                wlo = torch.empty((3 * H, H), dtype=ops.BF16, device=x.device)
                 ops.cast_bf16_lo(sq.weight, out=wlo[:H])
                 ops.cast_bf16_lo(sk.weight, out=wlo[H:2 * H])
                 ops.cast_bf16_lo(sv.weight, out=wlo[2 * H:])
@@ -102,7 +102,7 @@ class _LayerFn(torch.autograd.Function):
                      alpha=hd ** -0.5)
             probs, pd = ops.softmax_fwd(scores, pa, seed, sid)
             del scores
-            ctxv = torch.empty((M, H), dtype=torch.bfloat16, device=x.device)
+            ctxv = torch.empty((M, H), dtype=ops.BF16, device=x.device)
             ops.gemm(pd, qkv[:, 2 * H:], ctxv, t, hd, t, t, 3 * H, H, b_kmajor=1, batch=b * nh, nb2=nh,
                      sA=(nh * t * t, t * t), sB=(t * 3 * H, hd), sC=(t * H, hd))
         wo = ops.cast_bf16(att.output.dense.weight)
@@ -161,7 +161,7 @@ class _LayerFn(torch.autograd.Function):
             dpd = torch.empty((b, nh, t, t), dtype=torch.float32, device=x.device)
             ops.gemm(dctx, qkv[:, 2 * H:], dpd, t, t, hd, H, 3 * H, t, c_f32=1, batch=b * nh, nb2=nh,
                      sA=(t * H, hd), sB=(t * 3 * H, hd), sC=(nh * t * t, t * t))
-            dqkv = torch.empty((b * t, 3 * H), dtype=torch.bfloat16, device=x.device)
+            dqkv = torch.empty((b * t, 3 * H), dtype=ops.BF16, device=x.device)
             ops.gemm(pd, dctx, dqkv[:, 2 * H:], t, hd, t, t, H, 3 * H, a_kmajor=1, b_kmajor=1, batch=b * nh, nb2=nh,
                      sA=(nh * t * t, t * t), sB=(t * H, hd), sC=(t * 3 * H, hd))                       # dV = Pd^T dO
             ds = ops.softmax_bwd(probs, dpd, pa, seed, sid, hd ** -0.5)
@@ -175,7 +175,7 @@ class _LayerFn(torch.autograd.Function):
         dbqkv = ops.colsum(dqkv)
         tc = getattr(lyr, "_qkv_t_cache", None)                      # [in, 3*out] = wqkv^T, rebuilt only when a weight changed
         if tc is None or tc[0] != sv["qkv_ver"] or tc[1].device != x.device:
-            wqkv_t = torch.empty((H, 3 * H), dtype=torch.bfloat16, device=x.device)
+            wqkv_t = torch.empty((H, 3 * H), dtype=ops.BF16, device=x.device)
             for i, m_ in enumerate((att.self.query, att.self.key, att.self.value)):
                 wqkv_t[:, i * H:(i + 1) * H].copy_(ops.cast_transpose_bf16(m_.weight))
             lyr._qkv_t_cache = tc = (sv["qkv_ver"], wqkv_t)

@@ -103,7 +103,7 @@ __global__ __launch_bounds__(512) void attn_fwd_k(attn_args a) {
                     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int ks = 0; ks < 2; ++ks)
-                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(perm_frag(Ks, 32 * J + 4 * tt, ks, lane), qf[ks], acc, 0, 0, 0);
+                        acc = MC_MFMA_16x16x32(perm_frag(Ks, 32 * J + 4 * tt, ks, lane), qf[ks], acc, 0, 0, 0);
                     const float4 bv = *reinterpret_cast<const float4*>(mb + 32 * J + g * 8 + 4 * tt);
                     s[J][tt * 4 + 0] = acc[0] * a.alpha + bv.x;
                     s[J][tt * 4 + 1] = acc[1] * a.alpha + bv.y;
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(512) void attn_fwd_k(attn_args a) {
                 const bf16x8_t pf = as_frag(v);
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt)
-                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(Vs, 32 * J, dt * 16, lane), pf, o[dt], 0, 0, 0);
+                    o[dt] = MC_MFMA_16x16x32(tr_frag(Vs, 32 * J, dt * 16, lane), pf, o[dt], 0, 0, 0);
             }
         }
         bf16_t* const dst = a.ctx + ((long long)bi * t + q) * H + h * HD + g * 4;
@@ -198,8 +198,8 @@ __global__ __launch_bounds__(512) void attn_bwd_k(attn_args a) {
                     f32x4_t acc = {0.f, 0.f, 0.f, 0.f}, dacc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int ks = 0; ks < 2; ++ks) {
-                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(perm_frag(Ks, 32 * J + 4 * tt, ks, lane), qf[ks], acc, 0, 0, 0);
-                        dacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(perm_frag(Vs, 32 * J + 4 * tt, ks, lane), dof[ks], dacc, 0, 0, 0);
+                        acc = MC_MFMA_16x16x32(perm_frag(Ks, 32 * J + 4 * tt, ks, lane), qf[ks], acc, 0, 0, 0);
+                        dacc = MC_MFMA_16x16x32(perm_frag(Vs, 32 * J + 4 * tt, ks, lane), dof[ks], dacc, 0, 0, 0);
                     }
                     const float4 bv = *reinterpret_cast<const float4*>(mb + 32 * J + g * 8 + 4 * tt);
                     const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(512) void attn_bwd_k(attn_args a) {
                 const bf16x8_t dsf = as_frag(dsv);
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt)
-                    dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(Ks, 32 * J, dt * 16, lane), dsf, dq[dt], 0, 0, 0);
+                    dq[dt] = MC_MFMA_16x16x32(tr_frag(Ks, 32 * J, dt * 16, lane), dsf, dq[dt], 0, 0, 0);
             }
         }
         bf16_t* const dst = gbase + (long long)q * ld + g * 4;
@@ -285,8 +285,8 @@ __global__ __launch_bounds__(512) void attn_bwd_k(attn_args a) {
                 f32x4_t acc = {0.f, 0.f, 0.f, 0.f}, dacc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qr[ks], kfr[kt][ks], acc, 0, 0, 0);
-                    dacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dor[ks], vfr[kt][ks], dacc, 0, 0, 0);
+                    acc = MC_MFMA_16x16x32(qr[ks], kfr[kt][ks], acc, 0, 0, 0);
+                    dacc = MC_MFMA_16x16x32(dor[ks], vfr[kt][ks], dacc, 0, 0, 0);
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { sv[kt][tt * 4 + r] = acc[r]; dp[kt][tt * 4 + r] = dacc[r]; }
@@ -327,8 +327,8 @@ __global__ __launch_bounds__(512) void attn_bwd_k(attn_args a) {
             const bf16x8_t dot_f = tr_frag(Vs, 32 * I, dt * 16, lane);
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt) {
-                dk[kt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt, dsf[kt], dk[kt][dt], 0, 0, 0);
-                dv[kt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dot_f, pdf[kt], dv[kt][dt], 0, 0, 0);
+                dk[kt][dt] = MC_MFMA_16x16x32(qt, dsf[kt], dk[kt][dt], 0, 0, 0);
+                dv[kt][dt] = MC_MFMA_16x16x32(dot_f, pdf[kt], dv[kt][dt], 0, 0, 0);
             }
         }
     }

@@ -5,8 +5,19 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// The 16-bit storage / MFMA operand type is a property of the BUILD: bf16 (default: libmammoclip_hip.so) or IEEE f16
+// (-DMC_F16: libmammoclip_hip_f16.so, the reference's AMP dtype [ref: trainer.py:271-278] -- 10 mantissa bits, same MFMA
+// rate; the configuration in which |dloss| <= 1e-3 holds in train mode).  Kernels never look inside a
+// 16-bit value except through the helpers below (bf2f / bf_lo / bf_hi / pack_bf2) and MC_MFMA_16x16x32, so both builds
+// come from the same sources; names keep the "bf" of the default build.
 typedef unsigned short bf16_t;
+#ifdef MC_F16
+typedef __attribute__((ext_vector_type(8))) _Float16 bf16x8_t;
+#define MC_MFMA_16x16x32(a, b, c, x, y, z) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, x, y, z)
+#else
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+#define MC_MFMA_16x16x32(a, b, c, x, y, z) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, x, y, z)
+#endif
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
 #define MC_OK 0
@@ -32,14 +43,21 @@ extern "C" void mc_set_error(const char* msg);   // api_util.hip
         }                                                     \
     } while (0)
 
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+#ifdef MC_F16
+typedef __attribute__((ext_vector_type(2))) _Float16 bf16x2_t;
+__device__ __forceinline__ float bf2f(bf16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
+__device__ __forceinline__ float bf_lo(uint32_t w) { return (float)__builtin_bit_cast(bf16x2_t, w).x; }
+__device__ __forceinline__ float bf_hi(uint32_t w) { return (float)__builtin_bit_cast(bf16x2_t, w).y; }
+#else
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
 __device__ __forceinline__ float bf_lo(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
-
-// fp32 -> bf16, round-to-nearest-even (same rounding as torch's float -> bfloat16): gfx950 has a packed hardware
-// convert (v_cvt_pk_bf16_f32) -- one instruction per two elements instead of ~6 integer ops per element.
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
-typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+#endif
+
+// fp32 -> 16 bit, round-to-nearest-even (same rounding as torch's float -> bfloat16 / float16): gfx950 has a packed
+// hardware convert (v_cvt_pk_bf16_f32) -- one instruction per two elements instead of ~6 integer ops per element.
 __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
     f32x2_t f = {lo, hi};
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, bf16x2_t));

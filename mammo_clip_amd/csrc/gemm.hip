@@ -341,7 +341,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 && !GL) ? 4 : 2) vo
             for (int i = 0; i < FM; ++i)
 #pragma unroll
                 for (int j = 0; j < FN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = MC_MFMA_16x16x32(bfr[j], af[i], acc[i][j], 0, 0, 0);
         }
     };
     // acc[i][j][r]: row m = wm*WM + i*16 + (lane & 15), col n = wn*WN + j*16 + (lane >> 4)*4 + r
@@ -592,7 +592,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, (WGM * WGN == 8 && !GL) ? 4 : 2) vo
                 for (int a = 0; a < FM; ++a)
 #pragma unroll
                     for (int b = 0; b < FN; ++b)
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[kk][b], af[kk][a], acc[a][b], 0, 0, 0);
+                        acc[a][b] = MC_MFMA_16x16x32(bfr[kk][b], af[kk][a], acc[a][b], 0, 0, 0);
             GPROF(3);
             const bool last_k = ck0 + BK >= kend;
             if (last_k) { ebuf = buf; epilogue(cm0); drain = true; }

@@ -203,7 +203,7 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256_tn_kernel(const mc_gemm_args 
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
                     acc[ih * 4 + i][jh * 2 + j] =
-                        __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j][kk], af[i][kk], acc[ih * 4 + i][jh * 2 + j], 0, 0, 0);
+                        MC_MFMA_16x16x32(bf[j][kk], af[i][kk], acc[ih * 4 + i][jh * 2 + j], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
     };
 

@@ -236,7 +236,7 @@ __global__ __launch_bounds__(256, 2) void gemm_rows_kernel(const mc_gemm_rows_ar
                     bf16x8_t wf = *reinterpret_cast<const bf16x8_t*>(sW + ((size_t)(kc * FN + f) * 64 + lane) * 16);
 #pragma unroll
                     for (int rg = 0; rg < RG; ++rg)
-                        acc[rg][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        acc[rg][f] = MC_MFMA_16x16x32(
                             wf, *reinterpret_cast<const bf16x8_t*>(&xf[rg][kc]), acc[rg][f], 0, 0, 0);
                 }
             }

@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_rows_kernel(const mc_wgrad_rows_
 #pragma unroll
             for (int i = 0; i < AF; ++i)
 #pragma unroll
-                for (int j = 0; j < BF; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < BF; ++j) acc[i][j] = MC_MFMA_16x16x32(a[i], b[j], acc[i][j], 0, 0, 0);
         }
         if (p.pro_gate && s + gridDim.x < nsteps && tid * 4 < p.K)      // next step's gate row -> the other LDS slot
             *reinterpret_cast<float4*>(sgate + (par ^ 1) * p.K + tid * 4) = greg;

@@ -102,7 +102,70 @@ __global__ void __launch_bounds__(256) adamw_multi_k(AdamPack pk, int count, Ada
     }
 }
 
+// ---- gradient unscale + non-finite check of the loss-scaled (f16 storage) step [ref: trainer.py:271-278 runs the backward
+// under torch.cuda.amp.GradScaler: scaler.step() = unscale the gradients, skip the update if any is inf / nan].
+// Same packing as the update kernel: a workgroup owns one CHUNK of one gradient tensor.
+struct UnscalePack {
+    float* g[PACK];
+    int first_chunk[PACK + 1];
+    long long n[PACK];
+};
+
+__global__ void __launch_bounds__(256) grads_unscale_k(UnscalePack pk, int count, float inv_scale, float* __restrict__ found_inf) {
+    int t = 0;
+    const int blk = blockIdx.x;
+    while (t + 1 < count && pk.first_chunk[t + 1] <= blk) ++t;
+    const long long base = (long long)(blk - pk.first_chunk[t]) * CHUNK;
+    float* __restrict__ g = pk.g[t] + base;
+    const long long left = pk.n[t] - base;
+    const int len = left < CHUNK ? (int)left : CHUNK;
+    bool bad = false;
+    int i = threadIdx.x * 4;
+    if ((((uintptr_t)g) & 15) == 0) {
+        for (; i + 3 < len; i += 1024) {
+            float4 v = *(const float4*)(g + i);
+            v.x *= inv_scale; v.y *= inv_scale; v.z *= inv_scale; v.w *= inv_scale;
+            bad |= !(fabsf(v.x) <= 3.4e38f) || !(fabsf(v.y) <= 3.4e38f) || !(fabsf(v.z) <= 3.4e38f) || !(fabsf(v.w) <= 3.4e38f);
+            *(float4*)(g + i) = v;
+        }
+        const int j = (len & ~3) + threadIdx.x;
+        if (j < len) { const float v = g[j] * inv_scale; bad |= !(fabsf(v) <= 3.4e38f); g[j] = v; }
+    } else {
+        for (int j = threadIdx.x; j < len; j += 256) { const float v = g[j] * inv_scale; bad |= !(fabsf(v) <= 3.4e38f); g[j] = v; }
+    }
+    if (bad) *found_inf = 1.0f;          // (every writer stores the same value)
+}
+
 }  // namespace
+
+extern "C" int mc_grads_unscale(const mc_adamw_tensor* tensors, int n_tensors, float inv_scale, float* found_inf, void* stream) {
+    MC_CHECK(n_tensors >= 0 && (tensors || n_tensors == 0) && found_inf, "grads_unscale: bad arguments");
+    UnscalePack pk;
+    int cnt = 0, chunks = 0;
+    auto flush = [&]() -> int {
+        if (cnt == 0) return MC_OK;
+        pk.first_chunk[cnt] = chunks;
+        hipLaunchKernelGGL(grads_unscale_k, dim3(chunks), dim3(256), 0, (hipStream_t)stream, pk, cnt, inv_scale, found_inf);
+        MC_LAUNCH_CHECK();
+        cnt = 0; chunks = 0;
+        return MC_OK;
+    };
+    for (int i = 0; i < n_tensors; ++i) {
+        const mc_adamw_tensor& t = tensors[i];
+        if (t.numel == 0) continue;
+        MC_CHECK(t.grad && t.numel > 0, "grads_unscale: null gradient pointer");
+        const long long nch = (t.numel + CHUNK - 1) / CHUNK;
+        MC_CHECK(nch < (1ll << 30), "grads_unscale: tensor too large");
+        if (cnt == PACK || (long long)chunks + nch > (1ll << 30)) {
+            int r = flush();
+            if (r != MC_OK) return r;
+        }
+        pk.g[cnt] = const_cast<float*>(t.grad); pk.n[cnt] = t.numel; pk.first_chunk[cnt] = chunks;
+        chunks += (int)nch;
+        ++cnt;
+    }
+    return flush();
+}
 
 extern "C" int mc_adamw_step(const mc_adamw_tensor* tensors, int n_tensors, double lr, double beta1, double beta2,
                              double eps, double weight_decay, long long step, void* stream) {

@@ -10,6 +10,11 @@ extern "C" void mc_set_error(const char* msg) {
 }
 extern "C" const char* mc_last_error(void) { return g_err; }
 extern "C" int mc_version(void) { return 100; }
+#ifdef MC_F16
+extern "C" int mc_storage_is_f16(void) { return 1; }
+#else
+extern "C" int mc_storage_is_f16(void) { return 0; }
+#endif
 
 namespace {
 

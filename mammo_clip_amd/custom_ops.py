@@ -172,7 +172,7 @@ def softmax(scores: Tensor) -> Tensor:
 
 @softmax.register_fake
 def _(scores):
-    return scores.new_empty(scores.shape, dtype=torch.bfloat16)
+    return scores.new_empty(scores.shape, dtype=ops.BF16)
 
 
 @_op("l2norm")

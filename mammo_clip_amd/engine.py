@@ -16,6 +16,7 @@ from typing import Dict, List, Optional
 import torch
 import torch.distributed as dist
 
+from . import lib as L
 from . import ops
 from .breastclip.model.modules import efficientnet_custom as _encmod
 
@@ -109,11 +110,67 @@ class GradBuckets:
         self.pending = []
 
 
+class LossScaler:
+    """Dynamic loss scale of the f16 storage build: the policy of ``torch.cuda.amp.GradScaler`` with its default constants
+    (init 65536, x 0.5 on a non-finite gradient with the optimizer step skipped, x 2 after 2000 clean steps in a row), which
+    is what the reference trains under [ref: trainer.py:271-278, trainer_ddp.py:296-303].  f16 keeps 10 mantissa bits but
+    only 5 exponent bits: at 32 x 1520 x 912 the activation gradients of the early stages are ~1e-8 and flush to zero
+    without a scale (measured: gradient cosine -0.22 against the scaled run on _blocks.2._bn2.bias).  The unscale + check
+    is one multi-tensor HIP launch per 40 tensors (``mc_grads_unscale``); reading the flag is the step's one host sync."""
+
+    def __init__(self, init_scale=65536.0, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000, dynamic=True):
+        self.scale, self.growth_factor, self.backoff_factor = float(init_scale), float(growth_factor), float(backoff_factor)
+        self.growth_interval, self.dynamic = int(growth_interval), bool(dynamic)
+        self._good, self._flag = 0, None
+        self.skipped = 0
+
+    def unscale_(self, params) -> bool:
+        """grad *= 1 / scale for every parameter gradient; True if all of them are finite"""
+        ps = [p for p in params if p.grad is not None]
+        if not ps:
+            return True
+        if self._flag is None or self._flag.device != ps[0].device:
+            self._flag = torch.zeros(1, dtype=torch.float32, device=ps[0].device)
+        else:
+            self._flag.zero_()
+        arr = (L.AdamwTensor * len(ps))()
+        keep = []
+        for a, p in zip(arr, ps):
+            g = p.grad
+            if not g.is_contiguous() or g.dtype != torch.float32:
+                raise L.MammoClipHipError("LossScaler: parameter gradients must be dense contiguous fp32 tensors")
+            keep.append(g)
+            a.grad, a.numel = g.data_ptr(), g.numel()
+        L.call("mc_grads_unscale", arr, len(ps), 1.0 / self.scale, self._flag.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        return float(self._flag.item()) == 0.0
+
+    def update(self, finite: bool):
+        if not finite:
+            self.skipped += 1
+        if not self.dynamic:
+            return
+        if not finite:
+            self.scale *= self.backoff_factor
+            self._good = 0
+        else:
+            self._good += 1
+            if self._good >= self.growth_interval:
+                self.scale *= self.growth_factor
+                self._good = 0
+
+
 class Trainer:
     def __init__(self, model, loss_func, optimizer, scheduler=None, device=None, bucket_mb: int = 256,
                  overlap_micro: bool = False, keep_graphs: int = 1, grad_sink: bool = True, keep_recompute: Optional[int] = None,
-                 stat_tapes: bool = True):
+                 stat_tapes: bool = True, loss_scale="auto"):
         self.model, self.loss_func, self.optimizer, self.scheduler = model, loss_func, optimizer, scheduler
+        # loss scaling: "auto" = a dynamic LossScaler in the f16 storage build (the reference's GradScaler), none in the
+        # bf16 build (fp32's exponent range); a number = that static scale; a LossScaler = yours; None = off
+        if loss_scale == "auto":
+            loss_scale = LossScaler() if L.STORAGE == "f16" else None
+        elif isinstance(loss_scale, (int, float)):
+            loss_scale = LossScaler(init_scale=float(loss_scale), dynamic=False) if float(loss_scale) != 1.0 else None
+        self.scaler = loss_scale
         self.device = device
         # Gradient reduction: by default the flat buckets are all-reduced AFTER the last backward (reduce_all) -- the whole
         # exchange is 552 MB per step against >= 1.2 s of backward at 128 pairs per GPU, there is nothing worth hiding, and
@@ -164,12 +221,27 @@ class Trainer:
             self.buckets.enabled = not self.grad_sink
         outputs = self.model(batch, self.device)
         loss_dict = self.loss_func(**outputs, is_train=True)
-        self._backward(lambda: loss_dict["total"].backward())
+        self._backward(lambda: self._seed(loss_dict["total"]).backward())
         self._grads_done(hooked=not self.grad_sink)
-        self.optimizer.step()
+        self._optimizer_step()
         if self.scheduler is not None:
             self.scheduler.step()
         return {k: v.detach() for k, v in loss_dict.items()}
+
+    def _seed(self, total):
+        """the tensor the step's backward starts from: the loss, times the loss scale when one is in use"""
+        return total if self.scaler is None else total * self.scaler.scale
+
+    def _optimizer_step(self):
+        """optimizer update; under a loss scale: unscale the (already rank-averaged) gradients first and skip the update
+        if any of them is non-finite, like GradScaler.step() [ref: trainer_ddp.py:300-303]"""
+        if self.scaler is None:
+            self.optimizer.step()
+            return
+        finite = self.scaler.unscale_(self.model.parameters())
+        if finite:
+            self.optimizer.step()
+        self.scaler.update(finite)
 
     def _backward(self, run):
         """one backward call; with the gradient sink the hand-written functions deliver their parameter gradients to it"""
@@ -286,7 +358,7 @@ def _step_micro(self, batch: Dict, k: int) -> Dict[str, torch.Tensor]:
     if self.buckets is not None and self.overlap_micro and not parts:
         self.buckets.enabled = True            # every micro-batch kept: this is the only backward
     loss_dict = self.loss_func(**outputs, is_train=True)
-    self._backward(lambda: loss_dict["total"].backward())   # d loss / d embeddings of the re-run micro-batches, full backward of the kept ones
+    self._backward(lambda: self._seed(loss_dict["total"]).backward())   # d loss / d embeddings of the re-run micro-batches, full backward of the kept ones
     del out, lives, full, outputs
     bns = [m for m in model.modules() if hasattr(m, "track_update")]
     for m in bns:
@@ -315,7 +387,7 @@ def _step_micro(self, batch: Dict, k: int) -> Dict[str, torch.Tensor]:
             m.track_update = True
         irng.calls, trng._calls = after
     self._grads_done(hooked=self.overlap_micro)
-    self.optimizer.step()
+    self._optimizer_step()
     if self.scheduler is not None:
         self.scheduler.step()
     return {kk: v.detach() for kk, v in loss_dict.items()}

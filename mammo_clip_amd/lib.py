@@ -7,7 +7,13 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libmammoclip_hip.so")
+# 16-bit storage / MFMA operand type of the process: "bf16" (default) or "f16" (MC_STORAGE=f16, the reference's AMP dtype
+# [ref: trainer.py:271-278]).  It is a property of the BUILD of the kernel library (csrc/common_hip.h, -DMC_F16): both
+# libraries export the same C ABI, the process loads exactly one of them and ops.BF16 names the matching torch dtype.
+STORAGE = os.environ.get("MC_STORAGE", "bf16").lower()
+if STORAGE not in ("bf16", "f16"):
+    raise ValueError(f"MC_STORAGE must be 'bf16' or 'f16', got {STORAGE!r}")
+LIB_PATH = os.path.join(_HERE, "lib", "libmammoclip_hip.so" if STORAGE == "bf16" else "libmammoclip_hip_f16.so")
 
 P, LL, I, F, D, U, ULL = C.c_void_p, C.c_longlong, C.c_int, C.c_float, C.c_double, C.c_uint, C.c_ulonglong
 
@@ -88,7 +94,9 @@ class AdamwTensor(C.Structure):
 
 _SIGS = {
     "mc_version": ([], I),
+    "mc_storage_is_f16": ([], I),
     "mc_adamw_step": ([C.POINTER(AdamwTensor), I, D, D, D, D, D, LL, P], I),
+    "mc_grads_unscale": ([C.POINTER(AdamwTensor), I, F, P, P], I),
     "mc_gemm_bf16": ([C.POINTER(GemmArgs), P], I),
     "mc_gemm_stat_rows": ([C.POINTER(GemmArgs)], I),
     "mc_gemm_tile_config": ([C.POINTER(GemmArgs)], I),
@@ -193,6 +201,8 @@ def load():
         fn = getattr(lib, name)
         fn.argtypes = args
         fn.restype = res
+    if bool(lib.mc_storage_is_f16()) != (STORAGE == "f16"):
+        raise MammoClipHipError(f"{LIB_PATH} is not the {STORAGE} build of the kernel library")
     _lib = lib
     return lib
 

@@ -13,7 +13,7 @@ import torch
 
 from . import lib as L
 
-BF16 = torch.bfloat16
+BF16 = torch.bfloat16 if L.STORAGE == "bf16" else torch.float16     # the 16-bit storage dtype of this process (lib.STORAGE)
 
 
 def _p(t):

@@ -1,0 +1,101 @@
+"""Worker of tests/test_f16_storage_gpu.py: runs in a process of its own with MC_STORAGE=f16 (the storage type is fixed when
+the kernel library is loaded) and prints ONE JSON line.  usage: python tests/_f16_worker.py bn8k | scaler"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+import test_fullsize_gpu as T                       # noqa: E402  (model / batch helpers, fixtures)
+from mammo_clip_amd import engine, lib as L, ops    # noqa: E402
+from mammo_clip_amd.breastclip import util          # noqa: E402
+from mammo_clip_amd.breastclip.optimizer import build_optimizer   # noqa: E402
+from oracle import weights as ow                    # noqa: E402
+
+assert L.STORAGE == "f16" and ops.BF16 == torch.float16 and L.load().mc_storage_is_f16() == 1
+
+
+def bn8k():
+    """reference fixture e2e_b2_bn8k (B2 + BERT-base, b = 8, 456^2, T = 64, stochastic ops off): eval and TRAIN loss,
+    embeddings, and -- through a loss-scaled backward -- the stored parameter gradients"""
+    z = np.load(os.path.join(T.GOLDEN, "e2e_b2_bn8k.npz"))
+    b, H, W, Tn = [int(v) for v in z["meta"]]
+    model, lossf, sd, arch = T._build("tf_efficientnetv2-detect", "efficientnet-b2")
+    bt = T._to_dev(ow.synth_batch(b, H, W, Tn, seed=10))
+    util.GlobalEnv.reset()
+    rep = {}
+    model.eval()
+    with torch.no_grad():
+        out = model(bt, T.DEV)
+        rep["eval_dloss"] = float(lossf(**out, is_train=False)["total"]) - float(z["eval/total"])
+    rep["eval_min_cos"] = min(T._cos_rows(out[k], z["eval/" + k]) for k in T.EMB)
+    model.train()
+    out = model(bt, T.DEV)
+    loss = lossf(**out, is_train=True)["total"]
+    rep["train_dloss"] = float(loss) - float(z["train/total"])
+    rep["train_min_cos"] = min(T._cos_rows(out[k], z["train/" + k]) for k in T.EMB)
+    scale = 4096.0
+    (loss * scale).backward()
+    named = dict(model.named_parameters())
+    cs, nr = {}, {}
+    for key in z.files:
+        if not key.startswith("train/grad/"):
+            continue
+        n = key[len("train/grad/"):]
+        g = named[n].grad.float() / scale
+        ref = torch.as_tensor(z[key]).to(g.device)
+        cs[n] = T._cos_flat(g, ref)
+        nr[n] = float(g.norm() / (ref.norm() + 1e-30))
+    rep["grad_min_cos"], rep["grad_min_cos_at"] = min(cs.values()), min(cs, key=cs.get)
+    rep["grad_norm_ratio_min"], rep["grad_norm_ratio_max"] = min(nr.values()), max(nr.values())
+    rep["n_grads"] = len(cs)
+    rep["nonfinite_grads"] = sum(int(not torch.isfinite(p.grad).all()) for p in model.parameters() if p.grad is not None)
+    return rep
+
+
+def scaler():
+    """Trainer under the dynamic loss scale: a clean step updates the parameters and leaves UNSCALED finite gradients; a step
+    whose scale overflows f16 is skipped (parameters and optimizer state untouched) and halves the scale"""
+    model, lossf, sd, arch = T._build("tf_efficientnetv2-detect", "efficientnet-b2")
+    bt = T._to_dev(ow.synth_batch(4, 224, 224, 64, seed=10))
+    util.GlobalEnv.reset()
+    opt = build_optimizer(model, {"name": "adamw", "config": {"lr": 1e-4, "weight_decay": 1e-4}})
+    tr = engine.Trainer(model, lossf, opt, None, T.DEV)
+    rep = {"auto_scaler": type(tr.scaler).__name__, "init_scale": tr.scaler.scale}
+    tr.scaler = engine.LossScaler(init_scale=1024.0)
+    w0 = {n: p.detach().clone() for n, p in model.named_parameters()}
+    out = tr.step(bt)
+    rep["clean_loss"] = float(out["total"])
+    rep["clean_skipped"] = tr.scaler.skipped
+    rep["clean_changed"] = sum(int(not torch.equal(w0[n], p)) for n, p in model.named_parameters() if p.grad is not None)
+    rep["clean_grads_finite"] = all(bool(torch.isfinite(p.grad).all()) for p in model.parameters() if p.grad is not None)
+    # unscaled: the same step without a scaler on a fresh model gives the same gradient (to f16 underflow of the unscaled run)
+    g_scaled = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+    model2, lossf2, _, _ = T._build("tf_efficientnetv2-detect", "efficientnet-b2")
+    util.GlobalEnv.reset()
+    tr2 = engine.Trainer(model2, lossf2, torch.optim.SGD(model2.parameters(), lr=0.0), None, T.DEV, loss_scale=None)
+    tr2.step(bt)
+    # (one cosine over ALL gradients: parameters whose exact gradient is zero -- a bias in front of a BatchNorm -- hold
+    # round-off only, their own cosine means nothing)
+    names = [n for n, p in model2.named_parameters() if p.grad is not None and n in g_scaled]
+    a = torch.cat([g_scaled[n].reshape(-1).double() for n in names])
+    b_ = torch.cat([dict(model2.named_parameters())[n].grad.reshape(-1).double() for n in names])
+    rep["scaled_vs_unscaled_cos"] = float((a @ b_) / (a.norm() * b_.norm()))
+    # overflow: 2^40 x gradients of O(1e-2) do not fit f16
+    tr.scaler = engine.LossScaler(init_scale=2.0 ** 40)
+    w1 = {n: p.detach().clone() for n, p in model.named_parameters()}
+    steps1 = dict(enumerate(opt._plans[0]["steps"]))
+    tr.step(bt)
+    rep["overflow_skipped"] = tr.scaler.skipped
+    rep["overflow_scale_after"] = tr.scaler.scale
+    rep["overflow_params_unchanged"] = all(torch.equal(w1[n], p) for n, p in model.named_parameters())
+    rep["overflow_steps_unchanged"] = dict(enumerate(opt._plans[0]["steps"])) == steps1
+    return rep
+
+
+if __name__ == "__main__":
+    print("F16-WORKER " + json.dumps({"bn8k": bn8k, "scaler": scaler}[sys.argv[1]]()))

@@ -47,6 +47,23 @@ def test_library_exports_every_header_symbol():
     assert isinstance(lib.mc_last_error(), bytes)
 
 
+def test_f16_build_exports_the_same_abi():
+    """the f16 storage build (libmammoclip_hip_f16.so, -DMC_F16) exports every header symbol too and says which build it is;
+    lib.py picks the library by MC_STORAGE and refuses a mismatch"""
+    header = open(os.path.join(ROOT, "include", "mammoclip_hip.h")).read()
+    declared = set(re.findall(r"\b(?:int|const char\*)\s+(mc_[a-z0-9_]+)\s*\(", header))
+    path = os.path.join(os.path.dirname(L.LIB_PATH), "libmammoclip_hip_f16.so")
+    assert os.path.exists(path), "build() makes both storage variants"
+    f16 = ctypes.CDLL(path)
+    missing = [n for n in sorted(declared) if not hasattr(f16, n)]
+    assert not missing, missing
+    assert f16.mc_storage_is_f16() == 1 and L.load().mc_storage_is_f16() == 0
+    assert L.STORAGE == "bf16" and L.LIB_PATH.endswith("libmammoclip_hip.so")
+    out = subprocess.run([sys.executable, "-c", "import mammo_clip_amd.lib as L, mammo_clip_amd.ops as o; L.load(); print(L.STORAGE, o.BF16, L.load().mc_storage_is_f16())"],
+                         cwd=ROOT, env=dict(os.environ, MC_STORAGE="f16"), capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.split()[-3:] == ["f16", "torch.float16", "1"], (out.stdout, out.stderr[-500:])
+
+
 def test_abi_argument_validation_without_gpu():
     """argument checks run before any launch: bad calls return a non-zero status and set mc_last_error()"""
     lib = L.load()

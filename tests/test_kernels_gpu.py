@@ -22,7 +22,7 @@ from mammo_clip_amd import ops  # noqa: E402
 import mammo_clip_amd.lib as L  # noqa: E402
 
 DEV = torch.device("cuda:0")
-BF = torch.bfloat16
+BF = ops.BF16               # the 16-bit storage dtype of the loaded kernel library (bf16; f16 under MC_STORAGE=f16)
 
 
 def rnd(*shape, seed=0, scale=1.0, dtype=BF):

@@ -20,6 +20,7 @@ if not torch.cuda.is_available():
     pytest.skip("needs a HIP device", allow_module_level=True)
 
 import mammo_clip_amd  # noqa: E402,F401
+from mammo_clip_amd import ops  # noqa: E402
 from mammo_clip_amd.breastclip.loss import build_loss  # noqa: E402
 from mammo_clip_amd.breastclip.loss._infonce import InfoNCEFn  # noqa: E402
 from mammo_clip_amd.breastclip.model import build_model  # noqa: E402
@@ -29,7 +30,7 @@ from mammo_clip_amd.breastclip import util  # noqa: E402
 from oracle import arch as oarch, bert as obert, weights as ow  # noqa: E402
 
 DEV = torch.device("cuda:0")
-BF = torch.bfloat16
+BF = ops.BF16               # the 16-bit storage dtype of the loaded kernel library (bf16; f16 under MC_STORAGE=f16)
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
