@@ -97,5 +97,29 @@ def scaler():
     return rep
 
 
+def shapes():
+    """BASELINE per-sample shapes against the fp32 oracle run on the same weights and batch: cfg3 / cfg4 (B5, 1520 x 912,
+    T = 256, 2 pairs) and cfg2 (B2, 912 x 912, T = 256, 4 pairs), eval and train mode (stochastic ops off)"""
+    rep = {}
+    for tag, enc, arch_name, b, H, W, Tn in (("cfg3", "tf_efficientnet_b5_ns-detect", "efficientnet-b5", 2, 1520, 912, 256),
+                                             ("cfg2", "tf_efficientnetv2-detect", "efficientnet-b2", 4, 912, 912, 256)):
+        model, lossf, sd, arch = T._build(enc, arch_name)
+        bt = T._to_dev(ow.synth_batch(b, H, W, Tn, seed=10))
+        util.GlobalEnv.reset()
+        for mode in ("eval", "train"):
+            train = mode == "train"
+            model.train(train)
+            model.load_state_dict(sd, strict=True)
+            with torch.set_grad_enabled(False):
+                out = model(bt, T.DEV)
+                lh = float(lossf(**out, is_train=train)["total"])
+            lo, eo, _ = T._oracle(sd, bt, arch, b, train, grad_keys=("logit_scale",))
+            rep[f"{tag}/{mode}_dloss"] = lh - lo
+            rep[f"{tag}/{mode}_min_cos"] = min(T._cos_rows(out[k], eo[k]) for k in T.EMB)
+        del model
+        torch.cuda.empty_cache()
+    return rep
+
+
 if __name__ == "__main__":
-    print("F16-WORKER " + json.dumps({"bn8k": bn8k, "scaler": scaler}[sys.argv[1]]()))
+    print("F16-WORKER " + json.dumps({"bn8k": bn8k, "scaler": scaler, "shapes": shapes}[sys.argv[1]]()))

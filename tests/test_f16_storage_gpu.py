@@ -74,3 +74,14 @@ def test_f16_trainer_dynamic_loss_scale():
     assert r["scaled_vs_unscaled_cos"] >= 0.999, r
     assert r["overflow_skipped"] == 1 and r["overflow_scale_after"] == 2.0 ** 39, r
     assert r["overflow_params_unchanged"] and r["overflow_steps_unchanged"], r
+
+
+def test_f16_baseline_shapes_train_and_eval_within_1e3_of_the_oracle():
+    """north_star's bound at the BASELINE per-sample shapes, BOTH modes.  Measured on MI355X (f16 | bf16 storage):
+    cfg3 / cfg4 shape (B5, 1520 x 912, T = 256) eval 3e-5 | 4.4e-4, train 2.0e-4 | 3.2e-3; cfg2 shape (B2, 912^2) eval
+    5e-5 | 1.8e-4, train 2.5e-4 | 3.4e-4."""
+    r = _worker("shapes", timeout=900)
+    print("f16 shapes", r)
+    for tag in ("cfg3", "cfg2"):
+        assert abs(r[tag + "/eval_dloss"]) <= 1e-3 and abs(r[tag + "/train_dloss"]) <= 1e-3, r
+        assert r[tag + "/eval_min_cos"] >= 0.99999 and r[tag + "/train_min_cos"] >= 0.9999, r
