@@ -165,10 +165,6 @@ def _conv_stats(fn, training, *a, **kw):
 # (ops.bn_fold_expand_bwd) instead of running the apply pass; tests set it to 0 to exercise the folded path at small sizes
 FUSE_PROJ_DGRAD = os.environ.get("MC_FUSE_PROJ_DGRAD", "1") != "0"        # projection data gradient with the SE / BatchNorm1 backward in its epilogue (ops.proj_dgrad_*)
 BN_FOLD_MIN_BYTES = int(os.environ.get("MC_BN_FOLD_MIN_BYTES", 400_000_000))
-# f16 storage build: never folded, whatever the thresholds say -- the folded 16-bit operands B.We ~ 1e-8 and Sxx = x^T x ~
-# rows * var ~ 1e6 leave f16's exponent range (measured: NaN expand-weight gradients of B5 blocks 3-13 at 32 x 1520 x 912,
-# and already at 4 x 193 x 129); the apply pass takes the fold's place
-BN_FOLD_ALLOWED = ops.BF16 == torch.bfloat16
 BN_FOLD_S2_MIN_BYTES = int(os.environ.get("MC_BN_FOLD_S2_MIN_BYTES", 0))
 
 
@@ -362,7 +358,7 @@ class _MBConvFn(torch.autograd.Function):
             dz0, part0 = ops.dwconv_bwd_data(dd, sv["wkkc"], n, h, w, a.cexp, k, s, l, t, oh, ow, w_kkc_flipped=wflip,
                                              epi=(e, st0))
             del dd
-            if BN_FOLD_ALLOWED and 2 * n * hw * a.cexp >= (BN_FOLD_MIN_BYTES if s == 1 else max(BN_FOLD_MIN_BYTES, BN_FOLD_S2_MIN_BYTES)):
+            if 2 * n * hw * a.cexp >= (BN_FOLD_MIN_BYTES if s == 1 else max(BN_FOLD_MIN_BYTES, BN_FOLD_S2_MIN_BYTES)):
                 # bn0 backward is linear in (dZ0, e) and e = x We^T: it is folded into the operands of the expand conv's
                 # two gradient GEMMs (ops.bn_fold_expand_bwd) -- de is never formed, e is not read again.  Three passes
                 # over the expanded tensor against ~10 small launches and 6 passes over the (6x smaller) block input:

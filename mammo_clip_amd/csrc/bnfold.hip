@@ -13,6 +13,15 @@
 namespace {
 
 // w1t[j][i] = bf16(We[i][j] * A[i]);  wb[i][j] = bf16(We[i][j] * B[i]);  sxx[i][j] = bf16(xtx[i][j] - cs[i] cs[j] / rows)
+// f16 storage build (MC_F16): B ~ 1e-8 and Sxx ~ rows * var ~ 1e6 lie outside f16's exponent range, so the two operands
+// carry the factor `rows` the other way round -- wb = f16(We * B * rows), sxx = f16(Sxx / rows): their product (B.We) Sxx
+// is unchanged, and G' = We^T wb = rows * G is undone by alpha = 1 / rows of the x G' GEMM (ops.bn_fold_expand_bwd) and
+// by fold_cvec_k below.
+#ifdef MC_F16
+#define MC_FOLD_ROWS(rows) (rows)
+#else
+#define MC_FOLD_ROWS(rows) 1.0
+#endif
 __global__ void fold_prepare_k(const float* __restrict__ we, const float* __restrict__ coef, const float* __restrict__ xtx,
                                const float* __restrict__ cs, double rows, int n, int k, bf16_t* __restrict__ w1t,
                                bf16_t* __restrict__ wb, bf16_t* __restrict__ sxx) {
@@ -22,11 +31,11 @@ __global__ void fold_prepare_k(const float* __restrict__ we, const float* __rest
             const int i = (int)(idx / k), j = (int)(idx % k);
             const float w = we[idx];
             w1t[(long long)j * n + i] = f2bf(w * coef[i]);
-            wb[idx] = f2bf(w * coef[n + i]);
+            wb[idx] = f2bf((float)((double)(w * coef[n + i]) * MC_FOLD_ROWS(rows)));
         } else {
             const long long r = idx - nk;
             const int i = (int)(r / k), j = (int)(r % k);
-            sxx[r] = f2bf((float)((double)xtx[r] - (double)cs[i] * (double)cs[j] / rows));
+            sxx[r] = f2bf((float)(((double)xtx[r] - (double)cs[i] * (double)cs[j] / rows) / MC_FOLD_ROWS(rows)));
         }
     }
 }
@@ -46,7 +55,7 @@ __global__ __launch_bounds__(256) void fold_cvec_k(const float* __restrict__ gt,
     for (int i = threadIdx.x; i < k; i += 256) {
         const bf16_t g = f2bf(gt[(long long)j * k + i]);
         gtb[(long long)j * k + i] = g;
-        acc += (double)cs[i] * (double)bf2f(g);
+        acc += (double)cs[i] * (double)bf2f(g) / MC_FOLD_ROWS(rows);      // (f16 build: gt holds rows * G)
     }
     __shared__ double red[256];
     red[threadIdx.x] = acc;

@@ -757,7 +757,14 @@ def bn_fold_expand_bwd(dz, x, we_f32, we_bf16, coef, dbeta, rows, residual=None)
     gt = linear_wgrad(we_bf16, wb, tag="_gt")              # (We^T (B.We))^T  [cin, cin] fp32
     gtb, cvec = empty((k, k), BF16, x), empty((k,), torch.float32, x)
     L.call("mc_bn_fold_cvec", _p(gt), _p(we_f32), _p(coef), _p(dbeta), _p(cs), float(rows), n, k, _p(gtb), _p(cvec), _st())
-    r = linear_fwd(x, gtb, bias=cvec, residual=residual, tag="_fold")   # x G + cvec (+ skip gradient)
+    if BF16 == torch.bfloat16:
+        r = linear_fwd(x, gtb, bias=cvec, residual=residual, tag="_fold")   # x G + cvec (+ skip gradient)
+    else:
+        # f16 storage build: gtb holds rows * G (bnfold.hip keeps the folded operands inside f16's exponent range), the
+        # factor goes back in through the tile GEMM's alpha
+        r = empty((x.shape[0], k), BF16, x)
+        gemm(x, gtb, r, x.shape[0], k, k, x.stride(0), k, k, bias=cvec, R=residual,
+             ldr=(residual.stride(0) if residual is not None else 0), alpha=1.0 / float(rows), kind="fwd_fold")
     dx = linear_dgrad(dz, we_bf16, residual=r, w_t=w1t)    # + dz (A.We)
     wx = empty((n, k), torch.float32, x)
     gemm(wb, sxx, wx, n, k, k, k, k, k, c_f32=1, kind="fold")      # (B.We) Sxx  (Sxx symmetric)
