@@ -166,6 +166,8 @@ class Trainer:
         self.model, self.loss_func, self.optimizer, self.scheduler = model, loss_func, optimizer, scheduler
         # loss scaling: "auto" = a dynamic LossScaler in the f16 storage build (the reference's GradScaler), none in the
         # bf16 build (fp32's exponent range); a number = that static scale; a LossScaler = yours; None = off
+        if loss_scale == "auto" and os.environ.get("MC_LOSS_SCALE"):
+            loss_scale = float(os.environ["MC_LOSS_SCALE"])          # a static scale for every "auto" Trainer of the process
         if loss_scale == "auto":
             loss_scale = LossScaler() if L.STORAGE == "f16" else None
         elif isinstance(loss_scale, (int, float)):

@@ -18,8 +18,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 
 
-def _run(args, timeout):
-    env = dict(os.environ, MC_STORAGE="f16")
+def _run(args, timeout, **extra_env):
+    env = dict(os.environ, MC_STORAGE="f16", **extra_env)
     p = subprocess.run([sys.executable] + args, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
     return p
 
@@ -85,3 +85,15 @@ def test_f16_baseline_shapes_train_and_eval_within_1e3_of_the_oracle():
     for tag in ("cfg3", "cfg2"):
         assert abs(r[tag + "/eval_dloss"]) <= 1e-3 and abs(r[tag + "/train_dloss"]) <= 1e-3, r
         assert r[tag + "/eval_min_cos"] >= 0.99999 and r[tag + "/train_min_cos"] >= 0.9999, r
+
+
+def test_f16_trainer_level_tests_under_a_static_loss_scale():
+    """the Trainer-level tests on the f16 build, every ``Trainer(loss_scale="auto")`` pinned to a static scale of 256 by
+    MC_LOSS_SCALE (single steps are compared there; a dynamic scale that starts at 65536 skips its first steps on these small
+    configurations, as GradScaler does): the two-rank steps over gloo on a shared GPU (gradients are unscaled AFTER the
+    rank average, bit-identical on both ranks), the 4-step trajectory against the reference's own loop, the recompute
+    modes, the evaluator / checkpoint entry points"""
+    p = _run(["-m", "pytest", os.path.join(HERE, "test_dist_gpu.py"), os.path.join(HERE, "test_model_gpu.py"), "-m", "gpu", "-x", "-q",
+              "-k", "two_rank or trajectory or recompute or evaluator"], 1500, MC_LOSS_SCALE="256")
+    assert p.returncode == 0, p.stdout[-3000:]
+    assert " passed" in p.stdout and "failed" not in p.stdout, p.stdout[-1000:]
