@@ -201,7 +201,12 @@ def main():
     ap.add_argument("--no-n8-load", action="store_true", help="skip the n8_load block of the default N = 1 run")
     ap.add_argument("--fp8", action="store_true", help="fp8 (e4m3) operands for the late-stage 1x1 convolutions (config #5 arithmetic on any workload)")
     ap.add_argument("--op-profile", action="store_true", help="print a per-entry-point HIP-event breakdown (rank 0)")
+    ap.add_argument("--storage", default=None, choices=("bf16", "f16"),
+                    help="16-bit storage / MFMA operand build of the kernel library (default: MC_STORAGE or bf16 -- BASELINE's dtype; "
+                         "f16 = the reference's AMP dtype with a dynamic loss scale, the parity configuration of DESIGN.md (c))")
     args = ap.parse_args()
+    if args.storage:
+        os.environ["MC_STORAGE"] = args.storage        # read when the package is imported (below; the spawned ranks inherit it)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # plain `python bench.py --gpus N`: spawn the N ranks ourselves (one process per GPU, RCCL) and relay rank 0's line
