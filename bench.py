@@ -232,6 +232,16 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the HIP path is the only path (no CPU fallback)")
     L.load()
+    # evidence that the collectives ran on RCCL with N ranks: RCCL's own INIT log goes to a per-process file
+    # (NCCL_DEBUG_FILE), rank 0 reads its communicator line ("... nranks N ...") back after the first collective
+    rccl_log = None
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and os.environ.get("MC_DIST_BACKEND", "nccl") == "nccl":
+        import tempfile
+        rccl_log = os.path.join(tempfile.gettempdir(), f"mc_rccl_{os.getpid()}.log")
+        os.environ.setdefault("NCCL_DEBUG", "INFO")
+        os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT")
+        os.environ.setdefault("NCCL_DEBUG_FILE", rccl_log)
+        rccl_log = os.environ["NCCL_DEBUG_FILE"]
     rank, local, world, device = engine.init_distributed()
     assert world == args.gpus or (world == 1 and args.gpus == 1), f"launched with WORLD_SIZE={world} but --gpus {args.gpus}"
     enc_name, arch_name, b, H, W, T = WORKLOADS[args.workload]
@@ -280,6 +290,22 @@ def main():
         if world > 1:
             dist.barrier()
             torch.cuda.synchronize()
+
+    dist_info = None
+    if world > 1:
+        ones = torch.ones(1, device=device)
+        dist.all_reduce(ones)                      # SUM of one per rank over the job's backend: = the ranks that took part
+        dist_info = {"backend": dist.get_backend(), "allreduce_of_ones": int(ones.item()), "rccl_ranks": None}
+        if rccl_log and rank == 0:
+            import glob
+            import re
+            for fn in glob.glob(rccl_log.replace("%h", "*").replace("%p", "*")):
+                try:
+                    m = re.findall(r"nranks (\d+)", open(fn, errors="replace").read())
+                except OSError:
+                    m = []
+                if m:
+                    dist_info["rccl_ranks"] = max(int(v) for v in m)
 
     # warm-up; the LAST warm-up step (an extra step when --warmup 0) is the survey step: HIP events around every C-ABI
     # launch -> GPU time per kernel class -> the three classes the timed steps bracket
@@ -340,8 +366,8 @@ def main():
         ms = dt / args.steps * 1e3
         pairs = b * world * args.steps / dt
         # per-workload PMC tables: rNN_roofline_traffic_cfg4.json (the default run's launch mix) when present, else the cfg3 table
-        cands = ([os.path.join(ROOT, "profiles", f"r{r:02d}_roofline_traffic_{args.workload}.json") for r in (4,)] +
-                 [os.path.join(ROOT, "profiles", f"r{r:02d}_roofline_traffic.json") for r in (4, 3)])
+        cands = ([os.path.join(ROOT, "profiles", f"r{r:02d}_roofline_traffic_{args.workload}.json") for r in (5, 4)] +
+                 [os.path.join(ROOT, "profiles", f"r{r:02d}_roofline_traffic.json") for r in (5, 4, 3)])
         tpath = next((q for q in cands if os.path.exists(q)), "")
         own_mix = tpath.endswith(f"_{args.workload}.json") or args.workload == "cfg3"
         tj = json.load(open(tpath)) if tpath and args.workload in ("cfg3", "cfg4") and not args.batch else {}
@@ -366,7 +392,7 @@ def main():
             tkey = key[:-5] if key.endswith("|mfma") else (key[:-4] if key.endswith("|hbm") else key)
             return {"bound": "mfma" if mfma else "hbm", "achieved": round(ach, 1), "peak": peak, "unit": unit,
                     "frac": round(ach / peak, 4), "traffic": tj.get(key, tj.get(tkey)), "traffic_source": tsrc if tj.get(key, tj.get(tkey)) is not None else None,
-                    "kernel": kernel_name(key), "launches": cnt,
+                    "kernel": kernel_name(key), "class": tkey, "launches": cnt, "launches_per_step": cnt // max(args.steps, 1),
                     "avg_launch_us": round(t_ms / max(cnt, 1) * 1e3, 1), "algorithmic_bytes_per_launch": int(by / max(cnt, 1)),
                     "algorithmic_flops_per_launch": int(fl / max(cnt, 1)), "gpu_ms_in_timed_steps": round(t_ms, 1),
                     "share_of_gpu_time_in_survey_step": round(ssum[key][1] / max(sum(v[1] for v in ssum.values()), 1e-9), 4),
@@ -389,6 +415,9 @@ def main():
         }
         if n8 is not None:
             res["n8_load"] = n8
+        if dist_info is not None:
+            res["rccl_ranks"] = dist_info["rccl_ranks"]
+            res["dist"] = dist_info
         if world == 1 and not args.no_cpu_baseline:
             try:
                 res["cpu_baseline"] = cpu_baseline(arch_name, H, W, T)

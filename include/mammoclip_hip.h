@@ -251,6 +251,12 @@ typedef struct mc_dwconv_args {
     const float* epi_shift;
     const float* epi_mean;
     const float* epi_invstd;
+    /* round 5 -- fused backward of a stride-1 depthwise conv (mc_dwconv_bwd_fused): weight gradient f32 [k*k][c] (+=) */
+    float* dw_out;
+    /* rows the caller allocated in stat_partials (what mc_dwconv_stat_rows / mc_dwconv_bwd_*_stat_rows returned for THIS
+     * argument block); 0 = not checked.  A launch whose kernel form would write a different number of rows is refused --
+     * the form can change between the two calls through mc_dwconv_set_lane_mode / MC_DW_LANE. */
+    int stat_rows;
 } mc_dwconv_args;
 int mc_dwconv_stat_rows(const mc_dwconv_args* args);
 int mc_dwconv_bwd_data_stat_rows(const mc_dwconv_args* args);
@@ -459,6 +465,20 @@ int mc_adamw_step(const mc_adamw_tensor* tensors, int n_tensors, double lr, doub
  * grad[i] *= inv_scale in place for every tensor of the list (only .grad and .numel are read), *found_inf (a device
  * float, zeroed by the caller) is set to 1 if any unscaled value is not finite. */
 int mc_grads_unscale(const mc_adamw_tensor* tensors, int n_tensors, float inv_scale, float* found_inf, void* stream);
+/* The same step with NO host synchronisation (round 5): the dynamic scale, the non-finite flag and the skip decision stay on
+ * the device, like torch's own GradScaler keeps them [ref: trainer_ddp.py:296-303 scaler.scale / step / update].
+ *   state = float[8] on the device: {scale, clean steps in a row, found_inf of the step in flight, steps skipped, outcome of
+ *           the last step (1 = skipped), -, -, -}
+ *   mc_grads_unscale_dev : grad *= 1 / *scale_dev, sets *found_inf (= &state[2]) on a non-finite value
+ *   mc_adamw_step_ls     : mc_adamw_step that does nothing when *found_inf != 0 and takes its bias corrections from the number
+ *                          of APPLIED steps, step - *skipped (skipped = the optimizer's own device counter)
+ *   mc_loss_scale_update : GradScaler.update(): consumes and clears the flag; scale *= backoff on a bad step, *= growth after
+ *                          growth_interval clean ones (dynamic != 0); counts the skip in state[3] and in *opt_skipped */
+int mc_grads_unscale_dev(const mc_adamw_tensor* tensors, int n_tensors, const float* scale_dev, float* found_inf, void* stream);
+int mc_adamw_step_ls(const mc_adamw_tensor* tensors, int n_tensors, double lr, double beta1, double beta2, double eps,
+                     double weight_decay, long long step, const float* found_inf, const float* skipped, void* stream);
+int mc_loss_scale_update(float* state, float* opt_skipped, float growth_factor, float backoff_factor, int growth_interval,
+                         int dynamic, void* stream);
 
 #ifdef __cplusplus
 }

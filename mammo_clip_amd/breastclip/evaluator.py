@@ -37,7 +37,8 @@ class Evaluator:
         m = self.model
         emb = m.encode_text(_tokens.to_device(text_token, self.device))
         emb = m.text_projection(emb) if m.projection else emb
-        return (emb / torch.norm(emb, dim=1, keepdim=True)).float().cpu().numpy()
+        from .. import ops
+        return ops.l2norm_fwd(emb.float().contiguous())[0].cpu().numpy()      # the HIP normalise kernel, like encode_image
 
     @staticmethod
     def zeroshot_scores(image_embeddings, text_embeddings) -> np.ndarray:

@@ -27,17 +27,24 @@ class AdamW(torch.optim.Optimizer):
     # and writes them back only when the state is looked at (state_dict) -- 700 tiny CPU tensor updates per step are
     # host time the small configurations cannot hide.
     def _sync_steps(self):
+        # loss-scaled steps (step_loss_scaled): the host counts ATTEMPTED steps, the device counts the skipped ones
+        skipped = int(self._ls_skipped.item()) if getattr(self, "_ls_skipped", None) is not None else 0
         for plan in self._plans.values():
             for p, t in zip(plan["params"], plan["steps"]):
-                self.state[p]["step"].fill_(float(t))
+                self.state[p]["step"].fill_(float(max(t - skipped, 0)))
+
+    def _fold_skipped(self):
+        """make the host counts the APPLIED counts and clear the device counter of skipped steps (before plans are rebuilt
+        from ``state[p]["step"]``: a rebuilt plan must not subtract the same skips again)"""
+        self._sync_steps()
+        if getattr(self, "_ls_skipped", None) is not None:
+            for plan in self._plans.values():
+                plan["steps"][:] = [int(self.state[p]["step"]) for p in plan["params"]]
+            self._ls_skipped.zero_()
 
     def state_dict(self):
         self._sync_steps()
         return super().state_dict()
-
-    def load_state_dict(self, state_dict):
-        super().load_state_dict(state_dict)
-        self._plans = {}
 
     def _plan(self, gi, group):
         params = [p for p in group["params"] if p.grad is not None]
@@ -49,7 +56,7 @@ class AdamW(torch.optim.Optimizer):
                    and self.state[p]["exp_avg_sq"].data_ptr() == ptrs[2] for p, ptrs in zip(params, plan["ptrs"])):
                 return plan
         if plan is not None:
-            self._sync_steps()
+            self._fold_skipped()
         steps = []
         arr = (L.AdamwTensor * max(len(params), 1))()
         for i, p in enumerate(params):
@@ -68,6 +75,29 @@ class AdamW(torch.optim.Optimizer):
         plan = {"params": params, "steps": steps, "arr": arr, "gen": -1, "images": {}, "keep": [], "ptrs": ptrs}
         self._plans[gi] = plan
         return plan
+
+    @torch.no_grad()
+    def step_loss_scaled(self, scaler):
+        """``step()`` under an ``engine.LossScaler`` without a host sync: the kernel reads the scaler's non-finite flag and
+        does nothing on a bad step (GradScaler.step() would not call optimizer.step()); its bias corrections use the
+        number of APPLIED steps = attempted steps (counted on the host) - skipped steps (counted on the device, in a tensor
+        this optimizer owns: it survives a change of scaler).  Returns that counter for ``scaler.update``."""
+        dev = self.param_groups[0]["params"][0].device
+        if getattr(self, "_ls_skipped", None) is None or self._ls_skipped.device != dev:
+            self._fold_skipped()                           # (a counter on another device: fold it into the host counts)
+            self._ls_skipped = torch.zeros(1, dtype=torch.float32, device=dev)
+        st = scaler.state(dev)
+        self._ls = (st.data_ptr() + 4 * scaler._FLAG, self._ls_skipped.data_ptr())
+        try:
+            self.step()
+        finally:
+            self._ls = None
+        return self._ls_skipped
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._plans = {}
+        self._ls_skipped = None
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -98,13 +128,15 @@ class AdamW(torch.optim.Optimizer):
             b1, b2 = group["betas"]
             stream = torch.cuda.current_stream().cuda_stream
             hyper = (float(group["lr"]), float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]))
+            ls = getattr(self, "_ls", None)
+            entry, tail = ("mc_adamw_step_ls", (ls[0], ls[1], stream)) if ls else ("mc_adamw_step", (stream,))
             if min(steps) == max(steps):
-                L.call("mc_adamw_step", arr, len(params), *hyper, steps[0], stream)
+                L.call(entry, arr, len(params), *hyper, steps[0], *tail)
             else:                                             # parameters that joined later: one launch set per step count
                 for t in sorted(set(steps)):
                     idx = [i for i, s_ in enumerate(steps) if s_ == t]
                     sub = (L.AdamwTensor * len(idx))(*[arr[i] for i in idx])
-                    L.call("mc_adamw_step", sub, len(idx), *hyper, t, stream)
+                    L.call(entry, sub, len(idx), *hyper, t, *tail)
             # the kernel wrote through raw pointers: tell autograd (and the derived-weight-image cache in ops.py,
             # which keys on the version counter) that these tensors changed in place
             torch.autograd.graph.increment_version(params)

@@ -6,6 +6,21 @@ MI355X note: the 4 embedding tensors of one step are gathered with ONE collectiv
 import torch
 import torch.distributed as dist
 
+MIN_TORCH = (2, 4)      # all_gather_into_tensor / reduce_scatter_tensor / ReduceOp.AVG on gloo host + device tensors
+
+
+def require_tensor_collectives():
+    """ONE collective code path on every backend needs ``all_gather_into_tensor``, ``reduce_scatter_tensor`` and
+    ``all_reduce(op=AVG)`` from the process group (RCCL always has them; gloo since torch 2.4-ish, verified on 2.10 with
+    scripts/gloo_cuda_probe.py).  Called once when the process group exists (engine.init_distributed / Trainer): an older
+    torch fails HERE with a clear message instead of inside the first training step."""
+    ver = tuple(int(v) for v in torch.__version__.split("+")[0].split(".")[:2])
+    missing = [n for n in ("all_gather_into_tensor", "reduce_scatter_tensor") if not hasattr(dist, n)]
+    if missing or not hasattr(dist.ReduceOp, "AVG") or ver < MIN_TORCH:
+        raise RuntimeError(f"mammo_clip_amd needs torch >= {MIN_TORCH[0]}.{MIN_TORCH[1]} for its collectives "
+                           f"(all_gather_into_tensor, reduce_scatter_tensor, all_reduce(AVG) on every backend); "
+                           f"this is torch {torch.__version__}" + (f", missing {missing}" if missing else ""))
+
 
 def _gather_ranks(x):
     """x [...] on every rank -> [W, ...] in rank order: ONE ``all_gather_into_tensor``.  The same call on every backend

@@ -13,12 +13,17 @@ import torch
 
 
 def save_checkpoint(path: str, model: torch.nn.Module, optimizer=None, scheduler=None, config: Optional[Dict] = None,
-                    epoch: int = 0, train_loss: float = 0.0, best: bool = False) -> str:
+                    epoch: int = 0, train_loss: float = 0.0, best: bool = False, scaler=None) -> str:
+    """``scaler``: an ``engine.LossScaler`` (f16 storage build) -- its state goes under the extra key ``"scaler"`` like the
+    reference's GradScaler would have to be saved for an exact resume (the reference itself resumes model weights only,
+    SURVEY.md appendix B 9; readers of the reference layout ignore the key)."""
     sd = {k: v.detach().to("cpu") for k, v in model.state_dict().items()}
     ckpt = {"model": sd,
             "optimizer": optimizer.state_dict() if optimizer is not None else None,
             "scheduler": scheduler.state_dict() if scheduler is not None else None,
             "config": config, "epoch": int(epoch), "train_loss": float(train_loss)}
+    if scaler is not None:
+        ckpt["scaler"] = scaler.state_dict()
     os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
     torch.save(ckpt, path)
     if best:                                   # "<name>-best.tar" beside it, like the reference
@@ -27,7 +32,7 @@ def save_checkpoint(path: str, model: torch.nn.Module, optimizer=None, scheduler
     return path
 
 
-def load_checkpoint(path: str, model: torch.nn.Module, optimizer=None, scheduler=None, strict: bool = True) -> Dict:
+def load_checkpoint(path: str, model: torch.nn.Module, optimizer=None, scheduler=None, strict: bool = True, scaler=None) -> Dict:
     ckpt = torch.load(path, map_location="cpu", weights_only=False)
     sd = ckpt["model"] if "model" in ckpt else ckpt
     sd = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in sd.items()}     # DDP-wrapped saves
@@ -36,4 +41,6 @@ def load_checkpoint(path: str, model: torch.nn.Module, optimizer=None, scheduler
         optimizer.load_state_dict(ckpt["optimizer"])
     if scheduler is not None and ckpt.get("scheduler") is not None:
         scheduler.load_state_dict(ckpt["scheduler"])
+    if scaler is not None and ckpt.get("scaler") is not None:
+        scaler.load_state_dict(ckpt["scaler"])
     return ckpt

@@ -8,6 +8,7 @@
 // items so the per-channel sum / sum-of-squares for the following training-mode BatchNorm leave the forward kernel
 // as a small [workgroups][2][C] partial buffer (deterministic, no atomics).  The stride-2 data gradient is a gather.
 #include "common_hip.h"
+#include <atomic>
 #include <type_traits>
 #include <cstdlib>
 #include "../../include/mammoclip_hip.h"
@@ -1172,10 +1173,19 @@ extern "C" int mc_dwconv_lane_supported(const mc_dwconv_args* a);
 extern "C" int mc_dwconv_lane_stat_rows(const mc_dwconv_args* a);
 extern "C" int mc_dwconv_fwd_lane(const mc_dwconv_args* a, void* stream);
 extern "C" int mc_dwconv_bwd_weight_lane(const mc_dwconv_args* a, void* stream);
-int g_lane_mode = -2;                 // -2: not read yet; -1 policy; 0 never; 1 wherever supported
+std::atomic<int> g_lane_mode{-2};     // -2: not read yet; -1 policy; 0 never; 1 wherever supported
+int lane_mode() {
+    int m = g_lane_mode.load(std::memory_order_relaxed);
+    if (m == -2) {
+        const char* e = getenv("MC_DW_LANE");
+        int want = e ? atoi(e) : -1, expect = -2;
+        g_lane_mode.compare_exchange_strong(expect, want);          // (a concurrent mc_dwconv_set_lane_mode wins)
+        m = g_lane_mode.load(std::memory_order_relaxed);
+    }
+    return m;
+}
 bool use_lane_fwd(const mc_dwconv_args& p) {
-    if (g_lane_mode == -2) { const char* e = getenv("MC_DW_LANE"); g_lane_mode = e ? atoi(e) : -1; }
-    const int mode = g_lane_mode;
+    const int mode = lane_mode();
     if (mode == 0 || !mc_dwconv_lane_supported(&p)) return false;
     if (mode == 1) return true;
     // measured per shape on one box (scripts/dw_form_ab.py, 32 images): the lane form wins for every 5x5 map (114 / 57 columns:
@@ -1192,9 +1202,9 @@ bool use_lane_fwd(const mc_dwconv_args& p) {
 }
 
 bool use_lane_bww(const mc_dwconv_args& p) {
-    if (g_lane_mode == -2) { const char* e = getenv("MC_DW_LANE"); g_lane_mode = e ? atoi(e) : -1; }
-    if (g_lane_mode == 0 || p.epi_x || !mc_dwconv_lane_supported(&p)) return false;
-    if (g_lane_mode == 1) return true;
+    const int mode = lane_mode();
+    if (mode == 0 || p.epi_x || !mc_dwconv_lane_supported(&p)) return false;
+    if (mode == 1) return true;
     // measured like the forward forms (scripts/dw_form_ab.py): 5x5 everywhere (29 columns: two images per wave), 3x3 at 57 and
     // at 29 columns (1.1-1.3x)
     const bool narrow = p.ow <= 29;
@@ -1207,9 +1217,8 @@ bool use_lane_bww(const mc_dwconv_args& p) {
 // developer / test switch of the depthwise forward form: -1 = the built-in policy, 0 = marching kernels only, 1 = the
 // lane = column kernels wherever they support the shape.  Returns the previous mode.
 extern "C" int mc_dwconv_set_lane_mode(int mode) {
-    const int old = g_lane_mode == -2 ? -1 : g_lane_mode;
-    g_lane_mode = mode;
-    return old;
+    const int old = g_lane_mode.exchange(mode);
+    return old == -2 ? -1 : old;
 }
 
 extern "C" int mc_dwconv_stat_rows(const mc_dwconv_args* a) {
@@ -1237,6 +1246,10 @@ extern "C" int mc_dwconv_fwd(const mc_dwconv_args* a, void* stream) {
     MC_CHECK(!p.epi_x || (p.stride == 1 && p.epi_scale && p.epi_shift && p.epi_mean && p.epi_invstd && p.stat_partials),
              "dwconv_fwd: the BatchNorm-backward epilogue needs stride 1, scale/shift/mean/invstd and stat_partials");
     hipStream_t st = (hipStream_t)stream;
+    // the kernel form decides how many rows of stat_partials are written: a caller that says how many it allocated is held
+    // to the form this launch picks (the form can change between mc_dwconv_stat_rows and here: mc_dwconv_set_lane_mode)
+    MC_CHECK(!(p.stat_partials && p.stat_rows > 0) || p.stat_rows == mc_dwconv_stat_rows(a),
+             "dwconv_fwd: stat_partials was sized for another kernel form (stat_rows != mc_dwconv_stat_rows now)");
     if (use_lane_fwd(p)) return mc_dwconv_fwd_lane(a, stream);
     if (p.k == 3 && p.stride == 1) return launch_march_cp<3, 1>(p, st);
     if (p.k == 3 && p.stride == 2) return launch_march_cp<3, 2>(p, st);

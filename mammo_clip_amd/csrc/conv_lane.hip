@@ -530,16 +530,23 @@ template <typename C, int MODE> int launch(const mc_dwconv_args& p, hipStream_t 
 // configuration by map width and image count: two output columns per lane wherever the registers allow it (not: stride 2,
 // the 5x5 weight gradient), and as many images per wave (4 / 2 / 1) as fit the map into a lane group
 static int gmax1() { static const int g = [] { const char* e = getenv("MC_DW_LANE_G"); return e ? atoi(e) : 4; }(); return g; }
+// G > 1 addresses a staged vector as seg * image pitch + row * row pitch + col * c in 32-bit arithmetic (seg < G): the
+// image-group forms are only picked while G whole images stay below 2^31 elements (a tall, narrow, wide-channel
+// tensor would otherwise wrap silently); larger maps take the one-image forms, whose offsets are row-sized
+static bool g_fits(const mc_dwconv_args& p, int g) {
+    const long long in_img = (long long)p.h * p.w * p.c, out_img = (long long)p.oh * p.ow * p.c;
+    return g * (in_img > out_img ? in_img : out_img) < (1ll << 31);
+}
 template <int K, int S, int MODE, typename F> auto pick(const mc_dwconv_args& p, F&& f) {
     constexpr bool one_col = (S == 2) || (MODE == 2 && K == 5);
     if constexpr (one_col) {
-        if (gmax1() >= 2 && p.n >= 2 && p.ow <= Cfg<K, S, 1, 2>::TOW) return f(Cfg<K, S, 1, 2>{});
+        if (gmax1() >= 2 && p.n >= 2 && p.ow <= Cfg<K, S, 1, 2>::TOW && g_fits(p, 2)) return f(Cfg<K, S, 1, 2>{});
         return f(Cfg<K, S, 1, 1>{});
     } else {
         // several images per wave for maps that do not fill 64 lanes x 2 columns (MC_DW_LANE_G=1 switches it off for A/B)
         static const int gmax = gmax1();
-        if (gmax >= 4 && p.n >= 4 && p.ow <= Cfg<K, S, 2, 4>::TOW) return f(Cfg<K, S, 2, 4>{});
-        if (gmax >= 2 && p.n >= 2 && p.ow <= Cfg<K, S, 2, 2>::TOW) return f(Cfg<K, S, 2, 2>{});
+        if (gmax >= 4 && p.n >= 4 && p.ow <= Cfg<K, S, 2, 4>::TOW && g_fits(p, 4)) return f(Cfg<K, S, 2, 4>{});
+        if (gmax >= 2 && p.n >= 2 && p.ow <= Cfg<K, S, 2, 2>::TOW && g_fits(p, 2)) return f(Cfg<K, S, 2, 2>{});
         if (gmax == 0 && p.ow <= Cfg<K, S, 2, 1>::TOW) return f(Cfg<K, S, 2, 1>{});
         if (p.ow <= Cfg<K, S, 1, 1>::TOW) return f(Cfg<K, S, 1, 1>{});
         return f(Cfg<K, S, 2, 1>{});

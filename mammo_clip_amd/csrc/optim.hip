@@ -40,7 +40,30 @@ __device__ __forceinline__ void adamw1(float& p, float g, float& m, float& v, co
     p -= s.step_size * (m / denom);
 }
 
-__global__ void __launch_bounds__(256) adamw_multi_k(AdamPack pk, int count, AdamScalars s) {
+// Loss-scaled step without a host sync (f16 storage build): the non-finite flag of the gradient unscale and the count of
+// steps skipped so far stay on the device.  A set flag makes the launch a no-op (GradScaler.step() skips optimizer.step());
+// the bias corrections use the number of APPLIED steps, host step - skipped, like an optimizer that was never called.
+struct AdamLs {
+    const float* found_inf;    // nullptr: plain step with the host-derived scalars
+    const float* skipped;      // steps skipped so far (float counter)
+    double lr, beta1, beta2;
+    long long step;
+};
+
+__global__ void __launch_bounds__(256) adamw_multi_k(AdamPack pk, int count, AdamScalars s, AdamLs ls) {
+    if (ls.found_inf) {
+        if (*ls.found_inf != 0.f) return;                              // (uniform: the whole grid leaves)
+        __shared__ float s_dev[2];
+        if (threadIdx.x == 0) {
+            long long te = ls.step - (long long)(*ls.skipped);
+            if (te < 1) te = 1;
+            s_dev[0] = (float)(ls.lr / (1.0 - pow(ls.beta1, (double)te)));
+            s_dev[1] = (float)(1.0 / sqrt(1.0 - pow(ls.beta2, (double)te)));
+        }
+        __syncthreads();
+        s.step_size = s_dev[0];
+        s.inv_bc2_sqrt = s_dev[1];
+    }
     int t = 0;
     const int blk = blockIdx.x;
     while (t + 1 < count && pk.first_chunk[t + 1] <= blk) ++t;       // uniform scan, <= PACK scalar compares
@@ -111,7 +134,9 @@ struct UnscalePack {
     long long n[PACK];
 };
 
-__global__ void __launch_bounds__(256) grads_unscale_k(UnscalePack pk, int count, float inv_scale, float* __restrict__ found_inf) {
+__global__ void __launch_bounds__(256) grads_unscale_k(UnscalePack pk, int count, float inv_scale, const float* __restrict__ scale_dev,
+                                                       float* __restrict__ found_inf) {
+    if (scale_dev) inv_scale = 1.0f / *scale_dev;                       // the dynamic scale lives on the device (no host sync)
     int t = 0;
     const int blk = blockIdx.x;
     while (t + 1 < count && pk.first_chunk[t + 1] <= blk) ++t;
@@ -136,16 +161,54 @@ __global__ void __launch_bounds__(256) grads_unscale_k(UnscalePack pk, int count
     if (bad) *found_inf = 1.0f;          // (every writer stores the same value)
 }
 
+// GradScaler.update() on the device [ref: trainer_ddp.py:303]: state = {scale, clean steps in a row, found_inf flag of the
+// step, steps skipped (this scaler), _}.  Consumes and clears the flag; the optimizer's own skipped-step counter follows.
+__global__ void loss_scale_update_k(float* __restrict__ st, float* __restrict__ opt_skipped, float growth, float backoff, int interval, int dynamic) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const bool bad = st[2] != 0.f;
+    if (bad) { st[3] += 1.f; if (opt_skipped) *opt_skipped += 1.f; }
+    if (dynamic) {
+        if (bad) { st[0] *= backoff; st[1] = 0.f; }
+        else {
+            st[1] += 1.f;
+            if (st[1] >= (float)interval) { st[0] *= growth; st[1] = 0.f; }
+        }
+    }
+    st[4] = bad ? 1.f : 0.f;        // what happened to the step just finished (for whoever looks, later)
+    st[2] = 0.f;
+}
+
+int grads_unscale_impl(const mc_adamw_tensor* tensors, int n_tensors, float inv_scale, const float* scale_dev, float* found_inf, void* stream);
+
 }  // namespace
 
 extern "C" int mc_grads_unscale(const mc_adamw_tensor* tensors, int n_tensors, float inv_scale, float* found_inf, void* stream) {
+    return grads_unscale_impl(tensors, n_tensors, inv_scale, nullptr, found_inf, stream);
+}
+
+extern "C" int mc_grads_unscale_dev(const mc_adamw_tensor* tensors, int n_tensors, const float* scale_dev, float* found_inf, void* stream) {
+    MC_CHECK(scale_dev, "grads_unscale_dev: null scale");
+    return grads_unscale_impl(tensors, n_tensors, 1.0f, scale_dev, found_inf, stream);
+}
+
+extern "C" int mc_loss_scale_update(float* state, float* opt_skipped, float growth_factor, float backoff_factor, int growth_interval,
+                                    int dynamic, void* stream) {
+    MC_CHECK(state && growth_factor > 0.f && backoff_factor > 0.f && growth_interval >= 1, "loss_scale_update: bad arguments");
+    hipLaunchKernelGGL(loss_scale_update_k, dim3(1), dim3(64), 0, (hipStream_t)stream, state, opt_skipped, growth_factor, backoff_factor,
+                       growth_interval, dynamic);
+    MC_LAUNCH_CHECK();
+    return MC_OK;
+}
+
+namespace {
+int grads_unscale_impl(const mc_adamw_tensor* tensors, int n_tensors, float inv_scale, const float* scale_dev, float* found_inf, void* stream) {
     MC_CHECK(n_tensors >= 0 && (tensors || n_tensors == 0) && found_inf, "grads_unscale: bad arguments");
     UnscalePack pk;
     int cnt = 0, chunks = 0;
     auto flush = [&]() -> int {
         if (cnt == 0) return MC_OK;
         pk.first_chunk[cnt] = chunks;
-        hipLaunchKernelGGL(grads_unscale_k, dim3(chunks), dim3(256), 0, (hipStream_t)stream, pk, cnt, inv_scale, found_inf);
+        hipLaunchKernelGGL(grads_unscale_k, dim3(chunks), dim3(256), 0, (hipStream_t)stream, pk, cnt, inv_scale, scale_dev, found_inf);
         MC_LAUNCH_CHECK();
         cnt = 0; chunks = 0;
         return MC_OK;
@@ -167,8 +230,25 @@ extern "C" int mc_grads_unscale(const mc_adamw_tensor* tensors, int n_tensors, f
     return flush();
 }
 
+int adamw_impl(const mc_adamw_tensor* tensors, int n_tensors, double lr, double beta1, double beta2, double eps, double weight_decay,
+               long long step, const float* found_inf, const float* skipped, void* stream);
+}  // namespace
+
 extern "C" int mc_adamw_step(const mc_adamw_tensor* tensors, int n_tensors, double lr, double beta1, double beta2,
                              double eps, double weight_decay, long long step, void* stream) {
+    return adamw_impl(tensors, n_tensors, lr, beta1, beta2, eps, weight_decay, step, nullptr, nullptr, stream);
+}
+
+extern "C" int mc_adamw_step_ls(const mc_adamw_tensor* tensors, int n_tensors, double lr, double beta1, double beta2,
+                                double eps, double weight_decay, long long step, const float* found_inf, const float* skipped,
+                                void* stream) {
+    MC_CHECK(found_inf && skipped, "adamw_step_ls: null loss-scale state");
+    return adamw_impl(tensors, n_tensors, lr, beta1, beta2, eps, weight_decay, step, found_inf, skipped, stream);
+}
+
+namespace {
+int adamw_impl(const mc_adamw_tensor* tensors, int n_tensors, double lr, double beta1, double beta2, double eps, double weight_decay,
+               long long step, const float* found_inf, const float* skipped, void* stream) {
     MC_CHECK(n_tensors >= 0 && (tensors || n_tensors == 0), "adamw: bad tensor list");
     MC_CHECK(step >= 1 && beta1 >= 0.0 && beta1 < 1.0 && beta2 >= 0.0 && beta2 < 1.0 && eps >= 0.0, "adamw: bad hyper-parameters");
     // scalars are derived in double like torch does on the host (1 - 0.999 in fp32 is already 1.3e-5 off)
@@ -180,12 +260,14 @@ extern "C" int mc_adamw_step(const mc_adamw_tensor* tensors, int n_tensors, doub
     s.step_size = (float)(lr / bc1);
     s.inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
     s.eps = (float)eps;
+    AdamLs ls;
+    ls.found_inf = found_inf; ls.skipped = skipped; ls.lr = lr; ls.beta1 = beta1; ls.beta2 = beta2; ls.step = step;
     AdamPack pk;
     int cnt = 0, chunks = 0;
     auto flush = [&]() -> int {
         if (cnt == 0) return MC_OK;
         pk.first_chunk[cnt] = chunks;
-        hipLaunchKernelGGL(adamw_multi_k, dim3(chunks), dim3(256), 0, (hipStream_t)stream, pk, cnt, s);
+        hipLaunchKernelGGL(adamw_multi_k, dim3(chunks), dim3(256), 0, (hipStream_t)stream, pk, cnt, s, ls);
         MC_LAUNCH_CHECK();
         cnt = 0; chunks = 0;
         return MC_OK;
@@ -208,3 +290,4 @@ extern "C" int mc_adamw_step(const mc_adamw_tensor* tensors, int n_tensors, doub
     }
     return flush();
 }
+}  // namespace

@@ -115,25 +115,58 @@ class LossScaler:
     (init 65536, x 0.5 on a non-finite gradient with the optimizer step skipped, x 2 after 2000 clean steps in a row), which
     is what the reference trains under [ref: trainer.py:271-278, trainer_ddp.py:296-303].  f16 keeps 10 mantissa bits but
     only 5 exponent bits: at 32 x 1520 x 912 the activation gradients of the early stages are ~1e-8 and flush to zero
-    without a scale (measured: gradient cosine -0.22 against the scaled run on _blocks.2._bn2.bias).  The unscale + check
-    is one multi-tensor HIP launch per 40 tensors (``mc_grads_unscale``); reading the flag is the step's one host sync."""
+    without a scale (measured: gradient cosine -0.22 against the scaled run on _blocks.2._bn2.bias).
+
+    Round 5: the step has NO host sync.  Scale, clean-step counter, non-finite flag and skip counter are one small device
+    tensor (like GradScaler's own ``_scale`` / ``_growth_tracker``): the loss is multiplied by the device scalar, the unscale
+    kernel reads it (``mc_grads_unscale_dev``), the AdamW kernel itself looks at the flag and does nothing on a bad step
+    (``mc_adamw_step_ls``), ``mc_loss_scale_update`` applies the policy.  ``scale`` / ``skipped`` / ``last_skipped`` READ the
+    device (they synchronise: for logging and tests, not for the hot loop); ``Trainer.step`` returns the device scalars."""
+    _SCALE, _GOOD, _FLAG, _SKIPPED, _LAST = 0, 1, 2, 3, 4
 
     def __init__(self, init_scale=65536.0, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000, dynamic=True):
-        self.scale, self.growth_factor, self.backoff_factor = float(init_scale), float(growth_factor), float(backoff_factor)
+        self.growth_factor, self.backoff_factor = float(growth_factor), float(backoff_factor)
         self.growth_interval, self.dynamic = int(growth_interval), bool(dynamic)
-        self._good, self._flag = 0, None
-        self.skipped = 0
+        self._host = [float(init_scale), 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0]       # until the first use names the device
+        self._state = None
+        self._warned = False
 
-    def unscale_(self, params) -> bool:
-        """grad *= 1 / scale for every parameter gradient; True if all of them are finite"""
+    # ---- device state
+    def state(self, device):
+        if self._state is None or self._state.device != torch.device(device):
+            host = self._host if self._state is None else self._state.cpu().tolist()
+            self._state = torch.tensor(host, dtype=torch.float32, device=device)
+        return self._state
+
+    def scale_tensor(self, device):
+        """0-dim device view of the current scale (what the loss is multiplied by)"""
+        return self.state(device)[self._SCALE]
+
+    def _read(self, idx):
+        return float(self._state[idx].item()) if self._state is not None else self._host[idx]
+
+    scale = property(lambda self: self._read(self._SCALE))                 # (synchronises)
+    skipped = property(lambda self: int(self._read(self._SKIPPED)))       # steps skipped since construction (synchronises)
+    last_skipped = property(lambda self: self._read(self._LAST) != 0.0)   # did the last finished step skip (synchronises)
+
+    def state_dict(self):
+        st = self._state.cpu().tolist() if self._state is not None else list(self._host)
+        return {"scale": st[0], "growth_tracker": int(st[1]), "skipped": int(st[3]), "growth_factor": self.growth_factor,
+                "backoff_factor": self.backoff_factor, "growth_interval": self.growth_interval, "dynamic": self.dynamic}
+
+    def load_state_dict(self, sd):
+        self.growth_factor, self.backoff_factor = float(sd["growth_factor"]), float(sd["backoff_factor"])
+        self.growth_interval, self.dynamic = int(sd["growth_interval"]), bool(sd["dynamic"])
+        dev = self._state.device if self._state is not None else None
+        self._host = [float(sd["scale"]), float(sd["growth_tracker"]), 0.0, float(sd.get("skipped", 0)), 0.0, 0.0, 0.0, 0.0]
+        self._state = None
+        if dev is not None:
+            self.state(dev)
+
+    # ---- the three launches of a loss-scaled optimizer step
+    def _grad_table(self, params):
         ps = [p for p in params if p.grad is not None]
-        if not ps:
-            return True
-        if self._flag is None or self._flag.device != ps[0].device:
-            self._flag = torch.zeros(1, dtype=torch.float32, device=ps[0].device)
-        else:
-            self._flag.zero_()
-        arr = (L.AdamwTensor * len(ps))()
+        arr = (L.AdamwTensor * max(len(ps), 1))()
         keep = []
         for a, p in zip(arr, ps):
             g = p.grad
@@ -141,22 +174,36 @@ class LossScaler:
                 raise L.MammoClipHipError("LossScaler: parameter gradients must be dense contiguous fp32 tensors")
             keep.append(g)
             a.grad, a.numel = g.data_ptr(), g.numel()
-        L.call("mc_grads_unscale", arr, len(ps), 1.0 / self.scale, self._flag.data_ptr(), torch.cuda.current_stream().cuda_stream)
-        return float(self._flag.item()) == 0.0
+        return ps, arr, keep
 
-    def update(self, finite: bool):
-        if not finite:
-            self.skipped += 1
-        if not self.dynamic:
+    def unscale_(self, params, sync=False):
+        """grad *= 1 / scale for every parameter gradient (one multi-tensor launch per 40 tensors), the non-finite flag goes
+        to the device state.  ``sync=True`` (optimizers without a device-side skip): returns True if all gradients are finite."""
+        ps, arr, _keep = self._grad_table(params)
+        if not ps:
+            return True
+        st = self.state(ps[0].device)
+        base = st.data_ptr()
+        L.call("mc_grads_unscale_dev", arr, len(ps), base + 4 * self._SCALE, base + 4 * self._FLAG, ops._st())
+        return float(st[self._FLAG].item()) == 0.0 if sync else None
+
+    def update(self, opt_skipped=None):
+        """GradScaler.update() on the device; ``opt_skipped``: the optimizer's own device counter of skipped steps"""
+        if self._state is None:
             return
-        if not finite:
-            self.scale *= self.backoff_factor
-            self._good = 0
-        else:
-            self._good += 1
-            if self._good >= self.growth_interval:
-                self.scale *= self.growth_factor
-                self._good = 0
+        L.call("mc_loss_scale_update", self._state.data_ptr(), opt_skipped.data_ptr() if opt_skipped is not None else None,
+               self.growth_factor, self.backoff_factor, self.growth_interval, int(self.dynamic), ops._st())
+
+    def check(self, log=print):
+        """One host read of the state (call it every few hundred steps, not per step): warns about a scale that has
+        collapsed -- a forward that overflows f16 permanently halves the scale at every step and skips every update while
+        the LR schedule still advances."""
+        sc, skipped = self.scale, self.skipped
+        if sc < 1.0 and not self._warned:
+            self._warned = True
+            log(f"[mammo_clip_amd] loss scale collapsed to {sc:g} after {skipped} skipped steps: the f16 forward overflows; "
+                "no optimizer update is being applied")
+        return {"scale": sc, "skipped": skipped}
 
 
 class Trainer:
@@ -169,10 +216,13 @@ class Trainer:
         if loss_scale == "auto" and os.environ.get("MC_LOSS_SCALE"):
             loss_scale = float(os.environ["MC_LOSS_SCALE"])          # a static scale for every "auto" Trainer of the process
         if loss_scale == "auto":
-            loss_scale = LossScaler() if L.STORAGE == "f16" else None
+            # MC_LOSS_SCALE_INIT: initial value of the DYNAMIC scale of every "auto" Trainer (tests: low enough not to skip)
+            init = float(os.environ.get("MC_LOSS_SCALE_INIT", 65536.0))
+            loss_scale = LossScaler(init_scale=init) if L.STORAGE == "f16" else None
         elif isinstance(loss_scale, (int, float)):
             loss_scale = LossScaler(init_scale=float(loss_scale), dynamic=False) if float(loss_scale) != 1.0 else None
         self.scaler = loss_scale
+        self.scaler_check_every = 500           # steps between the scaler's one host read (collapse warning)
         self.device = device
         # Gradient reduction: by default the flat buckets are all-reduced AFTER the last backward (reduce_all) -- the whole
         # exchange is 552 MB per step against >= 1.2 s of backward at 128 pairs per GPU, there is nothing worth hiding, and
@@ -190,6 +240,9 @@ class Trainer:
         self.keep_recompute = keep_recompute
         self._sink = None                       # ops.GradSink of the step in flight (installed only around a backward call)
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        if self.world > 1:
+            from .breastclip.util.dist_autograd import require_tensor_collectives
+            require_tensor_collectives()        # clear error on a torch without the tensor collectives / AVG (no silent fallback)
         self.buckets = GradBuckets(list(model.parameters()), bucket_mb << 20) if self.world > 1 else None
         if self.world > 1:
             # identical replicas: rank 0's parameters and buffers everywhere, like torch DDP does at construction
@@ -228,22 +281,40 @@ class Trainer:
         self._optimizer_step()
         if self.scheduler is not None:
             self.scheduler.step()
-        return {k: v.detach() for k, v in loss_dict.items()}
+        return self._result(loss_dict)
 
     def _seed(self, total):
-        """the tensor the step's backward starts from: the loss, times the loss scale when one is in use"""
-        return total if self.scaler is None else total * self.scaler.scale
+        """the tensor the step's backward starts from: the loss, times the loss scale (a device scalar) when one is in use"""
+        return total if self.scaler is None else total * self.scaler.scale_tensor(total.device)
 
     def _optimizer_step(self):
         """optimizer update; under a loss scale: unscale the (already rank-averaged) gradients first and skip the update
-        if any of them is non-finite, like GradScaler.step() [ref: trainer_ddp.py:300-303]"""
+        if any of them is non-finite, like GradScaler.step() [ref: trainer_ddp.py:300-303] -- without a host sync when the
+        optimizer is the HIP AdamW (the kernel reads the flag); any other optimizer: one flag read per step"""
         if self.scaler is None:
             self.optimizer.step()
             return
-        finite = self.scaler.unscale_(self.model.parameters())
-        if finite:
-            self.optimizer.step()
-        self.scaler.update(finite)
+        params = list(self.model.parameters())
+        if hasattr(self.optimizer, "step_loss_scaled"):
+            self.scaler.unscale_(params)
+            opt_skipped = self.optimizer.step_loss_scaled(self.scaler)
+            self.scaler.update(opt_skipped)
+        else:
+            if self.scaler.unscale_(params, sync=True):
+                self.optimizer.step()
+            self.scaler.update()
+        self._steps_done = getattr(self, "_steps_done", 0) + 1
+        if self._steps_done % self.scaler_check_every == 0:
+            self.scaler.check()
+
+    def _result(self, loss_dict):
+        out = {k: v.detach() for k, v in loss_dict.items()}
+        if self.scaler is not None and self.scaler._state is not None:
+            # device scalars (no sync): the scale the NEXT step will use and the skipped-step count so far (ADVICE r4: a skip
+            # must be visible to the caller like scaler.get_scale() is in the reference's loop)
+            out["loss_scale"] = self.scaler._state[LossScaler._SCALE]
+            out["skipped_steps"] = self.scaler._state[LossScaler._SKIPPED]
+        return out
 
     def _backward(self, run):
         """one backward call; with the gradient sink the hand-written functions deliver their parameter gradients to it"""
@@ -392,7 +463,7 @@ def _step_micro(self, batch: Dict, k: int) -> Dict[str, torch.Tensor]:
     self._optimizer_step()
     if self.scheduler is not None:
         self.scheduler.step()
-    return {kk: v.detach() for kk, v in loss_dict.items()}
+    return self._result(loss_dict)
 
 
 Trainer._step_micro = _step_micro

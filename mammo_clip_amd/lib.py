@@ -74,6 +74,7 @@ class DwconvArgs(C.Structure):
         ("k", I), ("stride", I), ("pad_l", I), ("pad_t", I), ("oh", I), ("ow", I),
         ("pro_scale", P), ("pro_shift", P), ("stat_partials", P),
         ("epi_x", P), ("epi_scale", P), ("epi_shift", P), ("epi_mean", P), ("epi_invstd", P),
+        ("dw_out", P), ("stat_rows", I),
     ]
 
 
@@ -97,6 +98,9 @@ _SIGS = {
     "mc_storage_is_f16": ([], I),
     "mc_adamw_step": ([C.POINTER(AdamwTensor), I, D, D, D, D, D, LL, P], I),
     "mc_grads_unscale": ([C.POINTER(AdamwTensor), I, F, P, P], I),
+    "mc_grads_unscale_dev": ([C.POINTER(AdamwTensor), I, P, P, P], I),
+    "mc_adamw_step_ls": ([C.POINTER(AdamwTensor), I, D, D, D, D, D, LL, P, P, P], I),
+    "mc_loss_scale_update": ([P, P, F, F, I, I, P], I),
     "mc_gemm_bf16": ([C.POINTER(GemmArgs), P], I),
     "mc_gemm_stat_rows": ([C.POINTER(GemmArgs)], I),
     "mc_gemm_tile_config": ([C.POINTER(GemmArgs)], I),

@@ -555,7 +555,7 @@ def _dwconv_fwd_impl(x, w_kkc, n, h, w, c, k, stride, pad_l, pad_t, oh, ow, pro=
     if stats:
         rows = L.load().mc_dwconv_stat_rows(C.byref(a))
         part = empty((rows, 2, c), torch.float32, x)
-        a.stat_partials = _p(part)
+        a.stat_partials, a.stat_rows = _p(part), rows
     _note(2 * n * c * (h * w + oh * ow * (2 if epi is not None else 1)), 2 * n * c * oh * ow * k * k)
     L.call("mc_dwconv_fwd", C.byref(a), _st(), kind=f"k{k}s{stride}" + ("|dgrad_bn" if epi is not None else ""))
     return (y, part) if stats else y

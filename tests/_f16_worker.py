@@ -88,12 +88,32 @@ def scaler():
     # overflow: 2^40 x gradients of O(1e-2) do not fit f16
     tr.scaler = engine.LossScaler(init_scale=2.0 ** 40)
     w1 = {n: p.detach().clone() for n, p in model.named_parameters()}
-    steps1 = dict(enumerate(opt._plans[0]["steps"]))
-    tr.step(bt)
+    steps1 = [int(v["step"]) for v in opt.state_dict()["state"].values()]      # APPLIED steps (host count - device skip count)
+    out = tr.step(bt)
+    rep["overflow_reported_skipped"] = int(out["skipped_steps"])                 # (the step's own report, a device scalar)
+    rep["overflow_reported_scale"] = float(out["loss_scale"])
     rep["overflow_skipped"] = tr.scaler.skipped
     rep["overflow_scale_after"] = tr.scaler.scale
     rep["overflow_params_unchanged"] = all(torch.equal(w1[n], p) for n, p in model.named_parameters())
-    rep["overflow_steps_unchanged"] = dict(enumerate(opt._plans[0]["steps"])) == steps1
+    rep["overflow_steps_unchanged"] = [int(v["step"]) for v in opt.state_dict()["state"].values()] == steps1
+    # ... and recovers: the next steps at the halved scales skip until the scale fits f16 again, then apply (dynamic policy,
+    # no host decision anywhere: the AdamW kernel reads the flag)
+    tr.scaler = engine.LossScaler(init_scale=2.0 ** 24)          # overflows f16 (stored gradients x 1.7e7); 2^16 does not (r04 trace)
+    seq = []
+    for _ in range(14):
+        o = tr.step(bt)
+        seq.append((float(o["loss_scale"]), int(o["skipped_steps"])))
+    rep["recover_seq"] = seq
+    rep["recover_applied"] = [int(v["step"]) for v in opt.state_dict()["state"].values()][0] - steps1[0]
+    rep["recover_params_finite"] = all(bool(torch.isfinite(p).all()) for p in model.parameters())
+    # a STATIC scale (Trainer(loss_scale=number) / MC_LOSS_SCALE): the flag still skips a bad step, the scale never moves
+    tr3 = engine.Trainer(model, lossf, opt, None, T.DEV, loss_scale=512.0)
+    o3 = tr3.step(bt)
+    rep["static_dynamic_flag"], rep["static_scale_after"], rep["static_skipped"] = tr3.scaler.dynamic, float(o3["loss_scale"]), int(o3["skipped_steps"])
+    sd_ = tr.scaler.state_dict()
+    sc2 = engine.LossScaler()
+    sc2.load_state_dict(sd_)
+    rep["scaler_state_roundtrip"] = sc2.state_dict() == sd_
     return rep
 
 
@@ -116,6 +136,33 @@ def shapes():
             lo, eo, _ = T._oracle(sd, bt, arch, b, train, grad_keys=("logit_scale",))
             rep[f"{tag}/{mode}_dloss"] = lh - lo
             rep[f"{tag}/{mode}_min_cos"] = min(T._cos_rows(out[k], eo[k]) for k in T.EMB)
+        if tag == "cfg3":
+            # BACKWARD at the production shape under the DYNAMIC loss scale at its default 65536 (this is where
+            # unscaled f16 gradients flush to zero): gradients of the fullsize test's parameter sample against the fp32 oracle
+            keys = T.GRAD_KEYS_B5
+            model.train()
+            model.load_state_dict(sd, strict=True)
+            model.zero_grad(set_to_none=True)
+            scaler = engine.LossScaler()
+            out = model(bt, T.DEV)
+            loss = lossf(**out, is_train=True)["total"]
+            (loss * scaler.scale_tensor(T.DEV)).backward()
+            del out, loss
+            params = [p for p in model.parameters() if p.grad is not None]
+            finite = scaler.unscale_(params, sync=True)
+            scaler.update()
+            pd = dict(model.named_parameters())
+            gh = {k: pd[k].grad.detach().clone() for k in keys}
+            model.zero_grad(set_to_none=True)
+            torch.cuda.empty_cache()
+            _, _, go = T._oracle(sd, bt, arch, b, True, keys)
+            cs = {k: T._cos_flat(gh[k], go[k]) for k in keys if k != "logit_scale"}
+            nr = {k: float(gh[k].float().norm() / (go[k].norm() + 1e-30)) for k in keys}
+            rep["cfg3/bwd_finite"], rep["cfg3/bwd_scale_after"], rep["cfg3/bwd_skipped"] = bool(finite), scaler.scale, scaler.skipped
+            rep["cfg3/grad_min_cos"], rep["cfg3/grad_min_cos_at"] = min(cs.values()), min(cs, key=cs.get)
+            rep["cfg3/grad_cos"] = {k.replace("image_encoder.", "img.").replace("text_encoder.text_encoder.encoder.", "txt."): round(v, 5) for k, v in cs.items()}
+            rep["cfg3/grad_norm_ratio"] = {k.replace("image_encoder.", "img.").replace("text_encoder.text_encoder.encoder.", "txt."): round(v, 4) for k, v in nr.items()}
+            del go, gh
         del model
         torch.cuda.empty_cache()
     return rep

@@ -409,3 +409,6 @@ def test_bench_launches_two_ranks_and_prints_one_json_line():
     js = json.loads(lines[0])
     assert js["n_gpus"] == 2 and js["steps"] == 1 and js["value"] > 0 and js["config"]["global_batch"] == 8
     assert js["scaling"] == "weak" and js["roofline"] is not None and "cpu_baseline" not in js
+    # the line says which backend the job's collectives ran on and how many ranks took part in one (round 5; over RCCL
+    # "rccl_ranks" additionally carries the rank count RCCL's own INIT log reports -- gloo has no such log: None here)
+    assert js["dist"]["backend"] == "gloo" and js["dist"]["allreduce_of_ones"] == 2 and js["rccl_ranks"] is None, js["dist"]

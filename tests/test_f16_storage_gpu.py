@@ -74,6 +74,17 @@ def test_f16_trainer_dynamic_loss_scale():
     assert r["scaled_vs_unscaled_cos"] >= 0.999, r
     assert r["overflow_skipped"] == 1 and r["overflow_scale_after"] == 2.0 ** 39, r
     assert r["overflow_params_unchanged"] and r["overflow_steps_unchanged"], r
+    assert r["overflow_reported_skipped"] == 1 and r["overflow_reported_scale"] == 2.0 ** 39, r
+    # skip-then-recover under the DYNAMIC policy: from 2^24 the scale halves on every skipped step until the
+    # gradients fit f16, then stays; every later step applies -- skipped + applied = 14, at least one of each, and the
+    # scale sequence is non-increasing by exact factors of two
+    seq = r["recover_seq"]
+    n_skip = seq[-1][1]
+    assert 1 <= n_skip <= 12 and r["recover_applied"] == 14 - n_skip and r["recover_params_finite"], r
+    assert seq[-1][0] == 2.0 ** (24 - n_skip) and all(a[0] >= b[0] for a, b in zip(seq, seq[1:])), r
+    assert seq[n_skip - 1][1] == n_skip and (n_skip == 1 or seq[n_skip - 2][1] == n_skip - 1), r     # the skips come first, in a row
+    assert r["scaler_state_roundtrip"], r
+    assert r["static_dynamic_flag"] is False and r["static_scale_after"] == 512.0 and r["static_skipped"] == 0, r
 
 
 def test_f16_baseline_shapes_train_and_eval_within_1e3_of_the_oracle():
@@ -85,15 +96,24 @@ def test_f16_baseline_shapes_train_and_eval_within_1e3_of_the_oracle():
     for tag in ("cfg3", "cfg2"):
         assert abs(r[tag + "/eval_dloss"]) <= 1e-3 and abs(r[tag + "/train_dloss"]) <= 1e-3, r
         assert r[tag + "/eval_min_cos"] >= 0.99999 and r[tag + "/train_min_cos"] >= 0.9999, r
+    # round 5: the BACKWARD at 1520 x 912 under the dynamic loss scale at its default 65536 -- no overflow (the step would
+    # apply), and the sampled parameter gradients agree with the fp32 oracle far better than the bf16 build's (image 0.87-0.95,
+    # norms within 4 % there): floors 0.99 / 3 % until the first measured values are in (see profiles/r05_f16_storage_parity.txt)
+    assert r["cfg3/bwd_finite"] and r["cfg3/bwd_skipped"] == 0 and r["cfg3/bwd_scale_after"] == 65536.0, r
+    assert r["cfg3/grad_min_cos"] >= 0.99, r
+    assert all(abs(v - 1.0) <= 0.03 for k, v in r["cfg3/grad_norm_ratio"].items() if k != "logit_scale"), r
 
 
-def test_f16_trainer_level_tests_under_a_static_loss_scale():
-    """the Trainer-level tests on the f16 build, every ``Trainer(loss_scale="auto")`` pinned to a static scale of 256 by
-    MC_LOSS_SCALE (single steps are compared there; a dynamic scale that starts at 65536 skips its first steps on these small
-    configurations, as GradScaler does): the two-rank steps over gloo on a shared GPU (gradients are unscaled AFTER the
-    rank average, bit-identical on both ranks), the 4-step trajectory against the reference's own loop, the evaluator /
-    checkpoint entry points (the overlapped-bucket and recompute-mode tests pass too; left out for run time)"""
+def test_f16_trainer_level_tests_under_the_dynamic_loss_scale():
+    """the Trainer-level tests on the f16 build under the DYNAMIC scaler (round 5; round 4 pinned a static scale here): every
+    ``Trainer(loss_scale="auto")`` gets ``LossScaler(init_scale=256)`` through MC_LOSS_SCALE_INIT -- the device-side policy
+    (unscale by the device scalar, flag read by the AdamW kernel, update kernel) runs in every step; 256 is low enough that no
+    step of these small configurations skips, so single steps and the 4-step trajectory stay comparable with the reference's
+    (a scaler that starts at 65536 skips its first steps there, as GradScaler does: test_f16_trainer_dynamic_loss_scale asserts
+    that skip-then-recover sequence).  Covered: the two-rank steps over gloo on a shared GPU (gradients are unscaled AFTER
+    the rank average, bit-identical on both ranks), the 4-step trajectory against the reference's own loop, the evaluator /
+    checkpoint entry points."""
     p = _run(["-m", "pytest", os.path.join(HERE, "test_dist_gpu.py"), os.path.join(HERE, "test_model_gpu.py"), "-m", "gpu", "-x", "-q",
-              "-k", "two_rank_step_equals or trajectory or evaluator"], 1500, MC_LOSS_SCALE="256")
+              "-k", "two_rank_step_equals or trajectory or evaluator"], 1500, MC_LOSS_SCALE_INIT="256")
     assert p.returncode == 0, p.stdout[-3000:]
     assert " passed" in p.stdout and "failed" not in p.stdout, p.stdout[-1000:]

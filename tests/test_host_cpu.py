@@ -162,6 +162,33 @@ def test_checkpoint_round_trip_reference_layout(tmp_path):
     load_checkpoint(str(tmp_path / "ddp.tar"), other, strict=True)
 
 
+def test_loss_scaler_state_travels_with_the_checkpoint(tmp_path):
+    """engine.LossScaler (GradScaler's policy for the f16 storage build) exposes state_dict / load_state_dict and the
+    checkpoint carries it under an extra key; before its first use the state is host-side, so this runs on CPU"""
+    from mammo_clip_amd import engine
+    from mammo_clip_amd.checkpoint import load_checkpoint, save_checkpoint
+    sc = engine.LossScaler(init_scale=4096.0, growth_interval=7)
+    assert sc.scale == 4096.0 and sc.skipped == 0 and sc.dynamic
+    sd = sc.state_dict()
+    assert sd["scale"] == 4096.0 and sd["growth_interval"] == 7 and sd["growth_tracker"] == 0
+    model = torch.nn.Linear(2, 2)
+    path = str(tmp_path / "m-epoch-1.tar")
+    save_checkpoint(path, model, scaler=sc)
+    raw = torch.load(path, map_location="cpu", weights_only=False)
+    assert raw["scaler"] == sd and "model" in raw
+    sc2 = engine.LossScaler()
+    load_checkpoint(path, torch.nn.Linear(2, 2), scaler=sc2)
+    assert sc2.state_dict() == sd and sc2.scale == 4096.0
+
+
+def test_collectives_requirement_is_checked_up_front():
+    """one collective code path on every backend needs the tensor collectives + ReduceOp.AVG: probed when a Trainer meets a
+    process group, with a clear message -- this torch has them"""
+    from mammo_clip_amd.breastclip.util.dist_autograd import MIN_TORCH, require_tensor_collectives
+    require_tensor_collectives()
+    assert tuple(int(v) for v in torch.__version__.split("+")[0].split(".")[:2]) >= MIN_TORCH
+
+
 def test_no_cpu_fallback():
     """the product path refuses CPU tensors instead of silently computing somewhere else"""
     model = build_model(_cfg(), {"breast_clip": {}}, types.SimpleNamespace(vocab_size=28996))
