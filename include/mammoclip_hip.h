@@ -270,6 +270,19 @@ int mc_dwconv_bwd_weight(const mc_dwconv_args* args, void* stream);
  * (Environment variable MC_DW_LANE sets the initial mode.)  Both forms produce bit-identical outputs. */
 int mc_dwconv_set_lane_mode(int mode);
 int mc_dwconv_lane_supported(const mc_dwconv_args* args);
+/* Round 5 -- the whole backward of a STRIDE-1 3x3 depthwise conv whose input was silu(bn0(e)) in ONE launch
+ * [ref: efficientnet_custom.py:104-111 backwards: _depthwise_conv, _bn0 + swish]: the data gradient with the BatchNorm0
+ * epilogue of mc_dwconv_fwd(epi_x) AND the weight gradient of mc_dwconv_bwd_weight from one staging of (dd, e) -- dd and e
+ * are read once, dZ0 is written once (3 passes over the expanded tensor instead of 5).  The argument block is the one of
+ * the data-gradient launch (x = dd [n, h, w, c] on the conv's OUTPUT geometry, w_kkc = the taps rotated by 180 degrees,
+ * pad = k-1-pad, (oh, ow) = the conv's input geometry, epi_* = e and its BatchNorm statistics, out = dZ0, stat_partials
+ * with mc_dwconv_bwd_fused_stat_rows() rows) plus dw_out: f32 [k*k][c], accumulated into (+=) in the conv's OWN tap order.
+ * _supported: 3x3, stride 1, c % 8 == 0, epi_x given (the 5x5 form does not fit a wave's registers: see conv_lane.hip).
+ * _preferred: the shapes on which this launch measured faster than the two it replaces. */
+int mc_dwconv_bwd_fused_supported(const mc_dwconv_args* args);
+int mc_dwconv_bwd_fused_preferred(const mc_dwconv_args* args);
+int mc_dwconv_bwd_fused_stat_rows(const mc_dwconv_args* args);
+int mc_dwconv_bwd_fused(const mc_dwconv_args* args, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * training-mode BatchNorm pieces [ref: efficientnet_custom.py:64,74,88,177,205; momentum 0.01, eps 1e-3]

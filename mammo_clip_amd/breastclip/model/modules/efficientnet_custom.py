@@ -163,6 +163,7 @@ def _conv_stats(fn, training, *a, **kw):
 
 # expanded-tensor bytes per call from which the BatchNorm0 backward is folded into the expand conv's gradient GEMMs
 # (ops.bn_fold_expand_bwd) instead of running the apply pass; tests set it to 0 to exercise the folded path at small sizes
+FUSE_DW_BWD = os.environ.get("MC_FUSE_DW_BWD", "1") != "0"              # stride-1 3x3 depthwise backward as one launch (ops.dwconv_bwd_fused)
 FUSE_PROJ_DGRAD = os.environ.get("MC_FUSE_PROJ_DGRAD", "1") != "0"        # projection data gradient with the SE / BatchNorm1 backward in its epilogue (ops.proj_dgrad_*)
 BN_FOLD_MIN_BYTES = int(os.environ.get("MC_BN_FOLD_MIN_BYTES", 400_000_000))
 BN_FOLD_S2_MIN_BYTES = int(os.environ.get("MC_BN_FOLD_S2_MIN_BYTES", 0))
@@ -346,8 +347,13 @@ class _MBConvFn(torch.autograd.Function):
             dw_in, pro0 = e, (st0.scale, st0.shift)
         else:
             dw_in, pro0 = x, None
-        dwdw = ops.dwconv_bwd_weight(dw_in, dd, n, h, w, a.cexp, k, s, l, t, oh, ow, pro=pro0)
         wflip = ops.flipped_taps_f32(blk._depthwise_conv.weight.view(a.cexp, k * k)) if s == 1 else None   # 180 degree rotation
+        # round 5: stride-1 3x3 blocks run the WHOLE depthwise backward as one launch (conv_lane.hip MODE 3): data gradient with
+        # the bn0 + swish epilogue AND the weight gradient from one staging of (dd, e) -- 3 passes over the expanded tensor
+        # instead of 5; where that launch is not preferred: weight gradient + data gradient as two launches
+        fused_dw = (FUSE_DW_BWD and a.expand != 1 and ops.dwconv_bwd_fused_ok(n, h, w, a.cexp, k, s, l, t, oh, ow))
+        if not fused_dw:
+            dwdw = ops.dwconv_bwd_weight(dw_in, dd, n, h, w, a.cexp, k, s, l, t, oh, ow, pro=pro0)
         grads = {}
         if a.expand != 1:
             # the data-gradient kernel finishes the bn0 + swish backward in its epilogue -- it reads e at the output
@@ -355,8 +361,11 @@ class _MBConvFn(torch.autograd.Function):
             # separate reduce pass over (e, dA0) is gone and the apply pass is a plain linear combination (stride 1: the
             # forward kernel on flipped taps; stride 2, round 3: the marching super-pixel kernel -- dA0 of the stride-2
             # blocks, the largest tensors of the network, is never written)
-            dz0, part0 = ops.dwconv_bwd_data(dd, sv["wkkc"], n, h, w, a.cexp, k, s, l, t, oh, ow, w_kkc_flipped=wflip,
-                                             epi=(e, st0))
+            if fused_dw:
+                dz0, part0, dwdw = ops.dwconv_bwd_fused(dd, e, st0, wflip, n, h, w, a.cexp, k, l, t, oh, ow)
+            else:
+                dz0, part0 = ops.dwconv_bwd_data(dd, sv["wkkc"], n, h, w, a.cexp, k, s, l, t, oh, ow, w_kkc_flipped=wflip,
+                                                 epi=(e, st0))
             del dd
             if 2 * n * hw * a.cexp >= (BN_FOLD_MIN_BYTES if s == 1 else max(BN_FOLD_MIN_BYTES, BN_FOLD_S2_MIN_BYTES)):
                 # bn0 backward is linear in (dZ0, e) and e = x We^T: it is folded into the operands of the expand conv's

@@ -64,6 +64,7 @@ template <int K, int S, int NCOL, int G = 1> struct Cfg {
     static constexpr int NV = (RB * G * IW_T * VPP + NT - 1) / NT;
     static constexpr int NVO = (ORB * G * TOW * VPP + NT - 1) / NT;
     static constexpr int LDS_BYTES = (2 * IN_DW + 2 * OUT_DW) * 4 + 2 * TCH * 4 + (128 * 16 + 24) * 4;
+    static constexpr int LDS_BYTES_FUSED = LDS_BYTES + 2 * OUT_DW * 4;      // MODE 3: the e rows have a tile of their own
     static_assert(RB % S == 0 && (K - 1) % S == 0, "block / tap geometry");
     static_assert(TOW <= LPI * NCOL, "a group's lanes cover its segment");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
@@ -72,7 +73,8 @@ template <int K, int S, int NCOL, int G = 1> struct Cfg {
 // Block descriptors live in LDS (a ring of 128, refilled 64 at a time by the lanes of wave 0 from a closed form of
 // block index -> (item, block)); everybody reads the few fields a pipeline stage needs when it needs them -- no long-lived
 // scalar state besides the filter taps (50 SGPRs for 5x5), no per-block cursor arithmetic on any wave's critical path.
-enum { D_FLAGS = 0, D_INB_LO, D_INB_HI, D_RLO, D_RHI, D_CLO, D_CHI, D_OUTB_LO, D_OUTB_HI, D_ORLO, D_ORHI, D_OCHI, D_NSEG, D_WORDS = 16 };
+enum { D_FLAGS = 0, D_INB_LO, D_INB_HI, D_RLO, D_RHI, D_CLO, D_CHI, D_OUTB_LO, D_OUTB_HI, D_ORLO, D_ORHI, D_OCHI, D_NSEG, D_EB_LO, D_EB_HI, D_ERHI,
+       D_WORDS = 16 };
 constexpr int NDESC = 128;
 
 // EPI (stride 1): the launch is the DATA GRADIENT of a depthwise conv whose input was silu(bn0(e)); the kernel reads e at
@@ -82,16 +84,26 @@ constexpr int NDESC = 128;
 // the "output" tile (dy row o enters when input row o*S is processed); the registers hold the K*K tap accumulators of the
 // wave's channel pair and an A-deep window of unpacked dy rows; one butterfly sum per tap + one atomic per (tap, channel)
 // and workgroup at the end.
+// MODE 3 (round 5, stride 1): the WHOLE backward of a depthwise conv whose input was a0 = silu(bn0(e)) in one launch -- the data
+// gradient with the BatchNorm0 epilogue of MODE 1 AND the weight gradient, from ONE staging of (dd with its halo, e):
+//   dA0[q] = sum_t dd[q + t - (K-1-pad)] wflip[t]        dW[K*K-1-t] += dd[q + t - (K-1-pad)] a0[q]
+// pair every staged dd value with the SAME (output pixel q, tap t), so the weight gradient is one more packed FMA beside each
+// FMA of the data gradient.  a0[q] is evaluated once, when output row q.y meets its first dd row (an A-deep register window of
+// a0 and of the packed e values, which the epilogue needs again when the row completes); the e rows therefore enter K-1 rows
+// EARLIER than in MODE 1 and get an LDS tile of their own.  dd and e are read once, dZ0 is written once: 3 passes over the
+// expanded tensor instead of 5 (MODE 1: dd + e read, dZ0 written; MODE 2: dd + e read).
 template <int K, int S, int NCOL, int MODE, int G>
 __global__ __launch_bounds__(1024, 4) void dwconv_lane_fwd_kernel(const mc_dwconv_args p, int strips, int nunits, int cpairs,
                                                                   int ctiles, int ymax) {
     using C = Cfg<K, S, NCOL, G>;
-    constexpr bool EPI = MODE == 1, BWW = MODE == 2, ETILE = EPI || BWW;       // ETILE: a second global tensor staged in the output tile
+    constexpr bool FUSED = MODE == 3;
+    constexpr bool EPI = MODE == 1 || FUSED, BWW = MODE == 2, ETILE = EPI || BWW;       // ETILE: a second global tensor staged beside the input
     static_assert(!EPI || S == 1, "the BatchNorm-backward epilogue is provided for stride 1");
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     uint32_t* const s_in = smem;                                    // [2][RB][IWP][PXD]
     uint32_t* const s_out = smem + 2 * C::IN_DW;                    // [2][ORB][TOW][PXD]
-    float* const pro_lds = reinterpret_cast<float*>(smem + 2 * C::IN_DW + 2 * C::OUT_DW);   // [2][TCH]
+    uint32_t* const s_e = FUSED ? smem + 2 * C::IN_DW + 2 * C::OUT_DW : s_out;   // e / dy rows (MODE 1 / 2: they travel in the output tile)
+    float* const pro_lds = reinterpret_cast<float*>(smem + 2 * C::IN_DW + (FUSED ? 4 : 2) * C::OUT_DW);   // [2][TCH]
     int* const s_desc = reinterpret_cast<int*>(pro_lds + 2 * C::TCH);                        // [NDESC][D_WORDS]
 
     // ---- workgroup -> (channel tile, virtual-row range); the two tiles of a 128-byte line share an XCD (block id % 8)
@@ -226,12 +238,17 @@ __global__ __launch_bounds__(1024, 4) void dwconv_lane_fwd_kernel(const mc_dwcon
         d[D_ORLO] = o_first < 0 ? -o_first : 0; d[D_ORHI] = orhi;
         d[D_OCHI] = ochi;
         d[D_NSEG] = g_n - img < G ? g_n - img : G;                     // images of the group that exist
+        if constexpr (FUSED) {                                          // the e rows of the output rows that ENTER in this block
+            const long long eb = (((long long)img * g_oh + oy0 + b * C::RB) * g_ow + ox0) * (long long)g_c + g_c0;
+            int erhi = nrows - b * C::RB; if (erhi > C::ORB) erhi = C::ORB;
+            d[D_EB_LO] = (int)(unsigned)eb; d[D_EB_HI] = (int)(eb >> 32); d[D_ERHI] = erhi;
+        }
     };
     if (wv == 0) { gen_desc(0); gen_desc(64); }            // blocks 0 .. 127
     // the output tile doubles as the e tile of the epilogue form: slots no stage ever writes (columns >= TOW) must not
     // hold NaN patterns (0 * NaN in the reductions)
     // (the weight-gradient form sums over ALL lanes: the staged positions no stage ever writes must be zero as well)
-    for (int i = tid; i < 2 * C::OUT_DW + (BWW ? 2 * C::IN_DW : 0); i += C::NT) (BWW ? s_in : s_out)[i] = 0u;
+    for (int i = tid; i < (FUSED ? 4 : 2) * C::OUT_DW + ((BWW || FUSED) ? 2 * C::IN_DW : 0); i += C::NT) ((BWW || FUSED) ? s_in : s_out)[i] = 0u;
     __syncthreads();                                        // pro_lds, descriptors
 
     uint4 vals[C::NV];
@@ -259,9 +276,9 @@ __global__ __launch_bounds__(1024, 4) void dwconv_lane_fwd_kernel(const mc_dwcon
             vals[i] = *reinterpret_cast<const uint4*>(ok ? org + goff : a_x);        // unconditional load, clamped address
             inb |= (ok ? 1u : 0u) << i;
         }
-        if constexpr (ETILE) {                             // e rows of the output rows block q completes / its dy rows
-            const long long obase = ((long long)d[D_OUTB_HI] << 32) | (unsigned)d[D_OUTB_LO];
-            const int orlo = d[D_ORLO], orhi = d[D_ORHI], ochi = d[D_OCHI];
+        if constexpr (ETILE) {                             // e rows of the output rows block q completes (MODE 3: that enter in it) / its dy rows
+            const long long obase = FUSED ? (((long long)d[D_EB_HI] << 32) | (unsigned)d[D_EB_LO]) : (((long long)d[D_OUTB_HI] << 32) | (unsigned)d[D_OUTB_LO]);
+            const int orlo = FUSED ? 0 : d[D_ORLO], orhi = FUSED ? d[D_ERHI] : d[D_ORHI], ochi = d[D_OCHI];
             const bf16_t* const esrc = BWW ? a_dy : a_epi_x;
             const bf16_t* eorg = esrc + obase + vv * 8;
             einb = 0;
@@ -318,7 +335,7 @@ __global__ __launch_bounds__(1024, 4) void dwconv_lane_fwd_kernel(const mc_dwcon
     };
     auto estore = [&](int buf) {                           // EPI / BWW: the e / dy rows of the block just loaded, into its output slots
         if constexpr (ETILE) {
-            uint32_t* dst = s_out + buf * C::OUT_DW;
+            uint32_t* dst = s_e + buf * C::OUT_DW;
 #pragma unroll
             for (int i = 0; i < C::NVO; ++i) {
                 if ((metao[i] & 0xffffu) != 0xffffu) {
@@ -335,9 +352,15 @@ __global__ __launch_bounds__(1024, 4) void dwconv_lane_fwd_kernel(const mc_dwcon
     for (int i = 0; i < NCOL; ++i)
 #pragma unroll
         for (int a = 0; a < C::A; ++a) acc[i][a] = f32x2_t{0.f, 0.f};
-    f32x2_t dwa[BWW ? K * K : 1];                          // BWW: tap accumulators of the wave's channel pair
+    f32x2_t dwa[(BWW || FUSED) ? K * K : 1];               // BWW / FUSED: tap accumulators of the wave's channel pair
 #pragma unroll
-    for (int t = 0; t < (BWW ? K * K : 1); ++t) dwa[t] = f32x2_t{0.f, 0.f};
+    for (int t = 0; t < ((BWW || FUSED) ? K * K : 1); ++t) dwa[t] = f32x2_t{0.f, 0.f};
+    f32x2_t a0w[FUSED ? NCOL : 1][FUSED ? C::A : 1];       // FUSED: a0 = silu(bn0(e)) of the output rows in flight (0 where no pixel exists)
+    uint32_t ew[FUSED ? NCOL : 1][FUSED ? C::A : 1];       // ... and their packed e values (the epilogue needs them when the row completes)
+#pragma unroll
+    for (int i = 0; i < (FUSED ? NCOL : 1); ++i)
+#pragma unroll
+        for (int a = 0; a < (FUSED ? C::A : 1); ++a) { a0w[i][a] = f32x2_t{0.f, 0.f}; ew[i][a] = 0u; }
     f32x2_t ssum = {0.f, 0.f}, ssq = {0.f, 0.f};
 
     // interval q: store block q (loaded in interval q-1), flush block q-2, load block q+1, compute block q-1.
@@ -396,6 +419,83 @@ __global__ __launch_bounds__(1024, 4) void dwconv_lane_fwd_kernel(const mc_dwcon
                                     dwa[kh * K + kw] = __builtin_elementwise_fma(acc[i][sl], in[i * S + kw], dwa[kh * K + kw]);
                         }
                     }
+                } else if constexpr (FUSED) {
+                const int* d = s_desc + ((q - 1) & (NDESC - 1)) * D_WORDS;
+                const int orlo = __builtin_amdgcn_readfirstlane(d[D_ORLO]), orhi = __builtin_amdgcn_readfirstlane(d[D_ORHI]);
+                const int erhi = __builtin_amdgcn_readfirstlane(d[D_ERHI]);
+                const int ochi = d[D_OCHI], nseg = d[D_NSEG];
+                if (__builtin_amdgcn_readfirstlane(d[D_FLAGS]) & 2) {       // new item: no output row has entered yet
+#pragma unroll
+                    for (int i = 0; i < NCOL; ++i)
+#pragma unroll
+                        for (int a = 0; a < C::A; ++a) { a0w[i][a] = f32x2_t{0.f, 0.f}; ew[i][a] = 0u; }
+                }
+                const uint32_t* lin = s_in + ((q - 1) & 1) * C::IN_DW + ((x / C::LPI) * C::SEGP + x % C::LPI) * C::PXD + wv;
+                const uint32_t* le = s_e + ((q - 1) & 1) * C::OUT_DW + x * C::PXD + wv;
+                uint32_t* lout = s_out + ((q - 1) & 1) * C::OUT_DW + x * C::PXD + wv;
+                uint32_t cm[NCOL];                                     // all ones where the lane's i-th column exists
+#pragma unroll
+                for (int i = 0; i < NCOL; ++i) cm[i] = (ch_ok && (x % C::LPI) * NCOL + i < ochi && x / C::LPI < nseg) ? 0xffffffffu : 0u;
+#pragma unroll
+                for (int j = 0; j < C::RB; ++j) {
+                    const int jr = (ph * C::RB + j) % C::P;            // rotation index of this dd row (static)
+                    f32x2_t in[C::NIN];
+#pragma unroll
+                    for (int i = 0; i < C::NIN; ++i) {
+                        const uint32_t v = lin[(j * C::IWP + (i % C::NS) * C::HQ + i / C::NS) * C::PXD];
+                        in[i] = f32x2_t{bf_lo(v), bf_hi(v)};
+                    }
+                    {   // the output row whose FIRST dd row this is enters the window: e-tile row j, slot jr % A
+                        const int s0 = jr % C::A;
+                        const bool e_ok = j < erhi;                    // (wave-uniform; rows beyond the item: a0 = 0)
+#pragma unroll
+                        for (int i = 0; i < NCOL; ++i) {
+                            uint32_t ev = 0u;
+                            f32x2_t a = {0.f, 0.f};
+                            if (e_ok) {
+                                ev = le[(j * C::TOWP + i * 64) * C::PXD] & cm[i];
+                                const f32x2_t e2 = {bf_lo(ev), bf_hi(ev)};
+                                const f32x2_t sa = silu2_f(__builtin_elementwise_fma(e2, e_sc, e_sh));
+                                // pixels that do not exist (columns beyond the map / the strip): a0 = 0, whatever silu(shift) is
+                                a = f32x2_t{__uint_as_float(__float_as_uint(sa.x) & cm[i]), __uint_as_float(__float_as_uint(sa.y) & cm[i])};
+                            }
+                            ew[i][s0] = ev;
+                            a0w[i][s0] = a;
+                        }
+                    }
+#pragma unroll
+                    for (int kh = 0; kh < K; ++kh) {
+                        const int sl = pmod_c(jr - kh, C::A);
+#pragma unroll
+                        for (int kw = 0; kw < K; ++kw)
+#pragma unroll
+                            for (int i = 0; i < NCOL; ++i) {
+                                if (kh == 0 && kw == 0) acc[i][sl] = in[i + kw] * w[kh * K + kw];
+                                else acc[i][sl] = __builtin_elementwise_fma(in[i + kw], w[kh * K + kw], acc[i][sl]);
+                                dwa[kh * K + kw] = __builtin_elementwise_fma(in[i + kw], a0w[i][sl], dwa[kh * K + kw]);
+                            }
+                    }
+                    {   // output row complete: out-tile row j
+                        const int sl = pmod_c(jr - (K - 1), C::A);
+                        const bool o_ok = j >= orlo && j < orhi;      // (wave-uniform)
+#pragma unroll
+                        for (int i = 0; i < NCOL; ++i) {
+                            uint32_t* slot = lout + (j * C::TOWP + i * 64) * C::PXD;
+                            const uint32_t ewv = ew[i][sl];
+                            const f32x2_t e2 = {bf_lo(ewv), bf_hi(ewv)};
+                            const f32x2_t z = __builtin_elementwise_fma(e2, e_sc, e_sh);
+                            const f32x2_t dz = acc[i][sl] * silu_grad2_f(z);
+                            const uint32_t o2 = pack_bf2(dz.x, dz.y);
+                            *slot = o2;
+                            if (o_ok) {
+                                const uint32_t m = o2 & cm[i];
+                                const f32x2_t r = {bf_lo(m), bf_hi(m)};          // reductions of the stored (rounded) dZ0
+                                ssum += r;
+                                ssq = __builtin_elementwise_fma(r, e2 - e_mu, ssq);
+                            }
+                        }
+                    }
+                }
                 } else {
                 const int* d = s_desc + ((q - 1) & (NDESC - 1)) * D_WORDS;
                 const int orlo = __builtin_amdgcn_readfirstlane(d[D_ORLO]), orhi = __builtin_amdgcn_readfirstlane(d[D_ORHI]);
@@ -469,14 +569,17 @@ __global__ __launch_bounds__(1024, 4) void dwconv_lane_fwd_kernel(const mc_dwcon
         }
     }
 done:
-    if constexpr (BWW) {
-        float* dw = reinterpret_cast<float*>(p.out);
+    if constexpr (BWW || FUSED) {
+        // FUSED: the launch ran on the FLIPPED taps (data gradient = forward conv with the filter rotated by 180 degrees); the
+        // gradient is returned for the conv's own tap order: accumulator t belongs to tap K*K-1-t
+        float* dw = FUSED ? p.dw_out : reinterpret_cast<float*>(p.out);
 #pragma unroll
         for (int t = 0; t < K * K; ++t) {
             const float a = wave_sum(dwa[t].x), b = wave_sum(dwa[t].y);
-            if (x == 0 && ch_ok) { atomicAdd(dw + (long long)t * p.c + cl, a); atomicAdd(dw + (long long)t * p.c + cl + 1, b); }
+            const int tt = FUSED ? K * K - 1 - t : t;
+            if (x == 0 && ch_ok) { atomicAdd(dw + (long long)tt * p.c + cl, a); atomicAdd(dw + (long long)tt * p.c + cl + 1, b); }
         }
-        return;
+        if constexpr (BWW) return;
     }
     if (p.stat_partials) {
         // the 64 lanes of a wave hold the same channel pair: butterfly sums, lane 0 writes
@@ -520,9 +623,11 @@ template <typename C> Plan plan(const mc_dwconv_args& p) {
 template <typename C, int MODE> int launch(const mc_dwconv_args& p, hipStream_t st) {
     static unsigned long long attr_done = 0;
     auto kern = dwconv_lane_fwd_kernel<C::K_, C::S_, C::NCOL_, MODE, C::G_>;
-    MC_SET_MAX_LDS(attr_done, kern, C::LDS_BYTES);
+    constexpr int lds = MODE == 3 ? C::LDS_BYTES_FUSED : C::LDS_BYTES;
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    MC_SET_MAX_LDS(attr_done, kern, lds);
     const Plan m = plan<C>(p);
-    hipLaunchKernelGGL(kern, dim3(m.grid), dim3(C::NT), C::LDS_BYTES, st, p, m.strips, m.nunits, m.cpairs, m.ctiles, m.ymax);
+    hipLaunchKernelGGL(kern, dim3(m.grid), dim3(C::NT), lds, st, p, m.strips, m.nunits, m.cpairs, m.ctiles, m.ymax);
     MC_LAUNCH_CHECK();
     return MC_OK;
 }
@@ -538,7 +643,9 @@ static bool g_fits(const mc_dwconv_args& p, int g) {
     return g * (in_img > out_img ? in_img : out_img) < (1ll << 31);
 }
 template <int K, int S, int MODE, typename F> auto pick(const mc_dwconv_args& p, F&& f) {
-    constexpr bool one_col = (S == 2) || (MODE == 2 && K == 5);
+    // one column per lane: stride 2; the 5x5 weight gradient (50 tap accumulators: no registers for two); the fused backward
+    // (its third LDS tile -- the e rows -- does not fit beside two-column input / output tiles)
+    constexpr bool one_col = (S == 2) || (MODE == 2 && K == 5) || MODE == 3;
     if constexpr (one_col) {
         if (gmax1() >= 2 && p.n >= 2 && p.ow <= Cfg<K, S, 1, 2>::TOW && g_fits(p, 2)) return f(Cfg<K, S, 1, 2>{});
         return f(Cfg<K, S, 1, 1>{});
@@ -590,6 +697,47 @@ extern "C" int mc_dwconv_fwd_lane(const mc_dwconv_args* a, void* stream) {
         return lane::pick<5, 1, 1>(p, [&](auto cfg) { return lane::launch<decltype(cfg), 1>(p, st); });
     }
     return lane::pick_ks<0>(p, [&](auto cfg) { return lane::launch<decltype(cfg), 0>(p, st); });
+}
+
+// ---- MODE 3: fused backward (stride 1).  Argument block = the data-gradient launch of MODE 1 (x = dd on the conv's OUTPUT
+// geometry as (h, w), flipped taps, pads K-1-pad, (oh, ow) = the conv's input geometry, epi_* = e and its BatchNorm
+// statistics) + dw_out [k*k][c] f32, accumulated into (+=, the conv's own tap order).
+// 3x3 only: the 5x5 form needs 50 tap accumulators + the two windows + the data gradient's partial rows in one wave --
+// ~177 live VGPRs against the 128 of a 16-wave workgroup (compiled and measured in round 5: 177-224 spilled registers); the
+// 5x5 backward stays two launches (MODE 1 + MODE 2).
+extern "C" int mc_dwconv_bwd_fused_lane_supported(const mc_dwconv_args* a) {
+    const mc_dwconv_args& p = *a;
+    return mc_dwconv_lane_supported(a) && p.k == 3 && p.stride == 1 && p.epi_x != nullptr;
+}
+
+extern "C" int mc_dwconv_bwd_fused_lane_stat_rows(const mc_dwconv_args* a) {
+    const mc_dwconv_args& p = *a;
+    return lane::pick<3, 1, 3>(p, [&](auto cfg) { return lane::plan<decltype(cfg)>(p).ymax; });
+}
+
+extern "C" int mc_dwconv_bwd_fused_lane(const mc_dwconv_args* a, void* stream) {
+    const mc_dwconv_args& p = *a;
+    MC_CHECK(mc_dwconv_bwd_fused_lane_supported(a), "dwconv_bwd_fused: stride-1 conv with the BatchNorm epilogue operands (epi_x) only");
+    MC_CHECK(p.x && p.w_kkc && p.out && p.dw_out, "dwconv_bwd_fused: null dd / w / out / dw_out");
+    MC_CHECK(p.epi_scale && p.epi_shift && p.epi_mean && p.epi_invstd && p.stat_partials,
+             "dwconv_bwd_fused: the BatchNorm-backward epilogue needs scale/shift/mean/invstd and stat_partials");
+    MC_CHECK(!p.pro_scale, "dwconv_bwd_fused: dd carries no prologue");
+    MC_CHECK(!(p.stat_rows > 0) || p.stat_rows == mc_dwconv_bwd_fused_lane_stat_rows(a), "dwconv_bwd_fused: stat_partials was sized for another configuration");
+    hipStream_t st = (hipStream_t)stream;
+    return lane::pick<3, 1, 3>(p, [&](auto cfg) { return lane::launch<decltype(cfg), 3>(p, st); });
+}
+
+// public names (include/mammoclip_hip.h).  _preferred: where the fused launch measured faster than the two launches it
+// replaces (scripts/dw_form_ab.py, 32 images; MC_DW_FUSED=0 never / =1 wherever supported, for A/B runs)
+extern "C" int mc_dwconv_bwd_fused_supported(const mc_dwconv_args* a) { return mc_dwconv_bwd_fused_lane_supported(a); }
+extern "C" int mc_dwconv_bwd_fused_stat_rows(const mc_dwconv_args* a) { return mc_dwconv_bwd_fused_lane_stat_rows(a); }
+extern "C" int mc_dwconv_bwd_fused(const mc_dwconv_args* a, void* stream) { return mc_dwconv_bwd_fused_lane(a, stream); }
+extern "C" int mc_dwconv_bwd_fused_preferred(const mc_dwconv_args* a) {
+    static const int mode = [] { const char* e = getenv("MC_DW_FUSED"); return e ? atoi(e) : -1; }();
+    if (mode == 0 || !mc_dwconv_bwd_fused_lane_supported(a)) return 0;
+    if (mode == 1) return 1;
+    const mc_dwconv_args& p = *a;
+    return p.ow >= 50 && p.ow < 100;          // the maps on which the separate 3x3 launches already run on the lane form
 }
 
 extern "C" int mc_dwconv_bwd_weight_lane(const mc_dwconv_args* a, void* stream) {

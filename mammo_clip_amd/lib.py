@@ -133,6 +133,10 @@ _SIGS = {
     "mc_dwconv_bwd_weight": ([C.POINTER(DwconvArgs), P], I),
     "mc_dwconv_set_lane_mode": ([I], I),
     "mc_dwconv_lane_supported": ([C.POINTER(DwconvArgs)], I),
+    "mc_dwconv_bwd_fused_supported": ([C.POINTER(DwconvArgs)], I),
+    "mc_dwconv_bwd_fused_preferred": ([C.POINTER(DwconvArgs)], I),
+    "mc_dwconv_bwd_fused_stat_rows": ([C.POINTER(DwconvArgs)], I),
+    "mc_dwconv_bwd_fused": ([C.POINTER(DwconvArgs), P], I),
     "mc_bn_finalize": ([P, I, I, D, P, P, P, P, F, F, I, P, P, P, P, P], I),
     "mc_bn_eval_coeffs": ([P, P, P, P, F, I, P, P, P], I),
     "mc_bnact_rows": ([C.POINTER(BnactArgs)], I),

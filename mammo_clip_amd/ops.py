@@ -583,6 +583,40 @@ def _dwconv_bwd_data_impl(dy, w_kkc, n, h, w, c, k, stride, pad_l, pad_t, oh, ow
     return dx if epi is None else (dx, part)
 
 
+def _dw_fused_args(dd, w_kkc_flipped, n, h, w, c, k, pad_l, pad_t, oh, ow, e, st):
+    """argument block of the fused stride-1 backward = the data-gradient launch on flipped taps: the conv's OUTPUT geometry
+    (oh, ow) is this launch's input geometry"""
+    a = _dw_args(n, oh, ow, c, k, 1, k - 1 - pad_l, k - 1 - pad_t, h, w)
+    a.x, a.w_kkc = _p(dd), _p(w_kkc_flipped)
+    a.epi_x, a.epi_scale, a.epi_shift, a.epi_mean, a.epi_invstd = _p(e), _p(st.scale), _p(st.shift), _p(st.mean), _p(st.invstd)
+    return a
+
+
+def dwconv_bwd_fused_ok(n, h, w, c, k, stride, pad_l, pad_t, oh, ow, force=False):
+    """does the fused backward launch (mc_dwconv_bwd_fused) take / win this stride-1 conv?  (pointers are not looked at)"""
+    if stride != 1:
+        return False
+    a = _dw_args(n, oh, ow, c, k, 1, k - 1 - pad_l, k - 1 - pad_t, h, w)
+    a.epi_x = 16                                    # any non-null value: only looked at
+    lib_ = L.load()
+    return bool(lib_.mc_dwconv_bwd_fused_supported(C.byref(a)) if force else lib_.mc_dwconv_bwd_fused_preferred(C.byref(a)))
+
+
+def dwconv_bwd_fused(dd, e, st, w_kkc_flipped, n, h, w, c, k, pad_l, pad_t, oh, ow):
+    """Whole backward of a stride-1 depthwise conv y = dw(silu(bn0(e))) in one launch (conv_lane.hip MODE 3):
+    returns (dZ0 [n*h*w, c] bf16 = dL/d bn0(e), BatchNorm0-backward partials [rows, 2, c], dW [k*k, c] f32 in the conv's own
+    tap order).  dd = dL/dy [n*oh*ow, c]; e = the expand conv's output [n*h*w, c]; st = its BatchNorm statistics."""
+    a = _dw_fused_args(dd, w_kkc_flipped, n, h, w, c, k, pad_l, pad_t, oh, ow, e, st)
+    dz = empty((n * h * w, c), BF16, dd)
+    dw = torch.zeros((k * k, c), dtype=torch.float32, device=dd.device)
+    rows = L.load().mc_dwconv_bwd_fused_stat_rows(C.byref(a))
+    part = empty((rows, 2, c), torch.float32, dd)
+    a.out, a.dw_out, a.stat_partials, a.stat_rows = _p(dz), _p(dw), _p(part), rows
+    _note(2 * n * c * (oh * ow + 2 * h * w), 4 * n * c * h * w * k * k)
+    L.call("mc_dwconv_bwd_fused", C.byref(a), _st(), kind=f"k{k}s1")
+    return dz, part, dw
+
+
 def _dwconv_bwd_weight_impl(x, dy, n, h, w, c, k, stride, pad_l, pad_t, oh, ow, pro=None):
     a = _dw_args(n, h, w, c, k, stride, pad_l, pad_t, oh, ow)
     dw = torch.zeros((k * k, c), dtype=torch.float32, device=x.device)

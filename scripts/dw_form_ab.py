@@ -33,7 +33,7 @@ def timeit(fn, iters=4):
 arch = oarch.build_arch("efficientnet-b5")
 chain = oarch.spatial_chain(arch, 1520, 912)
 seen = set()
-print("# k s c  in -> out      |  fwd+pro march / lane  |  dgrad+epi march / lane  |  wgrad march / lane   (ms per launch, 32 images)")
+print("# k s c  in -> out      |  fwd+pro march / lane  |  dgrad+epi march / lane  |  wgrad march / lane  |  policy: dgrad+epi + wgrad -> fused backward   (ms per launch, 32 images)")
 for blk in arch.blocks:
     (h, w), (oh, ow) = chain[blk.idx], chain[blk.idx + 1]
     key = (blk.cexp, blk.k, blk.s, h, w)
@@ -58,6 +58,13 @@ for blk in arch.blocks:
         res.append((f, e, g))
     lib.mc_dwconv_set_lane_mode(-1)
     (f0, e0, g0), (f1, e1, g1) = res
-    print(f"k{k} s{s} c={c:5d} {h:3d}x{w:3d}->{oh:3d}x{ow:3d} | {f0:7.3f} {f1:7.3f} {'L' if f1 < f0 else ' '} | {e0:7.3f} {e1:7.3f} {'L' if e1 < e0 else ' '} | {g0:7.3f} {g1:7.3f} {'L' if g1 < g0 else ' '}", flush=True)
+    fused = ""
+    if s == 1 and ops.dwconv_bwd_fused_ok(n, h, w, c, k, s, l, t, oh, ow, force=True):
+        # round 5: the two backward launches under the POLICY's form choice against the one fused launch (conv_lane.hip MODE 3)
+        ep = timeit(lambda: ops.dwconv_bwd_data(dy, wk, n, h, w, c, k, 1, l, t, oh, ow, w_kkc_flipped=wflip, epi=(x, st)))
+        gp = timeit(lambda: ops.dwconv_bwd_weight(x, dy, n, h, w, c, k, s, l, t, oh, ow, pro=(sc, sh)))
+        fu = timeit(lambda: ops.dwconv_bwd_fused(dy, x, st, wflip, n, h, w, c, k, l, t, oh, ow))
+        fused = f" | {ep:7.3f} + {gp:7.3f} = {ep + gp:7.3f} -> {fu:7.3f} {'F' if fu < ep + gp else ' '}"
+    print(f"k{k} s{s} c={c:5d} {h:3d}x{w:3d}->{oh:3d}x{ow:3d} | {f0:7.3f} {f1:7.3f} {'L' if f1 < f0 else ' '} | {e0:7.3f} {e1:7.3f} {'L' if e1 < e0 else ' '} | {g0:7.3f} {g1:7.3f} {'L' if g1 < g0 else ' '}{fused}", flush=True)
     del x, dy
     torch.cuda.empty_cache()

@@ -981,6 +981,53 @@ def test_dwconv_lane_form_epilogue_equals_marching_form(k, n, h, w, c):
     assert float(((s0 - s1).abs() / scale).max()) <= 2e-4, "BatchNorm-backward partials"
 
 
+FUSED_CASES = [  # n, h, w, c: several strips per row (w > 62), image groups (w <= 30 / 14), ragged channel tiles, tiny maps
+    (2, 70, 300, 48), (3, 33, 59, 24), (5, 95, 57, 72), (33, 48, 29, 64), (9, 7, 9, 24), (2, 40, 33, 240), (1, 200, 62, 40),
+    (70, 600, 40, 32)]   # > 128 blocks per workgroup: the descriptor ring is refilled
+
+
+@pytest.mark.parametrize("n,h,w,c", FUSED_CASES)
+def test_dwconv_fused_backward_equals_the_two_launches(n, h, w, c):
+    """Round 5: the whole stride-1 3x3 depthwise backward in ONE launch (conv_lane.hip MODE 3, ops.dwconv_bwd_fused) against the
+    two launches it replaces on the same inputs [ref: efficientnet_custom.py:104-111 backwards]:
+      * dZ0 and the BatchNorm0-backward partials: the data-gradient launch with the epilogue (the fused kernel adds the taps of
+        an output in the same order: dZ0 bit-identical; partials to 2e-4 of the column's scale),
+      * dW: the weight-gradient launch with the BN0 + SiLU prologue (the separate launch rounds the activated input to the
+        16-bit storage type while staging, the fused launch keeps fp32: <= 4e-3 of the largest tap gradient) and an fp32 torch
+        reference of dW[t, c] = sum dd[o] * silu(bn0(e))[o + t - pad] (<= 4e-3: 16-bit dd, fp32 sums).
+    Run twice: the second launch finds whatever the first left in LDS."""
+    k, pad = 3, 1
+    e = rnd(n * h * w, c, seed=1)
+    dd = rnd(n * h * w, c, seed=2)
+    wk = rnd(k * k, c, seed=3, dtype=torch.float32)
+    gamma, beta = rnd(c, seed=4, dtype=torch.float32) * 0.2 + 1.0, rnd(c, seed=5, dtype=torch.float32) * 0.1
+    ef = e.float()
+    mean, var = ef.mean(0), ef.var(0, unbiased=False)
+    st = ops.BNStats()
+    st.mean, st.invstd = mean.contiguous(), (var + 1e-3).rsqrt().contiguous()
+    st.scale = (gamma * st.invstd).contiguous()
+    st.shift = (beta - mean * st.scale).contiguous()
+    st.count = float(n * h * w)
+    wflip = wk.flip(0).contiguous()
+    assert ops.dwconv_bwd_fused_ok(n, h, w, c, k, 1, pad, pad, h, w, force=True)
+    dz_ref, part_ref = ops.dwconv_bwd_data(dd, wk, n, h, w, c, k, 1, pad, pad, h, w, w_kkc_flipped=wflip, epi=(e, st))
+    dw_sep = ops.dwconv_bwd_weight(e, dd, n, h, w, c, k, 1, pad, pad, h, w, pro=(st.scale, st.shift))
+    for _ in range(2):
+        dz, part, dw = ops.dwconv_bwd_fused(dd, e, st, wflip, n, h, w, c, k, pad, pad, h, w)
+    torch.cuda.synchronize()
+    assert torch.equal(dz, dz_ref), "fused dZ0 differs from the data-gradient launch"
+    s0, s1 = part_ref.double().sum(0), part.double().sum(0)
+    scale = s0.abs().amax(dim=1, keepdim=True)
+    assert float(((s0 - s1).abs() / scale).max()) <= 2e-4, "BatchNorm-backward partials"
+    assert torch.isfinite(dw).all()
+    assert float((dw - dw_sep).abs().max()) <= 4e-3 * float(dw_sep.abs().max()), "dW vs the separate weight-gradient launch"
+    a0 = torch.nn.functional.silu(ef * st.scale + st.shift).view(n, h, w, c).permute(0, 3, 1, 2)
+    a0p = torch.nn.functional.pad(a0, (pad, pad, pad, pad))
+    g = dd.float().view(n, h, w, c).permute(0, 3, 1, 2)
+    ref = torch.stack([(g * a0p[:, :, kh:kh + h, kw:kw + w]).sum((0, 2, 3)) for kh in range(k) for kw in range(k)])
+    check(dw, ref, 4e-3, "dW vs fp32 reference")
+
+
 @pytest.mark.parametrize("k,n,h,w,c,pad", [(3, 2, 40, 33, 144, (0, 1)), (3, 2, 41, 34, 240, (1, 1)), (5, 2, 29, 23, 384, (1, 2)),
                                           (5, 1, 60, 64, 64, (2, 2)), (3, 3, 17, 50, 48, (0, 0)), (5, 2, 30, 31, 1056, (2, 1))])
 def test_dwconv_s2_dgrad_with_bn_backward_epilogue(k, n, h, w, c, pad):
