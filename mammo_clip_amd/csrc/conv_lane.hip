@@ -737,7 +737,10 @@ extern "C" int mc_dwconv_bwd_fused_preferred(const mc_dwconv_args* a) {
     if (mode == 0 || !mc_dwconv_bwd_fused_lane_supported(a)) return 0;
     if (mode == 1) return 1;
     const mc_dwconv_args& p = *a;
-    return p.ow >= 50 && p.ow < 100;          // the maps on which the separate 3x3 launches already run on the lane form
+    // measured (32 images, two launches under the form policy -> fused, ms): c = 768 at 95x57 0.347 -> 0.286, c = 1824 at 48x29
+    // 0.223 -> 0.183, c = 3072 0.460 -> 0.343, c = 240 at 380x228 1.494 -> 1.345 (the whole-pixel marching pair); narrow pixels
+    // lose (c = 24 at 760x456: 0.711 -> 1.265 -- 48-byte pixels in 32-channel tiles)
+    return (p.ow >= 50 && p.c >= 192) || (p.ow <= 30 && p.n >= 2 && p.c >= 192);
 }
 
 extern "C" int mc_dwconv_bwd_weight_lane(const mc_dwconv_args* a, void* stream) {

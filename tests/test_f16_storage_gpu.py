@@ -81,8 +81,10 @@ def test_f16_trainer_dynamic_loss_scale():
     seq = r["recover_seq"]
     n_skip = seq[-1][1]
     assert 1 <= n_skip <= 12 and r["recover_applied"] == 14 - n_skip and r["recover_params_finite"], r
-    assert seq[-1][0] == 2.0 ** (24 - n_skip) and all(a[0] >= b[0] for a, b in zip(seq, seq[1:])), r
-    assert seq[n_skip - 1][1] == n_skip and (n_skip == 1 or seq[n_skip - 2][1] == n_skip - 1), r     # the skips come first, in a row
+    # every skip halves the scale exactly once, nothing else moves it (no growth inside 2000 clean steps); the skips need not be
+    # consecutive -- the parameters move between steps (measured: skips at steps 1-3 and again at step 6, 2^24 -> 2^20)
+    assert all(sc == 2.0 ** (24 - sk) for sc, sk in seq) and all(a[1] <= b[1] for a, b in zip(seq, seq[1:])), r
+    assert seq[0][1] == 1, r                                   # 2^24 overflows f16 on the first step
     assert r["scaler_state_roundtrip"], r
     assert r["static_dynamic_flag"] is False and r["static_scale_after"] == 512.0 and r["static_skipped"] == 0, r
 
@@ -98,10 +100,11 @@ def test_f16_baseline_shapes_train_and_eval_within_1e3_of_the_oracle():
         assert r[tag + "/eval_min_cos"] >= 0.99999 and r[tag + "/train_min_cos"] >= 0.9999, r
     # round 5: the BACKWARD at 1520 x 912 under the dynamic loss scale at its default 65536 -- no overflow (the step would
     # apply), and the sampled parameter gradients agree with the fp32 oracle far better than the bf16 build's (image 0.87-0.95,
-    # norms within 4 % there): floors 0.99 / 3 % until the first measured values are in (see profiles/r05_f16_storage_parity.txt)
+    # norms within 4 % there).  Measured on MI355X (profiles/r05_f16_storage_parity.txt): cosines 0.99848 (_blocks.21._se_reduce)
+    # .. 0.99998 (text), norm ratios 0.9921 .. 1.0025, logit_scale 1.0136 -- floors 0.997 / 1.5 % (logit_scale 3 %)
     assert r["cfg3/bwd_finite"] and r["cfg3/bwd_skipped"] == 0 and r["cfg3/bwd_scale_after"] == 65536.0, r
-    assert r["cfg3/grad_min_cos"] >= 0.99, r
-    assert all(abs(v - 1.0) <= 0.03 for k, v in r["cfg3/grad_norm_ratio"].items() if k != "logit_scale"), r
+    assert r["cfg3/grad_min_cos"] >= 0.997, r
+    assert all(abs(v - 1.0) <= (0.03 if k == "logit_scale" else 0.015) for k, v in r["cfg3/grad_norm_ratio"].items()), r
 
 
 def test_f16_trainer_level_tests_under_the_dynamic_loss_scale():
