@@ -163,6 +163,7 @@ def _conv_stats(fn, training, *a, **kw):
 
 # expanded-tensor bytes per call from which the BatchNorm0 backward is folded into the expand conv's gradient GEMMs
 # (ops.bn_fold_expand_bwd) instead of running the apply pass; tests set it to 0 to exercise the folded path at small sizes
+LINK_STEM = os.environ.get("MC_LINK_STEM", "1") != "0"                  # stem bn0 + swish inside block 0's depthwise kernels (_StemLink)
 FUSE_DW_BWD = os.environ.get("MC_FUSE_DW_BWD", "1") != "0"              # stride-1 3x3 depthwise backward as one launch (ops.dwconv_bwd_fused)
 FUSE_PROJ_DGRAD = os.environ.get("MC_FUSE_PROJ_DGRAD", "1") != "0"        # projection data gradient with the SE / BatchNorm1 backward in its epilogue (ops.proj_dgrad_*)
 BN_FOLD_MIN_BYTES = int(os.environ.get("MC_BN_FOLD_MIN_BYTES", 400_000_000))
@@ -173,7 +174,12 @@ class _StemFn(torch.autograd.Function):
     """_conv_stem (3x3 s2, static pad) + _bn0 + swish [ref: efficientnet_custom.py:273]."""
 
     @staticmethod
-    def forward(ctx, x, w, gamma, beta, mod):
+    def forward(ctx, x, w, gamma, beta, mod, link=None):
+        """link (round 5): a ``_StemLink`` -- the stem then returns its RAW conv output e and block 0 (no expand conv: its
+        depthwise stage reads the stem's output directly) applies bn0 + swish while it stages its LDS tiles, exactly like every
+        other block does with its own expand conv; the activated 48-channel 760x456 tensor (the widest map of the network) is
+        never written or read.  The backward mirrors it: block 0's depthwise data gradient finishes the bn0 + swish backward in
+        its epilogue and leaves the BatchNorm reductions in the link."""
         n, _, h, wd = x.shape
         l, r, t, b = mod.stem_pad
         oh, ow = _out_extent(h, t, b, 3, 2), _out_extent(wd, l, r, 3, 2)
@@ -183,12 +189,15 @@ class _StemFn(torch.autograd.Function):
         training = mod.training
         e, part = _conv_stats(ops.linear_fwd, training, patches, wb)
         st = _bn_stats(part, n * oh * ow, mod._bn0, training)
-        y = ops.bnact_apply(e, n, oh * ow, c0, st.scale, st.shift, 1)
         ctx.mod, ctx.st, ctx.geo = mod, st, (n, h, wd, oh, ow, c0)
         ctx.raw = (x.mean, x.std) if isinstance(x, ops.RawImages) else None
         ctx.save_for_backward(x.data if ctx.raw else x, e)
+        ctx.link = link
         mod._geo = (n, oh, ow)
-        return y
+        if link is not None:
+            link.st, link.part = st, None
+            return e.detach()               # (a new tensor object: autograd must not return a saved input as the output)
+        return ops.bnact_apply(e, n, oh * ow, c0, st.scale, st.shift, 1)
 
     @staticmethod
     def backward(ctx, dy):
@@ -197,13 +206,28 @@ class _StemFn(torch.autograd.Function):
             x = ops.RawImages(x, *ctx.raw)
         n, h, wd, oh, ow, c0 = ctx.geo
         mod = ctx.mod
-        de, dgamma, dbeta = ops.bnact_bwd(e, n, oh * ow, c0, ctx.st, mod._bn0.weight, 1, g=dy.contiguous())
+        link = ctx.link
+        if link is not None:
+            # dy is already dZ0 = dL/d bn0(e) (block 0's data-gradient epilogue), link.part its BatchNorm-backward reductions
+            de, dgamma, dbeta = ops.bnact_bwd(e, n, oh * ow, c0, ctx.st, mod._bn0.weight, 0, g=dy.contiguous(), partials=link.part)
+            link.part = None
+        else:
+            de, dgamma, dbeta = ops.bnact_bwd(e, n, oh * ow, c0, ctx.st, mod._bn0.weight, 1, g=dy.contiguous())
         l, r, t, b = mod.stem_pad
         patches = ops.stem_im2col(x, l, t, oh, ow)                 # recomputed, not stored
         dw = ops.linear_wgrad(de, patches)                         # [c0, 32]
         gw, gg, gb = ops.deliver_param_grads((mod._conv_stem.weight, mod._bn0.weight, mod._bn0.bias),
                                              (dw[:, :27].reshape(c0, 3, 3, 3), dgamma, dbeta))
-        return None, gw, gg, gb, None
+        return (None, gw, gg, gb, None) + ((None,) if link is not None else ())
+
+
+class _StemLink:
+    """hand-over between the stem and block 0 when the stem's bn0 + swish lives in block 0's depthwise kernels: the stem's
+    BatchNorm coefficients (forward) and the BatchNorm-backward reductions block 0's data gradient leaves (backward)"""
+    __slots__ = ("st", "part")
+
+    def __init__(self):
+        self.st, self.part = None, None
 
 
 def _expand_conv(blk, x, we, rows, training=False, recompute=False):
@@ -240,7 +264,10 @@ class _MBConvFn(torch.autograd.Function):
             dw_in, pro0 = e, (st0.scale, st0.shift)
             saved.update(we=we, e=None if rc >= 1 else e, st0=st0)
         else:
-            dw_in, pro0 = x, None
+            # block 0 behind a linked stem: x is the stem's RAW conv output, its bn0 + swish is this block's prologue
+            link = blk.__dict__.pop("_in_link", None)
+            dw_in, pro0 = x, ((link.st.scale, link.st.shift) if link is not None else None)
+            saved.update(link=link)
         wkkc = ops.transpose_f32(blk._depthwise_conv.weight.view(a.cexp, k * k), cache=True)
         d, part1 = _conv_stats(ops.dwconv_fwd, training, dw_in, wkkc, n, h, w, a.cexp, k, s, l, t, oh, ow, pro=pro0)
         st1 = _bn_stats(part1, n * ohw, blk._bn1, training)
@@ -299,9 +326,10 @@ class _MBConvFn(torch.autograd.Function):
             st0 = sv["st0"]
             if e is None:                                    # (recompute modes: same kernels, statistics epilogues off)
                 e = _expand_conv(blk, x, sv["we"], n * hw, recompute=True)
+        link = sv.get("link")
         if d is None:
             d = ops.dwconv_fwd(e if a.expand != 1 else x, sv["wkkc"], n, h, w, a.cexp, k, s, l, t, oh, ow,
-                               pro=(st0.scale, st0.shift) if a.expand != 1 else None)
+                               pro=(st0.scale, st0.shift) if a.expand != 1 else ((link.st.scale, link.st.shift) if link is not None else None))
             if sv["keep_act"]:
                 act1 = ops.bnact_pool(d, n, ohw, a.cexp, st1.scale, st1.shift, 1, keep_act=True)[1]
         if p is None:                                        # mode 4: the projection conv again, from the rebuilt d
@@ -346,7 +374,7 @@ class _MBConvFn(torch.autograd.Function):
         if a.expand != 1:
             dw_in, pro0 = e, (st0.scale, st0.shift)
         else:
-            dw_in, pro0 = x, None
+            dw_in, pro0 = x, ((link.st.scale, link.st.shift) if link is not None else None)
         wflip = ops.flipped_taps_f32(blk._depthwise_conv.weight.view(a.cexp, k * k)) if s == 1 else None   # 180 degree rotation
         # round 5: stride-1 3x3 blocks run the WHOLE depthwise backward as one launch (conv_lane.hip MODE 3): data gradient with
         # the bn0 + swish epilogue AND the weight gradient from one staging of (dd, e) -- 3 passes over the expanded tensor
@@ -381,6 +409,12 @@ class _MBConvFn(torch.autograd.Function):
                 de, dg0, db0 = ops.bnact_bwd(e, n, hw, a.cexp, st0, blk._bn0.weight, 0, g=dz0, partials=part0)
                 del e, dw_in
             del dz0
+        elif link is not None:
+            # linked stem: this launch finishes the STEM's bn0 + swish backward (x is the stem's raw conv output): what goes
+            # back is dZ0 = dL/d bn0(x), the BatchNorm reductions travel in the link
+            da0, link.part = ops.dwconv_bwd_data(dd, sv["wkkc"], n, h, w, a.cexp, k, s, l, t, oh, ow, w_kkc_flipped=wflip,
+                                                 epi=(x, link.st))
+            del dd
         else:
             da0 = ops.dwconv_bwd_data(dd, sv["wkkc"], n, h, w, a.cexp, k, s, l, t, oh, ow, w_kkc_flipped=wflip)
             del dd
@@ -663,7 +697,14 @@ class EfficientNet(nn.Module):
         for bn in bns:
             bn.defer_count = counters
         try:
-            y = _StemFn.apply(x, self._conv_stem.weight, self._bn0.weight, self._bn0.bias, self)
+            b0 = self._blocks[0].args
+            # block 0 has no expand conv (every EfficientNet-B*): the stem's bn0 + swish runs inside its depthwise kernels
+            link = _StemLink() if (LINK_STEM and b0.expand == 1 and not b0.skip and b0.s == 1) else None
+            if link is not None:
+                y = _StemFn.apply(x, self._conv_stem.weight, self._bn0.weight, self._bn0.bias, self, link)
+                self._blocks[0].__dict__["_in_link"] = link
+            else:
+                y = _StemFn.apply(x, self._conv_stem.weight, self._bn0.weight, self._bn0.bias, self)
             n, h, w = self._geo
             scales = self._drop_connect_scales(n, x.device, seed)
             for blk, rs in zip(self._blocks, scales):

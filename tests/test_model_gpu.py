@@ -551,6 +551,55 @@ def test_recompute_modes_same_gradients_less_memory():
         {m: res[m][3] for m in res}
 
 
+def test_round5_fusions_same_forward_close_gradients():
+    """Round 5 pass fusions of the MBConv / stem chain against the paths they replace, on the same model and batch:
+      * linked stem (efficientnet_custom._StemLink): the stem's bn0 + swish runs in block 0's depthwise prologue (forward) and
+        in the epilogue of block 0's depthwise data gradient (backward) instead of as apply / reduce passes;
+      * fused depthwise backward (ops.dwconv_bwd_fused): data gradient + BatchNorm0 epilogue + weight gradient of the stride-1
+        3x3 blocks in one launch (forced on for every shape the kernel supports).
+    Forward: the same rounded values enter the same kernels -- loss and embeddings bit-identical.  Backward: bf16 roundings of
+    the same fp32 expressions at different points -- every parameter gradient agrees (cosine >= 0.998, the gradients behind all
+    39 blocks are the worst, like in the folded-BatchNorm test below)."""
+    from mammo_clip_amd.breastclip.model.modules import efficientnet_custom as enc
+    z = np.load(os.path.join(GOLDEN, "e2e_b5_small.npz"))
+    b, H, W, T = [int(v) for v in z["meta"]]
+    model, lossf, sd = _build("tf_efficientnet_b5_ns-detect", "efficientnet-b5")
+    batch = ow.synth_batch(b, H, W, T, seed=33)
+    res = {}
+    old = (enc.LINK_STEM, enc.FUSE_DW_BWD, ops.dwconv_bwd_fused_ok)
+    forced = lambda *a, **kw: old[2](*a, **{**kw, "force": True})        # noqa: E731
+    try:
+        for tag, link, fuse in (("base", False, False), ("link", True, False), ("fused", False, True), ("both", True, True)):
+            enc.LINK_STEM, enc.FUSE_DW_BWD = link, fuse
+            ops.dwconv_bwd_fused_ok = forced if fuse else old[2]
+            model.load_state_dict(sd, strict=True)
+            model.zero_grad(set_to_none=True)
+            out, ld = _run(model, lossf, batch, True)
+            ld["total"].backward()
+            res[tag] = (float(ld["total"]), out["image_embeddings"].detach().clone(),
+                        {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None})
+    finally:
+        enc.LINK_STEM, enc.FUSE_DW_BWD, ops.dwconv_bwd_fused_ok = old
+    # (parameters with a mathematically ZERO gradient -- the _bn2.bias in front of a BatchNorm'd conv -- hold rounding noise in
+    # either path: cosine only for gradients that are not noise-sized against the encoder's gradient scale G, like below)
+    G = max(float(g.abs().max()) for n, g in res["base"][2].items() if n.startswith("image_encoder"))
+    worst = {}
+    for tag in ("link", "fused", "both"):
+        assert res[tag][0] == res["base"][0] and torch.equal(res[tag][1], res["base"][1]), tag
+        assert res[tag][2].keys() == res["base"][2].keys()
+        w_ = (1.0, "")
+        for n, g in res["base"][2].items():
+            g2 = res[tag][2][n]
+            if float(g.abs().max()) > 0.05 * G:
+                cos = float(torch.nn.functional.cosine_similarity(g.flatten().double(), g2.flatten().double(), dim=0))
+                w_ = min(w_, (cos, n))
+                assert cos >= 0.998, (tag, n, cos)
+            else:
+                assert float((g2 - g).abs().max()) <= 1e-2 * G, (tag, n)
+        worst[tag] = w_
+    print("round-5 fusions, worst gradient cosine against the unfused path:", worst)
+
+
 def test_bn0_backward_folded_into_expand_gemms():
     """_MBConvFn.backward with the BatchNorm0 backward folded into the expand conv's gradient GEMMs (the path the large
     early blocks take at the benchmark shapes; forced on for every stride-1 block here) against the explicit apply-pass
