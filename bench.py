@@ -70,6 +70,8 @@ KERNEL_NAMES = {
     "mc_dwconv_fwd": "dwconv_march_fwd_kernel + lane::dwconv_lane_fwd_kernel<K,S,NCOL,0|1> (depthwise conv forward / stride-1 data gradient: marching LDS kernels for 3x3, lane = column kernels with the taps in SGPRs for 5x5)",
     "mc_dwconv_bwd_weight": "dwconv_march_bww_kernel + lane::dwconv_lane_fwd_kernel<K,S,NCOL,2> (depthwise conv weight gradient)",
     "mc_dwconv_bwd_data": "dwconv_march_bwd_s2_kernel (depthwise conv stride-2 data gradient, with the BatchNorm0+SiLU backward epilogue)",
+    "mc_dwconv_bwd_fused": "lane::dwconv_lane_fwd_kernel<3,1,1,3,G> (round 5: whole stride-1 3x3 depthwise backward in one launch -- data gradient + BatchNorm0 epilogue + weight gradient from one staging of (dd, e))",
+    "mc_xbwd_rows_bf16": "xbwd_rows_kernel (round 5: expand-conv backward, weight + data gradient from one pass over the upstream gradient, LDS transpose-reads + register-resident weight slice)",
     "mc_gemm_rows_bf16": "gemm_rows_kernel (row-streaming 1x1 conv forward / data gradient, weights resident in LDS)",
     "mc_wgrad_rows_bf16": "wgrad_rows_kernel (row-streaming 1x1 conv weight gradient, LDS transpose-reads)",
     "mc_gemm_bf16|glnt256": "g8::gemm8p_kernel (plain NT 256x256x64 MFMA tiles, 8 waves, 4 phases per K tile, LDS-direct DMA)",
@@ -101,7 +103,7 @@ def class_key(key):
         for side in ("mfma", "hbm"):
             if ep == "mc_gemm_bf16" and kind.endswith(f"|{tag}|{side}"):
                 return f"{ep}:|{tag}|{side}"
-    if ep in ("mc_dwconv_fwd", "mc_gemm_rows_bf16", "mc_dwconv_bwd_weight", "mc_wgrad_rows_bf16"):
+    if ep in ("mc_dwconv_fwd", "mc_gemm_rows_bf16", "mc_dwconv_bwd_weight", "mc_wgrad_rows_bf16", "mc_dwconv_bwd_fused", "mc_xbwd_rows_bf16"):
         return ep
     return key
 

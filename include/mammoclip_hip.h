@@ -188,6 +188,16 @@ typedef struct mc_wgrad_rows_args {
 int mc_wgrad_rows_supported(int n, int k);
 int mc_wgrad_rows_blocks(long long m);
 int mc_wgrad_rows_bf16(const mc_wgrad_rows_args* args, void* stream);
+/* Round 5 -- BOTH gradients of such a 1x1 convolution e = x W^T from ONE pass over the upstream gradient dY [M, N] (the expand
+ * conv of an MBConv block: dY is the widest tensor of the block, 6x its input) [ref: autograd backward of
+ * efficientnet_custom.py:104]:   dW[N, K] (fp32) (+)= dY^T x   (args as for mc_wgrad_rows_bf16, no prologue; ws with
+ * mc_xbwd_rows_blocks(M) * N * K floats)   and   dX[M, K] (bf16) = dY . wt[K, N]^T (+ r[M, K])   -- what
+ * mc_gemm_rows_bf16(dY, wt, residual r) returns.  Shapes: mc_xbwd_rows_supported(N, K) (K <= 64 and the expand geometries
+ * of EfficientNet-B2 / -B5: (96,16) (144,24) (240,40) (288,48) (384,64)). */
+int mc_xbwd_rows_supported(int n, int k);
+int mc_xbwd_rows_blocks(long long m);
+int mc_xbwd_rows_bf16(const mc_wgrad_rows_args* args, const mc_bf16* wt, long long ldwt, mc_bf16* dx, long long lddx,
+                      const mc_bf16* r, long long ldr, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * small helpers */

@@ -421,8 +421,11 @@ class _MBConvFn(torch.autograd.Function):
         if a.expand != 1:
             if de is not None:
                 we_t = ops.cast_transpose_bf16(blk._expand_conv.weight.view(a.cexp, a.cin))     # [cin, cexp]
-                dx = ops.linear_dgrad(de, sv["we"], residual=dy if a.skip else None, w_t=we_t)
-                dwe = ops.linear_wgrad(de, x)
+                if ops.xbwd_rows_ok(n * hw, a.cexp, a.cin):     # one pass over de for both gradients (round 5)
+                    dx, dwe = ops.xbwd_rows(de, x, we_t, residual=dy if a.skip else None)
+                else:
+                    dx = ops.linear_dgrad(de, sv["we"], residual=dy if a.skip else None, w_t=we_t)
+                    dwe = ops.linear_wgrad(de, x)
             grads["_expand_conv.weight"] = dwe.view(a.cexp, a.cin, 1, 1)
             grads["_bn0.weight"], grads["_bn0.bias"] = dg0, db0
         else:

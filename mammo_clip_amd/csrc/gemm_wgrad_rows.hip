@@ -206,6 +206,185 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, int parts, lon
     out[i] = accumulate ? out[i] + s : s;
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// Round 5: BOTH gradients of a 1x1 convolution e = x W^T from ONE pass over the upstream gradient (the expand conv of an MBConv
+// block; dY = dL/de resp. the folded BatchNorm form's dZ0, the widest tensor of the block, 6x the block input)
+//     dW[N,K] (fp32) (+)= sum_m dY[m,:]^T x[m,:]                 -- exactly wgrad_rows_kernel (no prologue on x)
+//     dX[m,K] (bf16)    = dY[m,:] . Wt[K,N]^T (+ R[m,:])         -- the data gradient of mc_gemm_rows_bf16(dY, Wt, R)
+// [ref: autograd backward of efficientnet_custom.py:104 (_expand_conv)].  dY is staged once per step for the transpose-reads of
+// the weight gradient; the data gradient reads the SAME rows as plain 16-byte MFMA A fragments.  Wave w owns the 16-column
+// fragment w of dX (K <= 64: at most four) and keeps its [N x 16] slice of Wt as NKS B fragments in REGISTERS for the whole
+// kernel (48 registers at N = 384) -- no weight tile in LDS, two workgroups per CU as before.  The dX tile leaves through a
+// small LDS tile as 16-byte rows (+ the residual, staged one step ahead like the operands).
+// RF = 16-row fragments per step (RB = 16 RF rows: 64, or 32 where the registers are short), NKS = ceil(N / 32).
+struct xbwd_extra {
+    const bf16_t* Wt; long long ldwt;       // [K][N] (row = dX column, contiguous along the reduction), the operand of the data gradient
+    bf16_t* dX; long long lddx;
+    const bf16_t* R; long long ldr;         // optional residual added to dX
+};
+
+template <int AF, int BF, int MAXCH, int NKS, int RF>
+__global__ __launch_bounds__(256, 2) void xbwd_rows_kernel(const mc_wgrad_rows_args p, const xbwd_extra q, int WB, int nchy, int nchx, int nchr) {
+    constexpr int RB = 16 * RF;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int rsy = p.N * 2, rsx = p.K * 2;
+    const int KF = (p.K + 15) >> 4, KO = KF * 16, rso = KO * 2;     // dX tile: KF column fragments, row stride rso bytes
+    unsigned char* sY = smem;
+    unsigned char* sX = smem + RB * rsy;
+    unsigned char* sO = smem + RB * (rsy + rsx) + 32 * 16 * 2 * 6 + 64;             // [RB][KO] bf16 (after the over-read slack)
+    unsigned char* sR = sO + RB * rso;                                               // [2][RB][K] bf16
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wa = wave / WB, wb = wave % WB;
+    const int ny8 = p.N >> 3, nx8 = p.K >> 3;
+    const int nch = nchy + nchx + nchr;
+    const bool has_r = q.R != nullptr;
+
+    f32x4_t acc[AF][BF];
+#pragma unroll
+    for (int i = 0; i < AF; ++i)
+#pragma unroll
+        for (int j = 0; j < BF; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    // this wave's slice of Wt as MFMA B fragments: lane (i = l & 15, g = l >> 4) holds Wt[wave * 16 + i][ks * 32 + g * 8 .. + 7]
+    // (zero beyond K rows / N columns: the A fragments over-read the next LDS row there, finite values)
+    bf16x8_t bw[NKS];
+    {
+        const int col = wave * 16 + (lane & 15);
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            const int n0 = ks * 32 + (lane >> 4) * 8;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (wave < KF && col < p.K && n0 < p.N) v = *reinterpret_cast<const uint4*>(q.Wt + (long long)col * q.ldwt + n0);   // (N % 8 == 0: whole chunks)
+            bw[ks] = __builtin_bit_cast(bf16x8_t, v);
+        }
+    }
+
+    // chunk slots: dY slots, then X slots, then residual slots (uniform per slot).  meta = row | chunk << 12
+    unsigned meta[MAXCH];
+#pragma unroll
+    for (int i = 0; i < MAXCH; ++i) {
+        meta[i] = 0xfffu;
+        int c = -1, per = 1;
+        if (i < nchy) { c = tid + i * 256; per = ny8; if (c >= RB * ny8) c = -1; }
+        else if (i < nchy + nchx) { c = tid + (i - nchy) * 256; per = nx8; if (c >= RB * nx8) c = -1; }
+        else if (i < nch) { c = tid + (i - nchy - nchx) * 256; per = nx8; if (c >= RB * nx8 || !has_r) c = -1; }
+        if (c >= 0) { const int row = c / per; meta[i] = (unsigned)row | ((unsigned)(c - row * per) << 12); }
+    }
+    const long long nsteps = (p.M + RB - 1) / RB;
+    uint4 regs[MAXCH];
+    auto load_step = [&](long long s) {
+        const long long m0 = s * RB;
+        const int rows = (int)(p.M - m0 < RB ? p.M - m0 : RB);
+        const char* yb = reinterpret_cast<const char*>(p.dY + m0 * p.lddy);
+        const char* xb = reinterpret_cast<const char*>(p.X + m0 * p.ldx);
+        const char* rb_ = has_r ? reinterpret_cast<const char*>(q.R + m0 * q.ldr) : xb;
+        const unsigned ldyb = (unsigned)p.lddy * 2u, ldxb = (unsigned)p.ldx * 2u, ldrb = has_r ? (unsigned)q.ldr * 2u : ldxb;
+#pragma unroll
+        for (int i = 0; i < MAXCH; ++i) {
+            if (i < nch) {                                 // unconditional loads (rows past the end re-read row 0, zeroed at the store)
+                const unsigned row = meta[i] & 0xfffu, cc = meta[i] >> 12;
+                const unsigned r = (int)row < rows ? row : 0u;
+                const bool isy = i < nchy, isx = !isy && i < nchy + nchx;
+                const unsigned off = r * (isy ? ldyb : (isx ? ldxb : ldrb)) + (row == 0xfffu ? 0u : cc * 16u);
+                regs[i] = *reinterpret_cast<const uint4*>((isy ? yb : (isx ? xb : rb_)) + off);
+            }
+        }
+    };
+    auto store_step = [&](long long s, int par) {
+        __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0) (keeps the compiler from draining the NEXT step's loads early)
+        const long long m0 = s * RB;
+        const int rows = (int)(p.M - m0 < RB ? p.M - m0 : RB);
+#pragma unroll
+        for (int i = 0; i < MAXCH; ++i) {
+            if (i < nch && (meta[i] & 0xfffu) != 0xfffu) {
+                const int row = (int)(meta[i] & 0xfffu), cc8 = (int)(meta[i] >> 12) * 8;
+                const uint4 v = row < rows ? regs[i] : make_uint4(0u, 0u, 0u, 0u);
+                unsigned char* dst = i < nchy ? sY + row * rsy : (i < nchy + nchx ? sX + row * rsx : sR + (par * RB + row) * rsx);
+                *reinterpret_cast<uint4*>(dst + cc8 * 2) = v;
+            }
+        }
+    };
+    // dX rows of step s (computed into sO during iteration s): + residual, 16-byte rows to global
+    auto flush_out = [&](long long s, int par) {
+        const long long m0 = s * RB;
+        const int rows = (int)(p.M - m0 < RB ? p.M - m0 : RB);
+        for (int c = tid; c < RB * nx8; c += 256) {
+            const int row = c / nx8, cc8 = (c - row * nx8) * 8;
+            if (row >= rows) continue;
+            uint4 v = *reinterpret_cast<const uint4*>(sO + row * rso + cc8 * 2);
+            if (has_r) {
+                const uint4 rv = *reinterpret_cast<const uint4*>(sR + (par * RB + row) * rsx + cc8 * 2);
+                float a[8], b[8];
+                unpack8(v, a); unpack8(rv, b);
+#pragma unroll
+                for (int t = 0; t < 8; ++t) a[t] += b[t];
+                v = pack8(a);
+            }
+            *reinterpret_cast<uint4*>(q.dX + (m0 + row) * q.lddx + cc8) = v;
+        }
+    };
+
+    long long s = blockIdx.x;
+    int par = 0;
+    long long s_prev = -1;
+    if (s < nsteps) load_step(s);
+    for (; s < nsteps; s += gridDim.x, par ^= 1) {
+        __syncthreads();                       // previous step's fragment reads and its dX tile are complete
+        if (s_prev >= 0) flush_out(s_prev, par ^ 1);
+        store_step(s, par);
+        __syncthreads();
+        if (s + gridDim.x < nsteps) load_step(s + gridDim.x);
+        // ---- weight gradient: dW += dY^T x  (as wgrad_rows_kernel)
+        for (int ks = 0; ks < RB / 32; ++ks) {
+            bf16x8_t a[AF], b[BF];
+#pragma unroll
+            for (int i = 0; i < AF; ++i) a[i] = tr_frag(sY, rsy, ks * 32, (wa * AF + i) * 16, lane);
+#pragma unroll
+            for (int j = 0; j < BF; ++j) b[j] = tr_frag(sX, rsx, ks * 32, (wb * BF + j) * 16, lane);
+#pragma unroll
+            for (int i = 0; i < AF; ++i)
+#pragma unroll
+                for (int j = 0; j < BF; ++j) acc[i][j] = MC_MFMA_16x16x32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        // ---- data gradient: dX[:, wave * 16 .. + 15] = dY . Wt^T
+        if (wave < KF) {
+            f32x4_t o[RF];
+#pragma unroll
+            for (int rf = 0; rf < RF; ++rf) o[rf] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+            const unsigned char* arow = sY + (lane & 15) * rsy + (lane >> 4) * 16;
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+#pragma unroll
+                for (int rf = 0; rf < RF; ++rf) {
+                    const bf16x8_t af_ = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(arow + rf * 16 * rsy + ks * 64));
+                    o[rf] = MC_MFMA_16x16x32(af_, bw[ks], o[rf], 0, 0, 0);
+                }
+            }
+            // C layout: o[rf][r] = dX[rf * 16 + (lane >> 4) * 4 + r][wave * 16 + (lane & 15)]
+            bf16_t* so = reinterpret_cast<bf16_t*>(sO);
+#pragma unroll
+            for (int rf = 0; rf < RF; ++rf)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) so[(rf * 16 + (lane >> 4) * 4 + r) * KO + wave * 16 + (lane & 15)] = f2bf(o[rf][r]);
+        }
+        s_prev = s;
+    }
+    __syncthreads();
+    if (s_prev >= 0) flush_out(s_prev, par ^ 1);
+    float* W = p.ws + (long long)blockIdx.x * p.N * p.K;
+#pragma unroll
+    for (int i = 0; i < AF; ++i)
+#pragma unroll
+        for (int j = 0; j < BF; ++j) {
+            const int k = (wb * BF + j) * 16 + (lane & 15);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = (wa * AF + i) * 16 + (lane >> 4) * 4 + r;
+                if (n < p.N && k < p.K) W[(long long)n * p.K + k] = acc[i][j][r];
+            }
+        }
+}
+
 }  // namespace
 
 static void wave_split(int n, int k, int* WA, int* WB, int* af, int* bfn) {
@@ -256,6 +435,62 @@ extern "C" int mc_wgrad_rows_bf16(const mc_wgrad_rows_args* a, void* stream) {
     WG_CASE(6, 1) WG_CASE(6, 2) WG_CASE(6, 3) WG_CASE(6, 4)
     { MC_CHECK(false, "wgrad_rows: internal: no instantiation"); }
 #undef WG_CASE
+    MC_LAUNCH_CHECK();
+    long long nk = (long long)p.N * p.K;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(mc_div_up(nk, 16)), dim3(256), 0, st, p.ws, blocks, nk, p.dW, p.accumulate);
+    MC_LAUNCH_CHECK();
+    return MC_OK;
+}
+
+// ---- fused backward (weight + data gradient) of the row-streaming 1x1 convolutions, see xbwd_rows_kernel
+struct XbwdCfg { int af, bf, nks, rf; };
+static bool xbwd_cfg(int n, int k, XbwdCfg* c) {
+    if (!mc_wgrad_rows_supported(n, k) || k > 64) return false;
+    int WA, WB;
+    wave_split(n, k, &WA, &WB, &c->af, &c->bf);
+    c->nks = (n + 31) / 32;
+    // rows per step = 16 rf: 32 where the registers are short (N = 384: 96 accumulators + 48 of Wt), 128 for the narrow
+    // tensors (a 64-row step of N = 144 is 21 KB: too few bytes in flight per CU -- measured 3.8 TB/s)
+    c->rf = n + k > 320 ? 2 : (n + k <= 176 ? 8 : 4);
+    // the instantiations below: EfficientNet-B5 (144,24) (240,40) (384,64), -B2 (96,16) (144,24) (288,48)
+    return (c->af == 3 && c->bf == 2 && c->nks == 5) || (c->af == 4 && c->bf == 3 && c->nks == 8) || (c->af == 6 && c->bf == 4 && c->nks == 12) ||
+           (c->af == 2 && c->bf == 1 && c->nks == 3) || (c->af == 5 && c->bf == 3 && c->nks == 9);
+}
+extern "C" int mc_xbwd_rows_supported(int n, int k) { XbwdCfg c; return xbwd_cfg(n, k, &c) ? 1 : 0; }
+extern "C" int mc_xbwd_rows_blocks(long long m) {
+    long long steps = (m + 31) / 32;
+    long long b = steps < 512 ? steps : 512;
+    return (int)(b < 1 ? 1 : b);
+}
+
+extern "C" int mc_xbwd_rows_bf16(const mc_wgrad_rows_args* a, const mc_bf16* wt, long long ldwt, mc_bf16* dx, long long lddx,
+                                 const mc_bf16* r, long long ldr, void* stream) {
+    const mc_wgrad_rows_args& p = *a;
+    MC_CHECK(p.dY && p.X && p.dW && p.ws && p.M > 0 && wt && dx, "xbwd_rows: bad args");
+    XbwdCfg c;
+    MC_CHECK(xbwd_cfg(p.N, p.K, &c), "xbwd_rows: unsupported shape (see mc_xbwd_rows_supported)");
+    MC_CHECK(!p.pro_scale && !p.pro_shift && !p.pro_gate, "xbwd_rows: no prologue on x (the expand conv's input is stored activated)");
+    MC_CHECK(p.lddy % 8 == 0 && p.ldx % 8 == 0 && ldwt % 8 == 0 && lddx % 8 == 0 && (!r || ldr % 8 == 0) && mc_aligned16(p.dY) && mc_aligned16(p.X) &&
+             mc_aligned16(wt) && mc_aligned16(dx) && (!r || mc_aligned16(r)), "xbwd_rows: alignment");
+    hipStream_t st = (hipStream_t)stream;
+    int WA, WB, af, bfn;
+    wave_split(p.N, p.K, &WA, &WB, &af, &bfn);
+    const int RB = 16 * c.rf;
+    const long long steps = (p.M + RB - 1) / RB;
+    const long long cap = mc_xbwd_rows_blocks(p.M);
+    const int blocks = (int)(steps < cap ? steps : cap);
+    const int nchy = (RB * (p.N / 8) + 255) / 256, nchx = (RB * (p.K / 8) + 255) / 256, nchr = r ? nchx : 0;
+    const int KO = ((p.K + 15) / 16) * 16;
+    const size_t lds = (size_t)RB * (p.N + p.K) * 2 + 32 * 16 * 2 * 6 + 64 + (size_t)RB * KO * 2 + (size_t)2 * RB * p.K * 2;
+    xbwd_extra q;
+    q.Wt = wt; q.ldwt = ldwt; q.dX = dx; q.lddx = lddx; q.R = r; q.ldr = ldr;
+    // (MAXCH = 16-byte chunks per thread and step, dY + x + residual slots: sized per instantiation -- every slot is 4 + 1 VGPRs)
+#define XB_CASE(A_, B_, N_, R_, CH_) if (c.af == A_ && c.bf == B_ && c.nks == N_ && c.rf == R_) { \
+        MC_CHECK(nchy + nchx + nchr <= CH_, "xbwd_rows: internal: step too large");               \
+        hipLaunchKernelGGL((xbwd_rows_kernel<A_, B_, CH_, N_, R_>), dim3(blocks), dim3(256), lds, st, p, q, WB, nchy, nchx, nchr); } else
+    XB_CASE(3, 2, 5, 8, 14) XB_CASE(4, 3, 8, 4, 12) XB_CASE(6, 4, 12, 2, 8) XB_CASE(2, 1, 3, 8, 8) XB_CASE(5, 3, 9, 2, 8)
+    { MC_CHECK(false, "xbwd_rows: internal: no instantiation"); }
+#undef XB_CASE
     MC_LAUNCH_CHECK();
     long long nk = (long long)p.N * p.K;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(mc_div_up(nk, 16)), dim3(256), 0, st, p.ws, blocks, nk, p.dW, p.accumulate);

@@ -117,6 +117,9 @@ _SIGS = {
     "mc_wgrad_rows_supported": ([I, I], I),
     "mc_wgrad_rows_blocks": ([LL], I),
     "mc_wgrad_rows_bf16": ([C.POINTER(WgradRowsArgs), P], I),
+    "mc_xbwd_rows_supported": ([I, I], I),
+    "mc_xbwd_rows_blocks": ([LL], I),
+    "mc_xbwd_rows_bf16": ([C.POINTER(WgradRowsArgs), P, LL, P, LL, P, LL, P], I),
     "mc_cast_f32_bf16": ([P, P, LL, P], I),
     "mc_cast_bf16_f32": ([P, P, LL, P], I),
     "mc_cast_f32_bf16_lo": ([P, P, LL, P], I),

@@ -417,6 +417,34 @@ def _linear_wgrad_impl(dy, x, pro=None, out=None, tag=""):
     return dw
 
 
+FUSE_XBWD = os.environ.get("MC_FUSE_XBWD", "1") != "0"       # expand conv backward: weight + data gradient from one pass (xbwd_rows)
+
+
+def xbwd_rows_ok(M, n_out, k_in):
+    """does ONE launch give both gradients of the 1x1 conv [M, k_in] -> [M, n_out] (mc_xbwd_rows_bf16)?"""
+    return FUSE_XBWD and M >= ROWS_MIN_M and bool(L.load().mc_xbwd_rows_supported(n_out, k_in))
+
+
+def xbwd_rows(dy, x, w_t, residual=None):
+    """(dx [M, K] bf16 = dy . w_t^T (+ residual), dw [N, K] f32 = dy^T x) from ONE pass over dy [M, N]: the data gradient of
+    ``linear_dgrad(dy, ., residual, w_t=w_t)`` and the weight gradient of ``linear_wgrad(dy, x)`` of a 1x1 convolution whose
+    output gradient is the wide tensor (expand conv; gemm_wgrad_rows.hip xbwd_rows_kernel).  w_t: [K, N] bf16."""
+    M, N = dy.shape
+    K = x.shape[1]
+    assert w_t.shape == (K, N) and x.shape[0] == M
+    a = L.WgradRowsArgs()
+    a.dY, a.N, a.lddy = _p(dy), N, dy.stride(0)
+    a.X, a.K, a.ldx, a.M = _p(x), K, x.stride(0), M
+    dw = empty((N, K), torch.float32, dy)
+    ws = empty((L.load().mc_xbwd_rows_blocks(M), N, K), torch.float32, dy)
+    a.dW, a.ws, a.accumulate = _p(dw), _p(ws), 0
+    dx = empty((M, K), BF16, dy)
+    _note(2 * M * (N + 2 * K) + (2 * M * K if residual is not None else 0) + 4 * N * K, 4 * M * N * K)
+    L.call("mc_xbwd_rows_bf16", C.byref(a), _p(w_t), w_t.stride(0), _p(dx), dx.stride(0), _p(residual),
+           residual.stride(0) if residual is not None else 0, _st(), kind="xbwd_rows")
+    return dx, dw
+
+
 def colsum(x, out=None, accumulate=False):
     """out[c] (+)= sum_m x[m,c]  (bf16 in, fp32 out)"""
     M, Cn = x.shape
@@ -783,7 +811,8 @@ def bn_fold_expand_bwd(dz, x, we_f32, we_bf16, coef, dbeta, rows, residual=None)
     (dx [rows, cin] bf16 (+ residual), dWe [cexp, cin] fp32).  Neither e nor de is read or written: the BatchNorm
     backward's linear combination lives in the small folded operands (A.We, G = We^T diag(B) We, Sxx)."""
     n, k = we_f32.shape
-    t1 = linear_wgrad(dz, x)                               # dz^T x   [cexp, cin]
+    fused = xbwd_rows_ok(x.shape[0], n, k)                  # round 5: dz is read ONCE for both of its GEMMs (below)
+    t1 = None if fused else linear_wgrad(dz, x)            # dz^T x   [cexp, cin]
     xtx = linear_wgrad(x, x, tag="_xtx")                   # x^T x    [cin, cin]
     cs = colsum(x)
     w1t, wb, sxx = empty((k, n), BF16, x), empty((n, k), BF16, x), empty((k, k), BF16, x)
@@ -799,7 +828,10 @@ def bn_fold_expand_bwd(dz, x, we_f32, we_bf16, coef, dbeta, rows, residual=None)
         r = empty((x.shape[0], k), BF16, x)
         gemm(x, gtb, r, x.shape[0], k, k, x.stride(0), k, k, bias=cvec, R=residual,
              ldr=(residual.stride(0) if residual is not None else 0), alpha=1.0 / float(rows), kind="fwd_fold")
-    dx = linear_dgrad(dz, we_bf16, residual=r, w_t=w1t)    # + dz (A.We)
+    if fused:
+        dx, t1 = xbwd_rows(dz, x, w1t, residual=r)         # dz (A.We) + r   and   dz^T x   from one pass over dz
+    else:
+        dx = linear_dgrad(dz, we_bf16, residual=r, w_t=w1t)    # + dz (A.We)
     wx = empty((n, k), torch.float32, x)
     gemm(wb, sxx, wx, n, k, k, k, k, k, c_f32=1, kind="fold")      # (B.We) Sxx  (Sxx symmetric)
     dwe = t1

@@ -981,6 +981,31 @@ def test_dwconv_lane_form_epilogue_equals_marching_form(k, n, h, w, c):
     assert float(((s0 - s1).abs() / scale).max()) <= 2e-4, "BatchNorm-backward partials"
 
 
+@pytest.mark.parametrize("M,N,K", [(9000, 144, 24), (20000, 240, 40), (8200, 384, 64), (8192, 96, 16), (12345, 288, 48), (70001, 240, 40)])
+@pytest.mark.parametrize("with_res", [False, True])
+def test_xbwd_rows_both_gradients_from_one_pass(M, N, K, with_res):
+    """Round 5: mc_xbwd_rows_bf16 -- weight gradient dW = dY^T x AND data gradient dX = dY . Wt^T (+ R) of a 1x1 convolution
+    from one pass over dY [ref: backward of efficientnet_custom.py:104] -- against the two launches it replaces (the same MFMA
+    products in the same per-row order: dX identical to mc_gemm_rows_bf16 up to one 16-bit ulp of the rounding of the sum with
+    the residual; dW to the fp32 summation order) and against fp32 torch.  Ragged row counts: the last step is partial."""
+    assert ops.xbwd_rows_ok(M, N, K)
+    dy, x = rnd(M, N, seed=1), rnd(M, K, seed=2)
+    w = rnd(N, K, seed=3, scale=K ** -0.5)                     # W [N, K]; the data gradient's operand is W^T
+    w_t = w.t().contiguous()
+    res = rnd(M, K, seed=4) if with_res else None
+    dx_sep = ops.linear_dgrad(dy, w, residual=res, w_t=w_t)
+    dw_sep = ops.linear_wgrad(dy, x)
+    for _ in range(2):
+        dx, dw = ops.xbwd_rows(dy, x, w_t, residual=res)
+    torch.cuda.synchronize()
+    ref_dx = dy.float() @ w.float() + (res.float() if with_res else 0.0)
+    check(dx, ref_dx, 1e-2, "dX vs fp32")
+    check(dx, dx_sep.float(), 8e-3, "dX vs the row-streaming data gradient")
+    ref_dw = dy.float().t() @ x.float()
+    check(dw, ref_dw, 2e-3, "dW vs fp32")
+    assert float((dw - dw_sep).abs().max()) <= 2e-4 * float(dw_sep.abs().max()), "dW vs the row-streaming weight gradient"
+
+
 FUSED_CASES = [  # n, h, w, c: several strips per row (w > 62), image groups (w <= 30 / 14), ragged channel tiles, tiny maps
     (2, 70, 300, 48), (3, 33, 59, 24), (5, 95, 57, 72), (33, 48, 29, 64), (9, 7, 9, 24), (2, 40, 33, 240), (1, 200, 62, 40),
     (70, 600, 40, 32)]   # > 128 blocks per workgroup: the descriptor ring is refilled
