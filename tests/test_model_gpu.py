@@ -353,12 +353,17 @@ def test_hot_loop_trajectory_vs_reference():
         cos = float(torch.nn.functional.cosine_similarity(d, r, dim=0))
         rep[k] = (round(cos, 3), round(float(d.norm()) / float(r.norm()), 3))
     print("trajectory", dict(hip=losses, ref=list(ref)), rep)
+    # Adam's early updates are ~ lr * sign(g): elements whose gradient is below the bf16 noise floor flip sign, so the
+    # direction agrees on the bulk (cos) and the step LENGTH (set by lr, weight decay and the schedule) is exact.
+    # Per-parameter floors from the measured values (round 5; bf16 build: logit_scale 1.0, image projection 0.721,
+    # text projection bias 0.794, stem _bn0.weight 0.664 (0.61 in round 4), head conv 0.674, BERT layer-11 output bias 0.781;
+    # length ratios 0.97 .. 1.03) minus ~0.07; parameters a new fixture might add fall back to the old global floor
+    floors = {"logit_scale": 0.95, "image_projection.projection.weight": 0.65, "text_projection.projection.bias": 0.72,
+              "image_encoder._bn0.weight": 0.57, "image_encoder._conv_head.weight": 0.60,
+              "text_encoder.text_encoder.encoder.layer.11.output.dense.bias": 0.71}
     for k, (cos, ratio) in rep.items():
-        # Adam's early updates are ~ lr * sign(g): elements whose gradient is below the bf16 noise floor flip sign, so the
-        # direction agrees on the bulk (cos) and the step LENGTH (set by lr, weight decay and the schedule) is exact
-        # (measured on MI355X, round 4: cosines 0.61 (_bn0.weight) .. 1.0, length ratios 0.98 .. 1.021)
-        assert cos >= 0.55, (k, cos)
-        assert abs(ratio - 1.0) <= 0.08, (k, ratio)
+        assert cos >= floors.get(k, 0.55), (k, cos)
+        assert abs(ratio - 1.0) <= 0.05, (k, ratio)
 
 
 def test_evaluator_entry_points(tmp_path):
