@@ -94,7 +94,7 @@ constexpr int NDESC = 128;
 // expanded tensor instead of 5 (MODE 1: dd + e read, dZ0 written; MODE 2: dd + e read).
 template <int K, int S, int NCOL, int MODE, int G>
 __global__ __launch_bounds__(1024, 4) void dwconv_lane_fwd_kernel(const mc_dwconv_args p, int strips, int nunits, int cpairs,
-                                                                  int ctiles, int ymax) {
+                                                                  int ctiles, int ymax, int xmap) {
     using C = Cfg<K, S, NCOL, G>;
     constexpr bool FUSED = MODE == 3;
     constexpr bool EPI = MODE == 1 || FUSED, BWW = MODE == 2, ETILE = EPI || BWW;       // ETILE: a second global tensor staged beside the input
@@ -109,7 +109,13 @@ __global__ __launch_bounds__(1024, 4) void dwconv_lane_fwd_kernel(const mc_dwcon
     // ---- workgroup -> (channel tile, virtual-row range); the two tiles of a 128-byte line share an XCD (block id % 8)
     const int bid = blockIdx.x;
     const int xcd = bid & 7, rr = bid >> 3;
-    const int member = rr & 1, unit = (rr >> 1) * 8 + xcd;
+    // xmap (round 5): units are (y slot, tile pair) with the pair index fastest; an XCD runs a CONTIGUOUS range of them, i.e.
+    // neighbouring channel tiles of the same rows meet in one L2.  Pixels whose byte pitch is not a multiple of 128 (c = 240:
+    // 480 bytes, c = 1056, 1824: odd multiples of 64) put 64-byte tile pieces of up to three tiles into one 128-byte line; with
+    // only the two tiles of a pair sharing an L2 (unit % 8 -> XCD) the c = 240 launches fetched 1.8 x their algorithmic bytes
+    // from HBM (profiles/r05_cfg3_pmc_by_kernel.csv): forward 0.911 -> 0.722 ms, weight gradient 0.833 -> 0.620 ms
+    const int member = rr & 1;
+    const int unit = xmap ? xcd * xmap + (rr >> 1) : (rr >> 1) * 8 + xcd;      // xmap = units per XCD: XCD x runs units [x * xmap, (x + 1) * xmap)
     if (unit >= nunits) return;
     const int cpair = unit % cpairs, yslot = unit / cpairs;
     const int ycp = (nunits - cpair + cpairs - 1) / cpairs;          // y slots of this tile pair
@@ -602,7 +608,8 @@ done:
     }
 }
 
-struct Plan { int strips, nunits, cpairs, ctiles, ymax, grid; };
+struct Plan { int strips, nunits, cpairs, ctiles, ymax, grid, xmap; };
+static int xmap_mode() { static const int m = [] { const char* e = getenv("MC_LANE_XMAP"); return e ? atoi(e) : 1; }(); return m; }
 template <typename C> Plan plan(const mc_dwconv_args& p) {
     Plan m;
     m.strips = C::G_ > 1 ? 1 : mc_div_up(p.ow, C::TOW);             // (image groups: the map fits one segment)
@@ -617,6 +624,8 @@ template <typename C> Plan plan(const mc_dwconv_args& p) {
     m.nunits = (int)nunits;
     m.ymax = (m.nunits + m.cpairs - 1) / m.cpairs;
     m.grid = 16 * ((m.nunits + 7) / 8);
+    // contiguous unit ranges per XCD (see the kernel) where the units divide evenly over the 8 XCDs; else unit % 8 -> XCD
+    m.xmap = (xmap_mode() && m.nunits % 8 == 0) ? m.nunits / 8 : 0;
     return m;
 }
 
@@ -627,7 +636,7 @@ template <typename C, int MODE> int launch(const mc_dwconv_args& p, hipStream_t 
     static_assert(lds <= 160 * 1024, "LDS budget");
     MC_SET_MAX_LDS(attr_done, kern, lds);
     const Plan m = plan<C>(p);
-    hipLaunchKernelGGL(kern, dim3(m.grid), dim3(C::NT), lds, st, p, m.strips, m.nunits, m.cpairs, m.ctiles, m.ymax);
+    hipLaunchKernelGGL(kern, dim3(m.grid), dim3(C::NT), lds, st, p, m.strips, m.nunits, m.cpairs, m.ctiles, m.ymax, m.xmap);
     MC_LAUNCH_CHECK();
     return MC_OK;
 }

@@ -16,6 +16,7 @@ SHAPES = [  # (batch, M, N, K, what)
     (1, 44544, 3072, 512, "expand 512->3072"), (1, 44544, 512, 3072, "dgrad 3072->512"), (1, 44544, 2048, 512, "head"),
     (32, 1392, 304, 1824, "project (gated weights) x32 img"), (32, 5415, 176, 1056, "project 1056->176 x32 img"),
     (1, 173280, 176, 1056, "dgrad 1056->176"), (1, 173280, 128, 768, "dgrad 768->128"),
+    (1, 173280, 1056, 176, "expand 176->1056 @95x57 x32"), (1, 173280, 768, 128, "expand 128->768 @95x57 x32"),
     (1, 8192, 2304, 768, "BERT qkv b32"), (1, 16384, 2304, 768, "BERT qkv b64"), (1, 16384, 768, 768, "BERT out b64"),
     (1, 16384, 3072, 768, "BERT ffn1 b64"), (1, 16384, 768, 3072, "BERT ffn2 b64"),
     (1, 4096, 4096, 4096, "4096^3"), (1, 8192, 8192, 8192, "8192^3")]

@@ -1,0 +1,73 @@
+# Round-5 rocprofv3 evidence (run on the GPU box through gpurun); everything lands in gpurun_out/prof_r5/.
+#   usage: bash scripts/profile_round5.sh [stats|pmc|cfg4]   (default: stats = kernel trace + stats of one cfg3 step)
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=/root/repo
+OUT=$R/gpurun_out/prof_r5; mkdir -p $OUT
+MODE=${1:-stats}
+C4="python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline"
+C3="python $R/bench.py --workload cfg3 --steps 1 --warmup 1 --no-cpu-baseline"
+if [ "$MODE" = "stats" ] || [ "$MODE" = "all" ]; then
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_c3 -- $C3 > $OUT/c3.log 2>&1
+  cp $(ls /tmp/p_c3/*/*kernel_stats.csv | head -1) $OUT/cfg3_kernel_stats.csv
+  cp $(ls /tmp/p_c3/*/*agent_info.csv | head -1) $OUT/agent_info.csv
+fi
+if [ "$MODE" = "cfg4" ] || [ "$MODE" = "all" ]; then
+  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_c4 -- $C4 > $OUT/c4.log 2>&1
+  cp $(ls /tmp/p_c4/*/*kernel_stats.csv | head -1) $OUT/cfg4_kernel_stats.csv
+fi
+if [ "$MODE" = "pmc" ] || [ "$MODE" = "all" ]; then
+  i=0
+  for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES"; do
+    i=$((i+1))
+    timeout 900 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d /tmp/p_pmc$i -- $C3 > $OUT/pmc$i.log 2>&1
+    f=$(ls /tmp/p_pmc$i/*/*counter_collection.csv 2>/dev/null | head -1)
+    [ -z "$f" ] && { echo "pass $i produced no counters"; tail -3 $OUT/pmc$i.log; continue; }
+    python - "$f" "$OUT/cfg3_pmc_$(echo $grp | cut -d' ' -f1).csv" <<'PY'
+import csv, sys, collections
+agg = collections.OrderedDict()
+for r in csv.DictReader(open(sys.argv[1])):
+    k = (r['Kernel_Name'], r['Counter_Name'])
+    a = agg.setdefault(k, [0, 0.0])
+    a[0] += 1; a[1] += float(r['Counter_Value'])
+with open(sys.argv[2], 'w') as f:
+    w = csv.writer(f); w.writerow(['kernel', 'counter', 'launches', 'sum', 'avg'])
+    for (k, c), (n, s) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        w.writerow([k, c, n, s, s / n])
+PY
+  done
+fi
+if [ "$MODE" = "pmc4" ]; then
+  # HBM traffic of the DEFAULT run's launch mix (cfg4: 32 micro-batches, re-forwards): FETCH_SIZE / WRITE_SIZE passes.
+  # NOT part of `all`: with ~300 000 dispatches per run a counter pass does not finish in 20 minutes (tried in round 4: both
+  # passes hit their timeouts) -- bench.py labels the cfg3-mix traffic instead (`roofline.traffic_source`)
+  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_c4 -- $C4 > $OUT/c4.log 2>&1
+  cp $(ls /tmp/p_c4/*/*kernel_stats.csv | head -1) $OUT/cfg4_kernel_stats.csv
+  i=0
+  for grp in "FETCH_SIZE" "WRITE_SIZE"; do
+    i=$((i+1))
+    timeout 1200 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d /tmp/p4_pmc$i -- $C4 > $OUT/pmc4_$i.log 2>&1
+    f=$(ls /tmp/p4_pmc$i/*/*counter_collection.csv 2>/dev/null | head -1)
+    [ -z "$f" ] && { echo "pass $i produced no counters"; tail -3 $OUT/pmc4_$i.log; continue; }
+    python - "$f" "$OUT/cfg4_pmc_$grp.csv" <<'PY'
+import csv, sys, collections
+agg = collections.OrderedDict()
+for r in csv.DictReader(open(sys.argv[1])):
+    k = (r['Kernel_Name'], r['Counter_Name'])
+    a = agg.setdefault(k, [0, 0.0])
+    a[0] += 1; a[1] += float(r['Counter_Value'])
+with open(sys.argv[2], 'w') as f:
+    w = csv.writer(f); w.writerow(['kernel', 'counter', 'launches', 'sum', 'avg'])
+    for (k, c), (n, s) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        w.writerow([k, c, n, s, s / n])
+PY
+  done
+fi
+if [ "$MODE" = "dw" ] || [ "$MODE" = "all" ]; then
+  # SQ counters of the depthwise kernels (one launch per shape and kernel, scripts/pmc_dw.py): VALU activity, resident waves,
+  # wait classes -- the evidence behind "VALU-issue bound" (marching 5x5) vs "four waves per SIMD" (lane = column form)
+  bash $R/scripts/pmc_run.sh "python $R/scripts/pmc_dw.py" "dwconv" \
+     "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" \
+     "GRBM_GUI_ACTIVE SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
+     "FETCH_SIZE" "WRITE_SIZE" > $OUT/dw_pmc.txt 2>&1
+fi
+ls -la $OUT
