@@ -420,9 +420,17 @@ def _linear_wgrad_impl(dy, x, pro=None, out=None, tag=""):
 FUSE_XBWD = os.environ.get("MC_FUSE_XBWD", "1") != "0"       # expand conv backward: weight + data gradient from one pass (xbwd_rows)
 
 
+_XBWD_OK = {}
+
+
 def xbwd_rows_ok(M, n_out, k_in):
     """does ONE launch give both gradients of the 1x1 conv [M, k_in] -> [M, n_out] (mc_xbwd_rows_bf16)?"""
-    return FUSE_XBWD and M >= ROWS_MIN_M and bool(L.load().mc_xbwd_rows_supported(n_out, k_in))
+    if not FUSE_XBWD or M < ROWS_MIN_M:
+        return False
+    hit = _XBWD_OK.get((n_out, k_in))
+    if hit is None:
+        hit = _XBWD_OK[(n_out, k_in)] = bool(L.load().mc_xbwd_rows_supported(n_out, k_in))
+    return hit
 
 
 def xbwd_rows(dy, x, w_t, residual=None):
@@ -620,14 +628,22 @@ def _dw_fused_args(dd, w_kkc_flipped, n, h, w, c, k, pad_l, pad_t, oh, ow, e, st
     return a
 
 
+_FUSED_OK = {}
+
+
 def dwconv_bwd_fused_ok(n, h, w, c, k, stride, pad_l, pad_t, oh, ow, force=False):
-    """does the fused backward launch (mc_dwconv_bwd_fused) take / win this stride-1 conv?  (pointers are not looked at)"""
+    """does the fused backward launch (mc_dwconv_bwd_fused) take / win this stride-1 conv?  (pointers are not looked at; the
+    answer is a function of the geometry alone and is cached: the launch-bound configurations notice every ctypes call)"""
     if stride != 1:
         return False
-    a = _dw_args(n, oh, ow, c, k, 1, k - 1 - pad_l, k - 1 - pad_t, h, w)
-    a.epi_x = 16                                    # any non-null value: only looked at
-    lib_ = L.load()
-    return bool(lib_.mc_dwconv_bwd_fused_supported(C.byref(a)) if force else lib_.mc_dwconv_bwd_fused_preferred(C.byref(a)))
+    key = (n, h, w, c, k, pad_l, pad_t, oh, ow, force)
+    hit = _FUSED_OK.get(key)
+    if hit is None:
+        a = _dw_args(n, oh, ow, c, k, 1, k - 1 - pad_l, k - 1 - pad_t, h, w)
+        a.epi_x = 16                                    # any non-null value: only looked at
+        lib_ = L.load()
+        hit = _FUSED_OK[key] = bool(lib_.mc_dwconv_bwd_fused_supported(C.byref(a)) if force else lib_.mc_dwconv_bwd_fused_preferred(C.byref(a)))
+    return hit
 
 
 def dwconv_bwd_fused(dd, e, st, w_kkc_flipped, n, h, w, c, k, pad_l, pad_t, oh, ow):

@@ -36,6 +36,33 @@ with open(sys.argv[2], 'w') as f:
 PY
   done
 fi
+if [ "$MODE" = "pmc4s" ]; then
+  # HBM traffic on the DEFAULT run's launch mix, sampled: 128 pairs as 4 micro-batches with ONE kept graph = 4
+  # graph-less forwards' worth of launches, 3 re-forwards with replayed statistics, 4 backwards -- the per-micro-batch launch mix
+  # of the N = 1 run (25 of 32 micro-batches re-forwarded) at 1 / 8 of its launches, so a counter pass takes minutes
+  C4S="python $R/bench.py --batch 128 --micro-batches 4 --keep-graphs 1 --steps 1 --warmup 1 --no-cpu-baseline --no-n8-load"
+  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_c4s -- $C4S > $OUT/c4s.log 2>&1
+  cp $(ls /tmp/p_c4s/*/*kernel_stats.csv | head -1) $OUT/cfg4_kernel_stats.csv
+  i=0
+  for grp in "FETCH_SIZE" "WRITE_SIZE"; do
+    i=$((i+1))
+    timeout 1200 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d /tmp/p4s_pmc$i -- $C4S > $OUT/pmc4s_$i.log 2>&1
+    f=$(ls /tmp/p4s_pmc$i/*/*counter_collection.csv 2>/dev/null | head -1)
+    [ -z "$f" ] && { echo "pass $i produced no counters"; tail -3 $OUT/pmc4s_$i.log; continue; }
+    python - "$f" "$OUT/cfg4_pmc_$grp.csv" <<'PY'
+import csv, sys, collections
+agg = collections.OrderedDict()
+for r in csv.DictReader(open(sys.argv[1])):
+    k = (r['Kernel_Name'], r['Counter_Name'])
+    a = agg.setdefault(k, [0, 0.0])
+    a[0] += 1; a[1] += float(r['Counter_Value'])
+with open(sys.argv[2], 'w') as f:
+    w = csv.writer(f); w.writerow(['kernel', 'counter', 'launches', 'sum', 'avg'])
+    for (k, c), (n, s) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        w.writerow([k, c, n, s, s / n])
+PY
+  done
+fi
 if [ "$MODE" = "pmc4" ]; then
   # HBM traffic of the DEFAULT run's launch mix (cfg4: 32 micro-batches, re-forwards): FETCH_SIZE / WRITE_SIZE passes.
   # NOT part of `all`: with ~300 000 dispatches per run a counter pass does not finish in 20 minutes (tried in round 4: both
