@@ -37,6 +37,11 @@ PY
   done
 fi
 if [ "$MODE" = "pmc4s" ]; then
+  # !! DO NOT RUN without a short outer timeout.  Tried in round 5: the kernel-trace pass of this command completes, but BOTH
+  # counter passes abort after ~1 minute with "HSA_STATUS_ERROR_INVALID_PACKET_FORMAT: The AQL packet is malformed" inside
+  # rocprofv3's counter service and then hang until their timeout (2 x 20 GPU-minutes lost) -- the micro-batched step under
+  # --pmc is not profilable on this stack (round 4 saw the cfg4 passes "not finish" for the same reason).  bench.py therefore
+  # keeps labelling the cfg3-mix traffic (`roofline.traffic_source`).
   # HBM traffic on the DEFAULT run's launch mix, sampled: 128 pairs as 4 micro-batches with ONE kept graph = 4
   # graph-less forwards' worth of launches, 3 re-forwards with replayed statistics, 4 backwards -- the per-micro-batch launch mix
   # of the N = 1 run (25 of 32 micro-batches re-forwarded) at 1 / 8 of its launches, so a counter pass takes minutes
@@ -46,7 +51,7 @@ if [ "$MODE" = "pmc4s" ]; then
   i=0
   for grp in "FETCH_SIZE" "WRITE_SIZE"; do
     i=$((i+1))
-    timeout 1200 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d /tmp/p4s_pmc$i -- $C4S > $OUT/pmc4s_$i.log 2>&1
+    timeout 240 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d /tmp/p4s_pmc$i -- $C4S > $OUT/pmc4s_$i.log 2>&1
     f=$(ls /tmp/p4s_pmc$i/*/*counter_collection.csv 2>/dev/null | head -1)
     [ -z "$f" ] && { echo "pass $i produced no counters"; tail -3 $OUT/pmc4s_$i.log; continue; }
     python - "$f" "$OUT/cfg4_pmc_$grp.csv" <<'PY'
