@@ -189,6 +189,34 @@ def test_collectives_requirement_is_checked_up_front():
     assert tuple(int(v) for v in torch.__version__.split("+")[0].split(".")[:2]) >= MIN_TORCH
 
 
+def test_round5_host_policies_of_the_library():
+    """pure host functions of the C ABI (no device needed): which shapes the round-5 fused launches take, and the split-K cost
+    model of the TN weight-gradient kernel (values pinned to the sweep in scripts/tn_split_sweep.py)"""
+    import ctypes as C
+    from mammo_clip_amd import lib as L
+    lib = L.load()
+    # expand-conv backward in one pass: the expand geometries of EfficientNet-B2 / -B5, nothing wider than 64 input channels
+    assert all(lib.mc_xbwd_rows_supported(n, k) for n, k in ((96, 16), (144, 24), (240, 40), (288, 48), (384, 64)))
+    assert not any(lib.mc_xbwd_rows_supported(n, k) for n, k in ((768, 128), (528, 88), (100, 20), (384, 96)))
+    # fused depthwise backward: 3x3, stride 1, with the BatchNorm epilogue operands; preferred from 192 channels on the wide
+    # and the narrow maps of the networks
+    def dw(c, k, s, h, w, n=32, epi=True):
+        a = L.DwconvArgs()
+        a.n, a.h, a.w, a.c, a.k, a.stride, a.pad_l, a.pad_t, a.oh, a.ow = n, h, w, c, k, s, (k - 1) // 2, (k - 1) // 2, h, w
+        a.epi_x = 16 if epi else None
+        return a
+    assert lib.mc_dwconv_bwd_fused_supported(C.byref(dw(240, 3, 1, 380, 228))) and lib.mc_dwconv_bwd_fused_preferred(C.byref(dw(240, 3, 1, 380, 228)))
+    assert lib.mc_dwconv_bwd_fused_preferred(C.byref(dw(768, 3, 1, 95, 57))) and lib.mc_dwconv_bwd_fused_preferred(C.byref(dw(3072, 3, 1, 48, 29)))
+    assert lib.mc_dwconv_bwd_fused_supported(C.byref(dw(24, 3, 1, 760, 456))) and not lib.mc_dwconv_bwd_fused_preferred(C.byref(dw(24, 3, 1, 760, 456)))
+    assert not lib.mc_dwconv_bwd_fused_supported(C.byref(dw(384, 5, 1, 190, 114)))          # 5x5: does not fit a wave's registers
+    assert not lib.mc_dwconv_bwd_fused_supported(C.byref(dw(240, 3, 1, 380, 228, epi=False)))
+    assert not lib.mc_dwconv_bwd_fused_supported(C.byref(dw(144, 3, 2, 760, 456)))
+    # TN split-K: round count x K tiles + workspace traffic
+    assert lib.mc_gemm256_tn_splits(512, 3072, 44544, 0) == 8 and lib.mc_gemm256_tn_splits(3072, 512, 44544, 0) == 8
+    assert lib.mc_gemm256_tn_splits(176, 1056, 173280, 0) == 48 and lib.mc_gemm256_tn_splits(304, 1824, 44544, 0) == 16
+    assert lib.mc_gemm256_tn_splits(3072, 768, 16384, 0) == 7 and lib.mc_gemm256_tn_splits(768, 768, 16384, 0) == 24
+
+
 def test_no_cpu_fallback():
     """the product path refuses CPU tensors instead of silently computing somewhere else"""
     model = build_model(_cfg(), {"breast_clip": {}}, types.SimpleNamespace(vocab_size=28996))
