@@ -331,7 +331,8 @@ extern "C" int mc_gemm256_tn_splits(long long M, long long N, long long K, long 
         // units of one K-tile time (~1.55 us per 256 x 256 x 64 step at the kernel's in-loop rate).  Round 5 sweep
         // (scripts/tn_split_sweep.py): 512 x 3072 over 44544 rows ran 204 us with the 32 splits the round count alone asks for
         // (403 MB of partials against 319 MB of operands) and 163 us with 8; every other model shape keeps its choice.
-        const double ws_units = (double)splits * (double)M * (double)N * 8.0 / 4.0e6 / 1.55;
+        // (weight 0.5: with the full term 768 x 768 over 16384 rows moved from 24 to 16 splits, 43 -> 47 us in the same sweep)
+        const double ws_units = 0.5 * (double)splits * (double)M * (double)N * 8.0 / 4.0e6 / 1.55;
         const double cost = (double)rounds * ((double)((ktiles + s - 1) / s) + 6.0) + ws_units;
         if (cost < best_cost * 0.999) { best_cost = cost; best = s; }
     }
