@@ -749,7 +749,8 @@ extern "C" int mc_dwconv_bwd_fused_preferred(const mc_dwconv_args* a) {
     // measured (32 images, two launches under the form policy -> fused, ms): c = 768 at 95x57 0.347 -> 0.286, c = 1824 at 48x29
     // 0.223 -> 0.183, c = 3072 0.460 -> 0.343, c = 240 at 380x228 1.494 -> 1.345 (the whole-pixel marching pair); narrow pixels
     // lose (c = 24 at 760x456: 0.711 -> 1.265 -- 48-byte pixels in 32-channel tiles)
-    return (p.ow >= 50 && p.c >= 192) || (p.ow <= 30 && p.n >= 2 && p.c >= 192);
+    // (B2 at 912 x 912, c = 144 at 228 x 228: forcing the fused form everywhere it is supported 153.7 -> 152.9 ms per cfg2 step)
+    return (p.ow >= 50 && p.c >= 128) || (p.ow <= 30 && p.n >= 2 && p.c >= 128);
 }
 
 extern "C" int mc_dwconv_bwd_weight_lane(const mc_dwconv_args* a, void* stream) {
