@@ -148,6 +148,15 @@ __global__ __launch_bounds__(1024, 4) void dwconv_lane_fwd_kernel(const mc_dwcon
             e_sh = f32x2_t{__uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(p.epi_shift[cl]))),
                            __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(p.epi_shift[cl + 1])))};
         }
+        if constexpr (K == 5) {
+            // Round 5: keep the epilogue's BatchNorm parameters in VECTOR registers where the 50 tap SGPRs fill the scalar file.
+            // The compiler knows they are wave-uniform and holds them in SGPRs otherwise -- and then spills TAPS: the 5x5 data-
+            // gradient instances reloaded spilled taps with 447-585 v_readlane_b32 per kernel body (179 of the 1128 VALU
+            // instructions of an interval); with these six values in VGPRs: 116-136 (ISA counts, scripts/lane_isa_mix.py)
+            asm volatile("v_mov_b32 %0, %0\n\tv_mov_b32 %1, %1" : "+v"(e_mu.x), "+v"(e_mu.y));
+            asm volatile("v_mov_b32 %0, %0\n\tv_mov_b32 %1, %1" : "+v"(e_sc.x), "+v"(e_sc.y));
+            asm volatile("v_mov_b32 %0, %0\n\tv_mov_b32 %1, %1" : "+v"(e_sh.x), "+v"(e_sh.y));
+        }
     }
     if (has_pro && tid < 2 * C::TCH) {
         const int ch = tid % C::TCH;
@@ -186,6 +195,29 @@ __global__ __launch_bounds__(1024, 4) void dwconv_lane_fwd_kernel(const mc_dwcon
         const int pos = (col % NCOL) * 64 + seg * C::LPI + col / NCOL;
         metao[i] = (unsigned)row | ((unsigned)seg << 4) | ((unsigned)col << 8) | ((unsigned)((row * C::TOWP + pos) * C::PXD + vv * 4) << 16);
         if (v >= C::ORB * G * C::TOW * C::VPP || !st_ch) metao[i] = 0xffffu;
+    }
+
+    // element offsets of the thread's vectors inside a block: constants for the whole kernel (round 5: they were re-derived from
+    // `meta` with two v_mul_lo_u32 per vector and interval -- 19 quarter-rate multiplies beside 208 packed FMAs)
+    // (not in the weight-gradient mode: its 50 tap accumulators leave no registers -- measured +4..6 % there, -5..6 % on the
+    // 5x5 data gradient together with the epilogue parameters in VGPRs)
+    constexpr bool PRE = MODE != 2;
+    int goff[PRE ? C::NV : 1], goffo[PRE ? C::NVO : 1];
+    auto in_off = [&](int i) {
+        if constexpr (PRE) return goff[i];
+        else return (int)((meta[i] >> 4) & 0xfu) * in_img_pitch + (int)(meta[i] & 0xfu) * in_row_pitch + (int)((meta[i] >> 8) & 0xffu) * a_c;
+    };
+    auto out_off = [&](int i) {
+        if constexpr (PRE) return goffo[i];
+        else return (int)((metao[i] >> 4) & 0xfu) * out_img_pitch + (int)(metao[i] & 0xfu) * out_row_pitch + (int)((metao[i] >> 8) & 0xffu) * a_c;
+    };
+    if constexpr (PRE) {
+#pragma unroll
+        for (int i = 0; i < C::NV; ++i)
+            goff[i] = (int)((meta[i] >> 4) & 0xfu) * in_img_pitch + (int)(meta[i] & 0xfu) * in_row_pitch + (int)((meta[i] >> 8) & 0xffu) * a_c;
+#pragma unroll
+        for (int i = 0; i < C::NVO; ++i)
+            goffo[i] = (int)((metao[i] >> 4) & 0xfu) * out_img_pitch + (int)(metao[i] & 0xfu) * out_row_pitch + (int)((metao[i] >> 8) & 0xffu) * a_c;
     }
 
     // ---- block descriptors: closed form of (block index -> item, block of the item), 64 blocks at a time by the lanes
@@ -278,8 +310,7 @@ __global__ __launch_bounds__(1024, 4) void dwconv_lane_fwd_kernel(const mc_dwcon
 #else
             const bool ok = live && row >= rlo && row < rhi && col >= clo && col < chi && seg < nseg;
 #endif
-            const int goff = seg * in_img_pitch + row * in_row_pitch + col * a_c;
-            vals[i] = *reinterpret_cast<const uint4*>(ok ? org + goff : a_x);        // unconditional load, clamped address
+            vals[i] = *reinterpret_cast<const uint4*>(ok ? org + in_off(i) : a_x);   // unconditional load, clamped address
             inb |= (ok ? 1u : 0u) << i;
         }
         if constexpr (ETILE) {                             // e rows of the output rows block q completes (MODE 3: that enter in it) / its dy rows
@@ -292,8 +323,7 @@ __global__ __launch_bounds__(1024, 4) void dwconv_lane_fwd_kernel(const mc_dwcon
             for (int i = 0; i < C::NVO; ++i) {
                 const int row = (int)(metao[i] & 0xfu), seg = (int)((metao[i] >> 4) & 0xfu), col = (int)((metao[i] >> 8) & 0xffu);
                 const bool ok = live && row >= orlo && row < orhi && col < ochi && seg < nseg;
-                const int goff = seg * out_img_pitch + row * out_row_pitch + col * a_c;
-                evals[i] = *reinterpret_cast<const uint4*>(ok ? eorg + goff : esrc);
+                evals[i] = *reinterpret_cast<const uint4*>(ok ? eorg + out_off(i) : esrc);
                 einb |= (ok ? 1u : 0u) << i;
             }
         }
@@ -335,7 +365,7 @@ __global__ __launch_bounds__(1024, 4) void dwconv_lane_fwd_kernel(const mc_dwcon
 #ifdef LANE_NO_STORE
                 if (a_n < 0)
 #endif
-                *reinterpret_cast<uint4*>(org + (seg * out_img_pitch + row * out_row_pitch + col * a_c)) = val;
+                *reinterpret_cast<uint4*>(org + out_off(i)) = val;
             }
         }
     };
