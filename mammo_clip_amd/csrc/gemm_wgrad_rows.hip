@@ -223,9 +223,14 @@ struct xbwd_extra {
     const bf16_t* R; long long ldr;         // optional residual added to dX
 };
 
-template <int AF, int BF, int MAXCH, int NKS, int RF>
-__global__ __launch_bounds__(256, 2) void xbwd_rows_kernel(const mc_wgrad_rows_args p, const xbwd_extra q, int WB, int nchy, int nchx, int nchr) {
+// NCHY / NCHX = 16-byte chunk slots per thread and step for dY / for x (and as many again for the residual): template constants, so
+// that "which tensor does slot i belong to" is decided at compile time -- with runtime slot counts the compiler kept a scalar base /
+// pitch selection per slot alive and a third of the step loop's VALU instructions were SGPR spill traffic (236 v_readlane /
+// v_writelane of 710, scripts/lane_isa_mix.py-style count)
+template <int AF, int BF, int NCHY, int NCHX, int NKS, int RF>
+__global__ __launch_bounds__(256, 2) void xbwd_rows_kernel(const mc_wgrad_rows_args p, const xbwd_extra q, int WB, int nchr) {
     constexpr int RB = 16 * RF;
+    constexpr int nchy = NCHY, nchx = NCHX, MAXCH = NCHY + 2 * NCHX;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int rsy = p.N * 2, rsx = p.K * 2;
     const int KF = (p.K + 15) >> 4, KO = KF * 16, rso = KO * 2;     // dX tile: KF column fragments, row stride rso bytes
@@ -452,9 +457,12 @@ static bool xbwd_cfg(int n, int k, XbwdCfg* c) {
     // rows per step = 16 rf: 32 where the registers are short (N = 384: 96 accumulators + 48 of Wt), 128 for the narrow
     // tensors (a 64-row step of N = 144 is 21 KB: too few bytes in flight per CU -- measured 3.8 TB/s)
     c->rf = n + k > 320 ? 2 : (n + k <= 176 ? 8 : 4);
-    // the instantiations below: EfficientNet-B5 (144,24) (240,40) (384,64), -B2 (96,16) (144,24) (288,48)
-    return (c->af == 3 && c->bf == 2 && c->nks == 5) || (c->af == 4 && c->bf == 3 && c->nks == 8) || (c->af == 6 && c->bf == 4 && c->nks == 12) ||
-           (c->af == 2 && c->bf == 1 && c->nks == 3) || (c->af == 5 && c->bf == 3 && c->nks == 9);
+    // the instantiations below: EfficientNet-B5 (144,24) (240,40) (384,64), -B2 (96,16) (144,24) (288,48) -- fragment counts AND the
+    // chunk slots per thread and step (template constants of the kernel) must be the ones of an instantiation
+    const int RB = 16 * c->rf, cy = (RB * (n / 8) + 255) / 256, cx = (RB * (k / 8) + 255) / 256;
+    return (c->af == 3 && c->bf == 2 && c->nks == 5 && cy == 9 && cx == 2) || (c->af == 4 && c->bf == 3 && c->nks == 8 && cy == 8 && cx == 2) ||
+           (c->af == 6 && c->bf == 4 && c->nks == 12 && cy == 6 && cx == 1) || (c->af == 2 && c->bf == 1 && c->nks == 3 && cy == 6 && cx == 1) ||
+           (c->af == 5 && c->bf == 3 && c->nks == 9 && cy == 5 && cx == 1);
 }
 extern "C" int mc_xbwd_rows_supported(int n, int k) { XbwdCfg c; return xbwd_cfg(n, k, &c) ? 1 : 0; }
 extern "C" int mc_xbwd_rows_blocks(long long m) {
@@ -484,11 +492,10 @@ extern "C" int mc_xbwd_rows_bf16(const mc_wgrad_rows_args* a, const mc_bf16* wt,
     const size_t lds = (size_t)RB * (p.N + p.K) * 2 + 32 * 16 * 2 * 6 + 64 + (size_t)RB * KO * 2 + (size_t)2 * RB * p.K * 2;
     xbwd_extra q;
     q.Wt = wt; q.ldwt = ldwt; q.dX = dx; q.lddx = lddx; q.R = r; q.ldr = ldr;
-    // (MAXCH = 16-byte chunks per thread and step, dY + x + residual slots: sized per instantiation -- every slot is 4 + 1 VGPRs)
-#define XB_CASE(A_, B_, N_, R_, CH_) if (c.af == A_ && c.bf == B_ && c.nks == N_ && c.rf == R_) { \
-        MC_CHECK(nchy + nchx + nchr <= CH_, "xbwd_rows: internal: step too large");               \
-        hipLaunchKernelGGL((xbwd_rows_kernel<A_, B_, CH_, N_, R_>), dim3(blocks), dim3(256), lds, st, p, q, WB, nchy, nchx, nchr); } else
-    XB_CASE(3, 2, 5, 8, 14) XB_CASE(4, 3, 8, 4, 12) XB_CASE(6, 4, 12, 2, 8) XB_CASE(2, 1, 3, 8, 8) XB_CASE(5, 3, 9, 2, 8)
+    // (chunk slots per thread and step are template constants of the instantiation: see the kernel)
+#define XB_CASE(A_, B_, N_, R_, CY_, CX_) if (c.af == A_ && c.bf == B_ && c.nks == N_ && c.rf == R_ && nchy == CY_ && nchx == CX_) { \
+        hipLaunchKernelGGL((xbwd_rows_kernel<A_, B_, CY_, CX_, N_, R_>), dim3(blocks), dim3(256), lds, st, p, q, WB, nchr); } else
+    XB_CASE(3, 2, 5, 8, 9, 2) XB_CASE(4, 3, 8, 4, 8, 2) XB_CASE(6, 4, 12, 2, 6, 1) XB_CASE(2, 1, 3, 8, 6, 1) XB_CASE(5, 3, 9, 2, 5, 1)
     { MC_CHECK(false, "xbwd_rows: internal: no instantiation"); }
 #undef XB_CASE
     MC_LAUNCH_CHECK();
