@@ -44,7 +44,10 @@ __device__ __forceinline__ bf16x8_t tr_frag(const unsigned char* tile, int rs, i
 // AF x BF = 16x16 output fragments per wave (exact: the host picks the instantiation), WB = waves along K.
 // Per-thread chunk geometry (global offset, LDS offset, row) is constant over the steps and lives in registers: a
 // step costs a few instructions per 16-byte chunk instead of two runtime divisions.
-template <int AF, int BF, int MAXCH>
+// NCHY_T > 0 (round 5, the hot shapes): the number of dY slots per thread as a compile-time constant -- "which tensor does slot i
+// belong to" then folds away (with the runtime count the per-slot scalar base / pitch selections cost ~120 SGPR spill
+// instructions per step, see xbwd_rows_kernel below)
+template <int AF, int BF, int MAXCH, int NCHY_T = 0>
 __global__ __launch_bounds__(256, 2) void wgrad_rows_kernel(const mc_wgrad_rows_args p, int WB, int RB, int nch) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int rsy = p.N * 2, rsx = p.K * 2;
@@ -68,7 +71,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_rows_kernel(const mc_wgrad_rows_
 
     // chunk slots: the first nchy slots of every thread belong to dY, the rest to X (uniform per slot, so the base
     // pointer of a slot is scalar and the per-lane part of an address is one 32-bit offset).  meta = row | chunk << 12.
-    const int nchy = (chY + 255) >> 8;
+    const int nchy = NCHY_T > 0 ? NCHY_T : (chY + 255) >> 8;
     unsigned meta[MAXCH];
 #pragma unroll
     for (int i = 0; i < MAXCH; ++i) {
@@ -431,6 +434,10 @@ extern "C" int mc_wgrad_rows_bf16(const mc_wgrad_rows_args* a, void* stream) {
     const size_t lds = (size_t)RB * (p.N + p.K) * 2 + 32 * 16 * 2 * 6 + 64 + (size_t)p.K * 16;
     const int nch = (RB * (p.N / 8) + 255) / 256 + (RB * (p.K / 8) + 255) / 256;   // dY slots + X slots per thread
     MC_CHECK(nch <= NCH, "wgrad_rows: internal: step too large");
+    const int nchy_h = (RB * (p.N / 8) + 255) / 256;
+    // hot shapes of EfficientNet-B5's projection convs, (c_out, c_exp) = (40, 240) and (64, 384): dY slot count as a template constant
+    if (af == 3 && bfn == 4 && nchy_h == 2) { hipLaunchKernelGGL((wgrad_rows_kernel<3, 4, 10, 2>), dim3(blocks), dim3(256), lds, st, p, WB, RB, nch); } else
+    if (af == 4 && bfn == 6 && nchy_h == 1) { hipLaunchKernelGGL((wgrad_rows_kernel<4, 6, 10, 1>), dim3(blocks), dim3(256), lds, st, p, WB, RB, nch); } else
 #define WG_CASE(A_, B_) if (af == A_ && bfn == B_) { hipLaunchKernelGGL((wgrad_rows_kernel<A_, B_, (A_ * B_ <= 8 ? 16 : 10)>), dim3(blocks), dim3(256), lds, st, p, WB, RB, nch); } else
     WG_CASE(1, 1) WG_CASE(1, 2) WG_CASE(1, 3) WG_CASE(1, 4) WG_CASE(1, 5) WG_CASE(1, 6)
     WG_CASE(2, 1) WG_CASE(2, 2) WG_CASE(2, 3) WG_CASE(2, 4) WG_CASE(2, 5) WG_CASE(2, 6)
