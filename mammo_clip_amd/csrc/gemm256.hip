@@ -88,7 +88,7 @@ __device__ __forceinline__ Coords item_coords(int xcd, int slot, int S, int NTl,
 }
 
 template <bool STATS, bool FP8>
-__global__ __launch_bounds__(NTHR, 2) void gemm8p_kernel(const mc_gemm_args p, const int MT, const int NTl, const int ktn) {
+__global__ __launch_bounds__(NTHR, 2) void gemm8p_kernel(const mc_gemm_args p, const int MT, const int NTl, const int ktn, const int nt_out) {
     constexpr int ES = FP8 ? 1 : 2;             // bytes per operand element
     constexpr int KT = 128 / ES;                // K tile in elements (128 bytes per LDS row)
     __shared__ __attribute__((aligned(1024))) unsigned char smem[LDS_BYTES];
@@ -356,6 +356,21 @@ __global__ __launch_bounds__(NTHR, 2) void gemm8p_kernel(const mc_gemm_args p, c
                 }
                 G8_BAR();
                 if (ncol < p.N) {
+                    // residual: the 4 vectors of this thread's slab rows in flight together, ONE wait (round 5; the first
+                    // form paid 4 dependent round trips per slab).  Rows beyond M re-read row m0 (valid) and are not stored.
+                    uint4 rv[4];
+                    if (Rb) {
+                        const bf16_t* rp[4];
+#pragma unroll
+                        for (int ps = 0; ps < 4; ++ps) {
+                            const long long m = m0 + s * 64 + r0 + ps * 16;
+                            rp[ps] = Rb + (m < p.M ? m : m0) * p.ldr + ncol;
+                        }
+                        asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %5, off\n\t"
+                                     "global_load_dwordx4 %2, %6, off\n\tglobal_load_dwordx4 %3, %7, off\n\ts_waitcnt vmcnt(0)"
+                                     : "=&v"(rv[0]), "=&v"(rv[1]), "=&v"(rv[2]), "=&v"(rv[3])
+                                     : "v"(rp[0]), "v"(rp[1]), "v"(rp[2]), "v"(rp[3]) : "memory");
+                    }
 #pragma unroll
                     for (int ps = 0; ps < 4; ++ps) {
                         const int row = r0 + ps * 16;
@@ -365,10 +380,7 @@ __global__ __launch_bounds__(NTHR, 2) void gemm8p_kernel(const mc_gemm_args p, c
                             if (Rb) {
                                 float f[8], g[8];
                                 unpack8(v, f);
-                                uint4 rv;
-                                asm volatile("global_load_dwordx4 %0, %1, off\n\ts_waitcnt vmcnt(0)"
-                                             : "=&v"(rv) : "v"(Rb + m * p.ldr + ncol) : "memory");
-                                unpack8(rv, g);
+                                unpack8(rv[ps], g);
 #pragma unroll
                                 for (int q = 0; q < 8; ++q) f[q] += g[q];
                                 v = pack8(f);
@@ -379,7 +391,10 @@ __global__ __launch_bounds__(NTHR, 2) void gemm8p_kernel(const mc_gemm_args p, c
 #pragma unroll
                                 for (int q = 0; q < 8; ++q) { csum[q] += f[q]; csq[q] += f[q] * f[q]; }
                             }
-                            *reinterpret_cast<uint4*>(Cb + m * p.ldc + ncol) = v;
+                            // nt_out (outputs of 128 MB and more): non-temporal stores -- the lines leave the L2 early instead
+                            // of queueing behind each other's evictions; small outputs stay cached for their consumer
+                            if (nt_out) __builtin_nontemporal_store((u32x4){v.x, v.y, v.z, v.w}, reinterpret_cast<u32x4*>(Cb + m * p.ldc + ncol));
+                            else *reinterpret_cast<uint4*>(Cb + m * p.ldc + ncol) = v;
                         }
                     }
                 }
@@ -471,13 +486,15 @@ extern "C" int mc_gemm256_launch(const mc_gemm_args* a, void* stream) {
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const dim3 grid(256), block(g8::NTHR);
     MC_CHECK(g8_layout_ok(p), "gemm256: leading dimension / problem size beyond the descriptor form's limits");
+    static const long long nt_min = getenv("MC_GEMM_NT_BYTES") ? atoll(getenv("MC_GEMM_NT_BYTES")) : (128LL << 20);
+    const int nt = (long long)p.batch * p.M * p.N * 2 >= nt_min ? 1 : 0;
     MC_CHECK(p.K % 8 == 0 && p.lda % 8 == 0 && p.ldb % 8 == 0, "gemm256: K, lda, ldb must be multiples of 8");
     if (p.ab_fp8) {
         MC_CHECK(p.K % 16 == 0 && p.lda % 16 == 0 && p.ldb % 16 == 0, "gemm (fp8 operands): K, lda, ldb must be multiples of 16");
-        if (p.stat_partials) hipLaunchKernelGGL((g8::gemm8p_kernel<true, true>), grid, block, 0, st, p, MT, NTl, ktn);
-        else hipLaunchKernelGGL((g8::gemm8p_kernel<false, true>), grid, block, 0, st, p, MT, NTl, ktn);
-    } else if (p.stat_partials) hipLaunchKernelGGL((g8::gemm8p_kernel<true, false>), grid, block, 0, st, p, MT, NTl, ktn);
-    else hipLaunchKernelGGL((g8::gemm8p_kernel<false, false>), grid, block, 0, st, p, MT, NTl, ktn);
+        if (p.stat_partials) hipLaunchKernelGGL((g8::gemm8p_kernel<true, true>), grid, block, 0, st, p, MT, NTl, ktn, nt);
+        else hipLaunchKernelGGL((g8::gemm8p_kernel<false, true>), grid, block, 0, st, p, MT, NTl, ktn, nt);
+    } else if (p.stat_partials) hipLaunchKernelGGL((g8::gemm8p_kernel<true, false>), grid, block, 0, st, p, MT, NTl, ktn, nt);
+    else hipLaunchKernelGGL((g8::gemm8p_kernel<false, false>), grid, block, 0, st, p, MT, NTl, ktn, nt);
     MC_LAUNCH_CHECK();
     return MC_OK;
 }

@@ -19,18 +19,21 @@ SHAPES = [  # (batch, M, N, K, what)
     (1, 173280, 1056, 176, "expand 176->1056 @95x57 x32"), (1, 173280, 768, 128, "expand 128->768 @95x57 x32"),
     (1, 8192, 2304, 768, "BERT qkv b32"), (1, 16384, 2304, 768, "BERT qkv b64"), (1, 16384, 768, 768, "BERT out b64"),
     (1, 16384, 3072, 768, "BERT ffn1 b64"), (1, 16384, 768, 3072, "BERT ffn2 b64"),
-    (1, 4096, 4096, 4096, "4096^3"), (1, 8192, 8192, 8192, "8192^3")]
+    (1, 4096, 4096, 4096, "4096^3"), (1, 8192, 8192, 8192, "8192^3"),
+    (1, 44544, 512, 3072, "dgrad 3072->512 + residual"), (1, 173280, 176, 1056, "dgrad 1056->176 + residual"),
+    (1, 173280, 128, 768, "dgrad 768->128 + residual")]
 
 
-def run(mode, b, M, N, K, reps=20):
+def run(mode, b, M, N, K, reps=20, res=False):
     os.environ["MC_GEMM_256"] = str(mode)
     g = torch.Generator(device=DEV).manual_seed(1)
     x = (torch.randn((b * M, K), generator=g, device=DEV)).to(torch.bfloat16)
     w = (torch.randn((b, N, K), generator=g, device=DEV) * K ** -0.5).to(torch.bfloat16)
     y = torch.empty((b * M, N), device=DEV, dtype=torch.bfloat16)
+    r = torch.randn((b * M, N), generator=g, device=DEV).to(torch.bfloat16) if res else None
 
     def call():
-        ops.gemm(x, w, y, M, N, K, K, K, N, batch=b, sA=(M * K, 0), sB=(N * K, 0), sC=(M * N, 0))
+        ops.gemm(x, w, y, M, N, K, K, K, N, batch=b, sA=(M * K, 0), sB=(N * K, 0), sC=(M * N, 0), R=r, ldr=N if res else 0)
     for _ in range(3):
         call()
     torch.cuda.synchronize()
@@ -46,9 +49,10 @@ def run(mode, b, M, N, K, reps=20):
 if __name__ == "__main__":
     print(f"{'shape':44s} {'128^2 us':>9s} {'TF/s':>7s} {'256^2 us':>9s} {'TF/s':>7s} {'GB/s(alg)':>9s}  maxdiff")
     for (b, M, N, K, what) in SHAPES:
-        t0, y0 = run(0, b, M, N, K)
+        res = what.endswith("residual")
+        t0, y0 = run(0, b, M, N, K, res=res)
         y0 = y0.float().clone()
-        t1, y1 = run(2, b, M, N, K)
+        t1, y1 = run(2, b, M, N, K, res=res)
         fl = 2.0 * b * M * N * K
         by = 2.0 * b * (M * K + N * K + M * N)
         d = float((y1.float() - y0).abs().max())
