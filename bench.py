@@ -203,6 +203,11 @@ def main():
     ap.add_argument("--no-n8-load", action="store_true", help="skip the n8_load block of the default N = 1 run")
     ap.add_argument("--fp8", action="store_true", help="fp8 (e4m3) operands for the late-stage 1x1 convolutions (config #5 arithmetic on any workload)")
     ap.add_argument("--op-profile", action="store_true", help="print a per-entry-point HIP-event breakdown (rank 0)")
+    ap.add_argument("--streams", type=int, default=None, choices=(0, 1, 2, 3, 7),
+                    help="encoder chains of one forward on separate HIP streams (model/clip.py MC_STREAMS: bit 0 the text encoder, "
+                         "bit 1 the second image view; default: MC_STREAMS or 3)")
+    ap.add_argument("--roofline-in-timed-region", action="store_true",
+                    help="with streams: no extra one-stream steps -- the roofline objects quote the (shared) launch durations of the timed steps")
     ap.add_argument("--storage", default=None, choices=("bf16", "f16"),
                     help="16-bit storage / MFMA operand build of the kernel library (default: MC_STORAGE or bf16 -- BASELINE's dtype; "
                          "f16 = the reference's AMP dtype with a dynamic loss scale, the parity configuration of DESIGN.md (c))")
@@ -285,6 +290,10 @@ def main():
     opt = build_optimizer(model, {"name": "adamw", "config": {"lr": 5e-5, "weight_decay": 1e-4}})
     sched = LinearWarmupCosineAnnealingLR(opt, total_steps=10000, warmup_steps=100)
     trainer = engine.Trainer(model, loss_func, opt, sched, device, keep_graphs=args.keep_graphs, keep_recompute=keep_recompute)
+    from mammo_clip_amd.breastclip.model import clip as clipmod
+    if args.streams is not None:
+        clipmod._STREAMS = args.streams
+    streams = clipmod._STREAMS
     batch = synth_batch_gpu(b, H, W, T, device, seed=10 + rank)
 
     def sync():
@@ -342,6 +351,29 @@ def main():
     peak_gb = torch.cuda.max_memory_allocated() / 1e9
     peak_res_gb = torch.cuda.max_memory_reserved() / 1e9
 
+    # Kernel rooflines need launch durations that belong to ONE kernel.  With the encoder chains on separate streams a
+    # bracketed launch shares the GPU with launches of the other chains: the HIP-event time around it is no longer that
+    # kernel's own time (two HBM-bound kernels side by side each see about half the bandwidth).  The roofline objects are
+    # therefore taken from `xsteps` further steps of the same trainer on ONE stream, right after the timed region (one untimed
+    # step first: the allocator pools of the side streams are released and the main pool regrows); the shared durations of the
+    # timed region are reported beside them (`in_timed_region`).
+    summ_x, xsteps = None, 0
+    if streams and not args.roofline_in_timed_region:
+        clipmod._STREAMS = 0
+        trainer.optimizer.zero_grad(set_to_none=True)
+        torch.cuda.empty_cache()
+        ld = trainer.step(batch, args.micro_batches)
+        sync()
+        xsteps = max(1, min(args.steps, 2))
+        timer_x = L.OpTimer(keys=[k for k in raw if class_key(k) in top])
+        L.TIMER = timer_x
+        for _ in range(xsteps):
+            ld = trainer.step(batch, args.micro_batches)
+        sync()
+        L.TIMER = None
+        summ_x = merged(timer_x.summary())
+        clipmod._STREAMS = streams
+
     n8 = None
     if world == 1 and args.workload == "cfg4" and strong and not args.no_n8_load:
         # the step one GPU runs at N = 8 (128 pairs = 4 micro-batches, recompute mode 3, four kept graphs), no communication
@@ -351,7 +383,8 @@ def main():
         model.image_encoder.set_recompute(3)
         trainer.keep_graphs, trainer.keep_recompute = 4, None
         b8 = synth_batch_gpu(128, H, W, T, device, seed=99)
-        trainer.step(b8, 4)
+        for _ in range(2):                         # (two untimed steps: the allocator pools of all streams settle)
+            trainer.step(b8, 4)
         torch.cuda.synchronize()
         torch.cuda.reset_peak_memory_stats()
         t8 = time.perf_counter()
@@ -381,9 +414,16 @@ def main():
                    "on the cfg3 launch mix; this run's launch mix differs (micro-batch re-forwards), compare traffic with "
                    "algorithmic bytes on --workload cfg3 only")) if tj else None
         timing = "HIP events on the launch stream around every launch of this class inside the timed steps"
+        if summ_x is not None:
+            timing = (f"HIP events on the launch stream around every launch of this class in {xsteps} step(s) of the same trainer on ONE "
+                      f"stream (MC_STREAMS=0) run right after the timed region: the timed steps run the encoder chains on "
+                      f"{1 + bin(streams).count('1')} concurrent streams, where a bracketed launch shares the GPU with other chains' "
+                      "launches (those shared durations: in_timed_region)")
 
-        def entry(key):
-            cnt, t_ms, by, fl = summ.get(key, (0, 0.0, 0, 0))
+        def entry(key, src=None, nsteps=None):
+            src = (summ_x if summ_x is not None else summ) if src is None else src
+            nsteps = (xsteps if summ_x is not None else args.steps) if nsteps is None else nsteps
+            cnt, t_ms, by, fl = src.get(key, (0, 0.0, 0, 0))
             # the tile-GEMM classes are split per launch by the roofline that bounds the launch's shape (ops.gemm tags them);
             # every other class by its aggregate intensity
             mfma = key.endswith("|mfma") or (not key.endswith("|hbm") and by > 0 and fl / by >= RIDGE)
@@ -394,12 +434,21 @@ def main():
             tkey = key[:-5] if key.endswith("|mfma") else (key[:-4] if key.endswith("|hbm") else key)
             return {"bound": "mfma" if mfma else "hbm", "achieved": round(ach, 1), "peak": peak, "unit": unit,
                     "frac": round(ach / peak, 4), "traffic": tj.get(key, tj.get(tkey)), "traffic_source": tsrc if tj.get(key, tj.get(tkey)) is not None else None,
-                    "kernel": kernel_name(key), "class": tkey, "launches": cnt, "launches_per_step": cnt // max(args.steps, 1),
+                    "kernel": kernel_name(key), "class": tkey, "launches": cnt, "launches_per_step": cnt // max(nsteps, 1),
                     "avg_launch_us": round(t_ms / max(cnt, 1) * 1e3, 1), "algorithmic_bytes_per_launch": int(by / max(cnt, 1)),
-                    "algorithmic_flops_per_launch": int(fl / max(cnt, 1)), "gpu_ms_in_timed_steps": round(t_ms, 1),
+                    "algorithmic_flops_per_launch": int(fl / max(cnt, 1)), "gpu_ms_in_timed_steps": round(summ.get(key, (0, 0.0, 0, 0))[1], 1),
+                    "gpu_ms_per_step": round(t_ms / max(nsteps, 1), 2),
                     "share_of_gpu_time_in_survey_step": round(ssum[key][1] / max(sum(v[1] for v in ssum.values()), 1e-9), 4),
                     "timing": timing}
-        ranked = sorted((entry(k) for k in top), key=lambda r: -r["gpu_ms_in_timed_steps"])
+
+        def entry2(key):
+            e = entry(key)
+            if summ_x is not None:
+                t = entry(key, summ, args.steps)
+                e["in_timed_region"] = {"avg_launch_us": t["avg_launch_us"], "achieved": t["achieved"], "frac": t["frac"],
+                                        "launches": t["launches"], "concurrent_streams": 1 + bin(streams).count("1")}
+            return e
+        ranked = sorted((entry2(k) for k in top), key=lambda r: -r["gpu_ms_per_step"])
         first, second, third = (ranked + [None, None, None])[:3]
         res = {
             "metric": "image-text pairs/s (whole node), EN-B5+BioClinicalBERT contrastive pre-training step",
@@ -412,7 +461,8 @@ def main():
                        "global_batch": b * world, "parallelism": f"dp{world}" + (f" x {args.micro_batches} micro-batches" if args.micro_batches > 1 else ""),
                        "loss": round(loss_val, 5), "peak_hbm_gb": round(peak_gb, 1), "peak_reserved_gb": round(peak_res_gb, 1),
                        "keep_graphs": args.keep_graphs, "recompute": args.recompute, "keep_recompute": keep_recompute,
-                       "stat_tapes": bool(getattr(trainer, "stat_tapes", False)) and args.micro_batches > args.keep_graphs},
+                       "stat_tapes": bool(getattr(trainer, "stat_tapes", False)) and args.micro_batches > args.keep_graphs,
+                       "streams": streams},
             "roofline": first, "roofline_runner_up": second, "roofline_third": third,
         }
         if n8 is not None:

@@ -49,6 +49,10 @@ class _L2NormFn(torch.autograd.Function):
 
 
 _TEXT_ONE_CALL = os.environ.get("MC_TEXT_ONE_CALL", "1") != "0"      # developer switch: A/B against two encoder calls
+# MC_STREAMS: encoder calls of one forward on separate HIP streams (ops.side_stream): bit 0 = the text encoder, bit 1 = the
+# second image view (both views then issued block by block in alternation, EfficientNet.forward_pair; bit 2 = call after call
+# instead).  Same kernels on the same operands with the same seeds and per-view statistics: same results.
+_STREAMS = int(os.environ.get("MC_STREAMS", "3"))
 
 
 class BreastClip(nn.Module):
@@ -99,9 +103,64 @@ class BreastClip(nn.Module):
 
     def forward(self, batch, device=None):
         device = batch["images"].device if device is None else device
-        img = self.encode_image(batch["images"].to(device))
-        tok = _tokens.to_device(batch["text_tokens"], device)
+        images = batch["images"].to(device)
+        use_streams = _STREAMS if images.is_cuda else 0
+        main = torch.cuda.current_stream(device) if use_streams else None
+        s_txt = ops.side_stream(0, device) if use_streams & 1 else None
         two = "text_tokens2" in batch and "image_views" in batch
+        enc = self.image_encoder
+        s_view = ops.side_stream(1, device) if (use_streams & 2 and two and hasattr(enc, "side_call_begin")) else None
+        if s_view is not None:
+            enc.warm_weight_images(backward=torch.is_grad_enabled())     # both views read them: built before the fork
+        if use_streams:
+            ops.fork_side(device)
+            ops.FORKED += 1
+        try:
+            return self._forward_chains(batch, device, images, two, main, s_txt, s_view)
+        finally:
+            if use_streams:
+                ops.FORKED -= 1
+
+    def _forward_chains(self, batch, device, images, two, main, s_txt, s_view):
+        enc = self.image_encoder
+        view = None
+        if s_view is not None and (_STREAMS & 4) == 0 and hasattr(enc, "forward_pair") \
+                and self.model_config["image_encoder"]["model_type"].lower() == "cnn":
+            # both views block by block in alternation (EfficientNet.forward_pair): the two chains are in flight side by side
+            # from the first launch on; MC_STREAMS bit 2 keeps the call-after-call issue order below (A/B)
+            img, view = enc.forward_pair(images, batch["image_views"].to(device), s_view)
+        else:
+            img = self.encode_image(images)
+        if s_view is not None and view is None:
+            # the second view on its own stream, issued right behind the first (same host order of the two encoder calls as
+            # without streams: seeds, statistics tapes and the gradient sink's arrival order do not change)
+            views = batch["image_views"].to(device)
+            torch.cuda.set_stream(s_view)
+            enc.side_call_begin()
+            try:
+                view = self.encode_image(views)
+            finally:
+                torch.cuda.set_stream(main)
+                main.wait_stream(s_view)
+                enc.side_call_end()
+            view.record_stream(main)
+        tok = _tokens.to_device(batch["text_tokens"], device)
+        txt2 = None
+        if s_txt is not None:
+            torch.cuda.set_stream(s_txt)
+        try:
+            txt, txt2 = self._encode_reports(batch, tok, two, device)
+        finally:
+            if s_txt is not None:
+                torch.cuda.set_stream(main)
+        if s_txt is not None:
+            main.wait_stream(s_txt)
+            for t_ in (txt, txt2):
+                if t_ is not None:
+                    t_.record_stream(main)
+        return self._finish(batch, device, img, txt, txt2, two, view)
+
+    def _encode_reports(self, batch, tok, two, device):
         txt2 = None
         if two:
             # Both reports of a pair go through the text encoder in ONE call when their token tensors have the same
@@ -117,17 +176,21 @@ class BreastClip(nn.Module):
                 txt = self.encode_text(tok)
         else:
             txt = self.encode_text(tok)
+        if two and txt2 is None:
+            txt2 = self.encode_text(_tokens.to_device(batch["text_tokens2"], device))
+        return txt, txt2
+
+    def _finish(self, batch, device, img, txt, txt2, two, view=None):
         img_e = self.image_projection(img) if self.projection else img
         txt_e = self.text_projection(txt) if self.projection else txt
         img_e, txt_e = _L2NormFn.apply(img_e), _L2NormFn.apply(txt_e)
         out = {"image_embeddings": img_e, "text_embeddings": txt_e,
                "labels": torch.arange(img_e.shape[0], device=device), "logit_scale": self.logit_scale.exp()}
         if two:
-            if txt2 is None:
-                txt2 = self.encode_text(tok2)
             txt2_e = self.text_projection(txt2) if self.projection else txt      # [ref quirk: clip.py:105]
             out["text_embeddings2"] = _L2NormFn.apply(txt2_e)
-            view = self.encode_image(batch["image_views"].to(device))
+            if view is None:
+                view = self.encode_image(batch["image_views"].to(device))
             view_e = self.image_projection(view) if self.projection else view
             out["image_view_embeddings"] = _L2NormFn.apply(view_e)
         return out

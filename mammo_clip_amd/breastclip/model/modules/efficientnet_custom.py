@@ -137,12 +137,53 @@ def _replaying():
     return _TAPE is not None and _TAPE.mode == "replay"
 
 
+class _BNDefer:
+    """Running-statistic updates of an encoder call that runs on a SIDE stream beside another call of the same encoder
+    (model/clip.py: the second image view).  Both calls update the same buffers -- r <- (1 - m) r + m s, view 1 first
+    [ref: clip.py:83,108 two sequential encode_image calls] -- so the side call must not touch them: its finalize launches
+    update zero-filled scratch slices instead (result: m s), and ``apply`` folds them in after the join, on the main
+    stream, behind view 1's updates: r <- (1 - m) r + (m s), the same two-term form (one rounding apart from the fused
+    kernel expression)."""
+
+    def __init__(self, enc):
+        offs, tot = {}, 0
+        for bn in enc._bn_layers:
+            offs[id(bn)] = tot
+            tot += bn.num_features
+        self.offs, self.total = offs, tot
+        self.flat = torch.zeros(2 * tot, dtype=torch.float32, device=enc._ones_b.device)
+        self.used = []
+
+    def scratch(self, bn):
+        o, c = self.offs[id(bn)], bn.num_features
+        self.used.append(bn)
+        return self.flat[o:o + c], self.flat[self.total + o:self.total + o + c]
+
+    @torch.no_grad()
+    def apply(self):
+        if not self.used:
+            return
+        self.flat.record_stream(torch.cuda.current_stream(self.flat.device))
+        dst = [bn.running_mean for bn in self.used] + [bn.running_var for bn in self.used]
+        src = [self.flat[self.offs[id(bn)]:self.offs[id(bn)] + bn.num_features] for bn in self.used] + \
+              [self.flat[self.total + self.offs[id(bn)]:self.total + self.offs[id(bn)] + bn.num_features] for bn in self.used]
+        torch._foreach_mul_(dst, 1.0 - BN_MOMENTUM)
+        torch._foreach_add_(dst, src)
+        self.used = []
+
+
+_BN_DEFER = None
+
+
 def _bn_stats(partials, count, bn: nn.BatchNorm2d, training: bool):
     if training:
         if _replaying():
             return _TAPE.get()
-        st = ops.bn_finalize(partials, count, bn.weight, bn.bias, bn.running_mean, bn.running_var, BN_MOMENTUM, BN_EPS,
-                             bn.track_update)
+        if _BN_DEFER is not None and bn.track_update:
+            rm, rv = _BN_DEFER.scratch(bn)
+        else:
+            rm, rv = bn.running_mean, bn.running_var
+        st = ops.bn_finalize(partials, count, bn.weight, bn.bias, rm, rv, BN_MOMENTUM, BN_EPS, bn.track_update)
         if bn.track_update:
             if bn.defer_count is not None:
                 bn.defer_count.append(bn.num_batches_tracked)     # the encoder bumps all counters with ONE launch
@@ -719,7 +760,124 @@ class EfficientNet(nn.Module):
         self._pending_counters = counters
         return y, n, h, w
 
+    # ---------------------------------------------------------------------------- side-stream calls (model/clip.py)
+    def warm_weight_images(self, backward: bool):
+        """Build (or find) every cached weight image the forward -- and, with ``backward``, the backward -- of this encoder
+        reads, on the CURRENT stream: two calls of the encoder on different streams then only ever hit the cache (an image
+        built by one chain while the other chain is in flight would be read without an ordering between the streams).  Same
+        helper calls with the same views as the autograd functions below (the cache key holds pointer, shape and strides)."""
+        for blk in self._blocks:
+            a = blk.args
+            if a.expand != 1:
+                ops.cast_bf16(blk._expand_conv.weight.view(a.cexp, a.cin))
+                if backward:
+                    ops.cast_transpose_bf16(blk._expand_conv.weight.view(a.cexp, a.cin))
+            ops.transpose_f32(blk._depthwise_conv.weight.view(a.cexp, a.k * a.k), cache=True)
+            if backward and a.s == 1:
+                ops.flipped_taps_f32(blk._depthwise_conv.weight.view(a.cexp, a.k * a.k))
+            ops.cast_bf16(blk._project_conv.weight.view(a.cout, a.cexp))
+            if backward:
+                ops.cast_transpose_bf16(blk._project_conv.weight.view(a.cout, a.cexp))
+        cout, cin = self._conv_head.weight.shape[0], self._conv_head.weight.shape[1]
+        ops.cast_bf16(self._conv_head.weight.view(cout, cin))
+        if backward:
+            ops.cast_transpose_bf16(self._conv_head.weight.view(cout, cin))
+
+    def side_call_begin(self):
+        """the next forward of this encoder runs on a side stream beside another one: BatchNorm running statistics and batch
+        counters are left to ``side_call_end`` (after the join, on the main stream)"""
+        global _BN_DEFER
+        self._hold_counters = True
+        if self.training:
+            _BN_DEFER = _BNDefer(self)
+
+    def side_call_end(self):
+        global _BN_DEFER
+        d, _BN_DEFER = _BN_DEFER, None
+        self._hold_counters = False
+        if d is not None:
+            d.apply()
+        self._flush_counters()
+
+    def forward_pair(self, x1, x2, side):
+        """Both image views of a batch [ref: clip.py:83,108 -- two sequential ``encode_image`` calls] as two chains issued
+        BLOCK BY BLOCK in alternation: view 1 on the current stream, view 2 on ``side``.  Each chain is exactly the
+        launch sequence of ``forward`` on its input (same seeds: two consecutive draws, view 1 first; per-view BatchNorm
+        statistics; view 2's running-statistic updates and both views' batch counters applied after the join, view 1
+        first), so every result equals two sequential calls; what changes is the ISSUE order -- the two chains are in flight
+        side by side from the first launch on, in the forward and (autograd replays the creation order backwards) in the
+        backward.  Returns the two pooled feature tensors."""
+        global _BN_DEFER
+        if not (x1.is_cuda and x2.is_cuda):
+            raise RuntimeError("mammo_clip_amd.EfficientNet runs only on a HIP device (no CPU fallback)")
+        main = torch.cuda.current_stream(x1.device)
+        conv = lambda x: x if isinstance(x, ops.RawImages) or x.dtype == torch.float32 else x.float()   # noqa: E731
+        xs = [conv(x1), conv(x2)]
+        seeds = [self.rng.next(), self.rng.next()]
+        training = self.training
+        counters = [[], []] if training else [None, None]
+        bns = self._bn_layers if training else ()
+        defer = None
+
+        def chain(i):
+            """switch the issue point to chain i (stream, counter list, running-statistic target)"""
+            global _BN_DEFER
+            torch.cuda.set_stream(side if i else main)
+            for bn in bns:
+                bn.defer_count = counters[i]
+            _BN_DEFER = defer if i else None
+
+        b0 = self._blocks[0].args
+        linked = LINK_STEM and b0.expand == 1 and not b0.skip and b0.s == 1
+        ys, scales, geo = [None, None], [None, None], None
+        try:
+            torch.cuda.set_stream(side)
+            defer = _BNDefer(self) if training else None          # (zero-filled scratch: allocated and cleared on the side stream)
+            links = [None, None]
+            for i in (0, 1):
+                chain(i)
+                links[i] = _StemLink() if linked else None
+                if linked:
+                    ys[i] = _StemFn.apply(xs[i], self._conv_stem.weight, self._bn0.weight, self._bn0.bias, self, links[i])
+                else:
+                    ys[i] = _StemFn.apply(xs[i], self._conv_stem.weight, self._bn0.weight, self._bn0.bias, self)
+                n, h, w = self._geo
+                scales[i] = self._drop_connect_scales(n, xs[i].device, seeds[i])
+            geo = (n, h, w)
+            for bi, blk in enumerate(self._blocks):
+                n, h, w = geo
+                for i in (0, 1):
+                    chain(i)
+                    if bi == 0 and linked:
+                        blk.__dict__["_in_link"] = links[i]
+                    ys[i] = blk(ys[i], n, h, w, scales[i][bi])
+                geo = blk._out_geo
+            n, h, w = geo
+            pooled = [None, None]
+            for i in (0, 1):
+                chain(i)
+                pooled[i] = _HeadFn.apply(ys[i], self._conv_head.weight, self._bn1.weight, self._bn1.bias, self, n, h, w)
+                if training and self._dropout_p > 0.0:
+                    pooled[i] = _DropoutFn.apply(pooled[i], self._dropout_p, seeds[i], 999)
+        finally:
+            torch.cuda.set_stream(main)
+            for bn in bns:
+                bn.defer_count = None
+            _BN_DEFER = None
+        self._last_seed = seeds[1]
+        main.wait_stream(side)
+        if defer is not None:
+            defer.apply()
+        with torch.no_grad():
+            for c in counters:
+                if c:
+                    torch._foreach_add_(c, 1)
+        pooled[1].record_stream(main)
+        return pooled[0], pooled[1]
+
     def _flush_counters(self):
+        if getattr(self, "_hold_counters", False):
+            return
         c = getattr(self, "_pending_counters", None)
         if c:
             with torch.no_grad():

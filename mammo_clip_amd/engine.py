@@ -318,8 +318,19 @@ class Trainer:
 
     def _backward(self, run):
         """one backward call; with the gradient sink the hand-written functions deliver their parameter gradients to it"""
+        # encoder chains on side streams (model/clip.py MC_STREAMS): their backward nodes run on those streams; the gradients
+        # they hand to the sink (or leave in .grad) are consumed on the current stream
+        sides = ops.side_streams() if torch.cuda.is_available() else ()
+        if sides:
+            ops.fork_side()
+            ops.FORKED += 1
         if not self.grad_sink:
-            return run()
+            try:
+                return run()
+            finally:
+                if sides:
+                    ops.FORKED -= 1
+                    ops.join_side()
         if self._sink is None:
             self._sink = ops.GradSink()
         # the sink is visible to the backward functions only while THIS backward call runs: a backward outside the Trainer
@@ -329,6 +340,9 @@ class Trainer:
             run()
         finally:
             ops.GRAD_SINK = None
+            if sides:
+                ops.FORKED -= 1
+                ops.join_side()
         self._sink.flush()
 
     def _grads_done(self, hooked: bool):

@@ -32,6 +32,47 @@ def _st():
     return _RAW_STREAM(_GET_DEV())
 
 
+# ---------------------------------------------------------------------------------------- side streams
+# The three encoder calls of one BreastClip.forward (view 1, view 2, both reports) are independent until the projection heads
+# [ref: model/clip.py:83-108]; model/clip.py can issue them on separate HIP streams so the latency-bound launches of one chain
+# (squeeze-excite MLPs, BatchNorm finalize, split-K reduces: ~1 900 launches under 25 us per config-#3 step) run beside the
+# large launches of another.  Autograd runs each backward node on the stream its forward ran on.  Rules kept here:
+#   * fork(): every side stream waits for the current stream; join(): the current stream waits for every side stream;
+#   * a tensor that crosses streams is held by its consumer until a later fork/join orders the allocator's reuse, or it is
+#     recorded on the consuming stream (record_stream);
+#   * weight images shared by two chains are built BEFORE the fork (EfficientNet.warm_weight_images), BatchNorm running
+#     statistics of the side chain are applied after the join in call order (efficientnet_custom._BNDefer).
+_SIDE = {}
+
+
+def side_stream(i, device=None):
+    dev = torch.cuda.current_device() if device is None else torch.device(device).index
+    key = (dev, i)
+    st = _SIDE.get(key)
+    if st is None:
+        st = _SIDE[key] = torch.cuda.Stream(device=dev)
+    return st
+
+
+def side_streams(device=None):
+    dev = torch.cuda.current_device() if device is None else torch.device(device).index
+    return [st for (d, _i), st in _SIDE.items() if d == dev]
+
+
+def fork_side(device=None):
+    """every side stream created so far waits for the work queued on the current stream"""
+    cur = torch.cuda.current_stream(device)
+    for st in side_streams(device):
+        st.wait_stream(cur)
+
+
+def join_side(device=None):
+    """the current stream waits for the work queued on every side stream"""
+    cur = torch.cuda.current_stream(device)
+    for st in side_streams(device):
+        cur.wait_stream(st)
+
+
 def _chk_dev(*ts):
     for t in ts:
         if t is not None and not t.is_cuda:
@@ -237,6 +278,8 @@ def _prefer_tiles(N, K):
 # tensors are cached; an entry is tied to the owning tensor OBJECT through a weak reference (addresses and ids are
 # recycled by the allocator) and to its version counter (bumped by the optimizer's in-place update / load_state_dict).
 _WCACHE = {}
+FORK_MISSES = None     # tests set a list: (kind, id(parameter)) of every image built between a fork and its join
+FORKED = 0             # > 0 while encoder chains may be in flight on several streams (model/clip.py, engine.Trainer._backward)
 _WGEN = 0          # bumped whenever an image is (re)built: lets the optimizer reuse its parameter -> image map
 
 
@@ -249,6 +292,8 @@ def _cached(kind, src, make):
     if hit is not None and hit[0]() is base and hit[1] == base._version and hit[2].device == src.device:
         return hit[2]
     val = make()
+    if FORK_MISSES is not None and FORKED:
+        FORK_MISSES.append((kind, id(base)))   # (tests: image built while encoder chains may be in flight on several streams)
     if len(_WCACHE) > 4096:
         for k in [k for k, v in _WCACHE.items() if v[0]() is None]:
             del _WCACHE[k]

@@ -7,15 +7,20 @@ MODE=${1:-stats}
 C4="python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline"
 C3="python $R/bench.py --workload cfg3 --steps 1 --warmup 1 --no-cpu-baseline"
 if [ "$MODE" = "stats" ] || [ "$MODE" = "all" ]; then
-  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_c3 -- $C3 > $OUT/c3.log 2>&1
-  cp $(ls /tmp/p_c3/*/*kernel_stats.csv | head -1) $OUT/cfg3_kernel_stats.csv
+  # the default run (encoder chains on three streams: kernel durations are SHARED with concurrent launches) ...
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_c3 -- $C3 --roofline-in-timed-region > $OUT/c3.log 2>&1
+  cp $(ls /tmp/p_c3/*/*kernel_stats.csv | head -1) $OUT/cfg3_kernel_stats_streams3.csv
   cp $(ls /tmp/p_c3/*/*agent_info.csv | head -1) $OUT/agent_info.csv
+  # ... and the same command on ONE stream: every kernel alone on the GPU -- the durations bench.py's roofline objects quote
+  MC_STREAMS=0 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_c3s0 -- $C3 > $OUT/c3_s0.log 2>&1
+  cp $(ls /tmp/p_c3s0/*/*kernel_stats.csv | head -1) $OUT/cfg3_kernel_stats.csv
 fi
 if [ "$MODE" = "cfg4" ] || [ "$MODE" = "all" ]; then
   timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_c4 -- $C4 > $OUT/c4.log 2>&1
   cp $(ls /tmp/p_c4/*/*kernel_stats.csv | head -1) $OUT/cfg4_kernel_stats.csv
 fi
 if [ "$MODE" = "pmc" ] || [ "$MODE" = "all" ]; then
+  export MC_STREAMS=0      # counters are attributed per dispatch: one kernel at a time on the GPU
   i=0
   for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES"; do
     i=$((i+1))

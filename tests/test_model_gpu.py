@@ -646,3 +646,56 @@ def test_bn0_backward_folded_into_expand_gemms():
         else:
             assert diff <= 1e-2 * G, (n, diff, G)
     print("folded bn0 backward: worst gradient cosine", worst)
+
+
+def test_encoder_chains_on_side_streams_same_step():
+    """MC_STREAMS (model/clip.py): the text encoder and the second image view on their own HIP streams beside view 1.
+    Same kernels, operands and host order as the one-stream step: the loss is bit-identical (micro-batched step with a
+    re-forward and a kept graph, dropout / drop-connect ON), gradients agree to the spread of the float-atomic reductions,
+    BatchNorm running statistics to one rounding (the side view's update is applied after the join: r (1 - m) + (m s)),
+    the batch counters exactly; no weight image of the IMAGE encoder is built after the fork (both views read them)."""
+    from mammo_clip_amd import engine
+    from mammo_clip_amd.breastclip.model import clip as clipmod
+    z = np.load(os.path.join(GOLDEN, "e2e_b5_small.npz"))
+    _, H, W, T = [int(v) for v in z["meta"]]
+    b, k = 4, 2
+    batch = ow.synth_batch(b, H, W, T, seed=23)
+    bt = {"images": batch["images"].to(DEV), "image_views": batch["image_views"].to(DEV),
+          "text_tokens": {kk: v.to(DEV) for kk, v in batch["text_tokens"].items()},
+          "text_tokens2": {kk: v.to(DEV) for kk, v in batch["text_tokens2"].items()}}
+
+    def run(streams, steps=2):
+        model, lossf, _ = _build("tf_efficientnet_b5_ns-detect", "efficientnet-b5", stochastic_off=False)
+        util.GlobalEnv.reset()
+        old = clipmod._STREAMS
+        clipmod._STREAMS = streams
+        ops.FORK_MISSES = []
+        try:
+            tr = engine.Trainer(model, lossf, torch.optim.SGD(model.parameters(), lr=0.0), None, DEV)
+            losses = []
+            for _ in range(steps):
+                losses.append(float(tr.step(bt, micro_batches=k)["total"]))
+            torch.cuda.synchronize()
+            misses = ops.FORK_MISSES
+        finally:
+            clipmod._STREAMS = old
+            ops.FORK_MISSES = None
+        enc_ids = {id(p_) for p_ in model.image_encoder.parameters()}
+        return (losses, {n: p_.grad.clone() for n, p_ in model.named_parameters() if p_.grad is not None},
+                {n: v.clone() for n, v in model.named_buffers()}, [m for m in misses if m[1] in enc_ids])
+
+    l0, g0, b0, _ = run(0)
+    for streams in (1, 3, 7):
+        l1, g1, b1, enc_misses = run(streams)
+        assert l1 == l0, (streams, l1, l0)
+        assert g1.keys() == g0.keys()
+        for n in g0:
+            assert relerr(g1[n], g0[n]) < 1e-5, (streams, n, relerr(g1[n], g0[n]))
+        for n in b0:
+            if n.endswith("num_batches_tracked"):
+                assert torch.equal(b1[n], b0[n]), n
+            else:
+                assert relerr(b1[n], b0[n]) < 1e-6, (streams, n, relerr(b1[n], b0[n]))
+        if streams & 2:
+            # every image-encoder weight image was built by warm_weight_images BEFORE the fork
+            assert ops.side_streams() and not enc_misses, enc_misses
