@@ -207,7 +207,7 @@ def _conv_stats(fn, training, *a, **kw):
 LINK_STEM = os.environ.get("MC_LINK_STEM", "1") != "0"                  # stem bn0 + swish inside block 0's depthwise kernels (_StemLink)
 FUSE_DW_BWD = os.environ.get("MC_FUSE_DW_BWD", "1") != "0"              # stride-1 3x3 depthwise backward as one launch (ops.dwconv_bwd_fused)
 FUSE_PROJ_DGRAD = os.environ.get("MC_FUSE_PROJ_DGRAD", "1") != "0"        # projection data gradient with the SE / BatchNorm1 backward in its epilogue (ops.proj_dgrad_*)
-BN_FOLD_MIN_BYTES = int(os.environ.get("MC_BN_FOLD_MIN_BYTES", 400_000_000))
+BN_FOLD_MIN_BYTES = int(os.environ.get("MC_BN_FOLD_MIN_BYTES", 250_000_000))
 BN_FOLD_S2_MIN_BYTES = int(os.environ.get("MC_BN_FOLD_S2_MIN_BYTES", 0))
 
 
@@ -440,7 +440,8 @@ class _MBConvFn(torch.autograd.Function):
                 # bn0 backward is linear in (dZ0, e) and e = x We^T: it is folded into the operands of the expand conv's
                 # two gradient GEMMs (ops.bn_fold_expand_bwd) -- de is never formed, e is not read again.  Three passes
                 # over the expanded tensor against ~10 small launches and 6 passes over the (6x smaller) block input:
-                # pays from ~0.4 GB of expanded tensor per call (measured: B5 blocks 4-12 at 32 x 1520 x 912)
+                # pays from ~0.25 GB of expanded tensor per call (B5 at 32 x 1520 x 912: blocks 4-12 from 0.4 GB on one stream; with
+                # the three launch chains of round 5 the small launches overlap and the blocks at 95 x 57 / c = 3072 join)
                 del e, dw_in
                 coef0, dg0, db0 = ops.bn_bwd_coefs(part0, n * hw, st0, blk._bn0.weight)
                 dx, dwe = ops.bn_fold_expand_bwd(dz0, x, blk._expand_conv.weight.view(a.cexp, a.cin), sv["we"], coef0,
