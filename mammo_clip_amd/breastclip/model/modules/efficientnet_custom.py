@@ -163,7 +163,8 @@ class _BNDefer:
     def apply(self):
         if not self.used:
             return
-        self.flat.record_stream(torch.cuda.current_stream(self.flat.device))
+        if self.flat.is_cuda:
+            self.flat.record_stream(torch.cuda.current_stream(self.flat.device))
         dst = [bn.running_mean for bn in self.used] + [bn.running_var for bn in self.used]
         src = [self.flat[self.offs[id(bn)]:self.offs[id(bn)] + bn.num_features] for bn in self.used] + \
               [self.flat[self.total + self.offs[id(bn)]:self.total + self.offs[id(bn)] + bn.num_features] for bn in self.used]

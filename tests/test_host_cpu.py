@@ -551,3 +551,53 @@ def test_trainer_step_failure_leaves_no_gradient_sink_behind():
     m.zero_grad(set_to_none=True)
     m({"x": torch.ones(3)})["y"].sum().backward()
     assert torch.equal(m.w.grad, torch.ones(3))
+
+
+def test_side_view_running_statistics_are_applied_in_the_reference_order():
+    """Launch chains (model/clip.py MC_STREAMS): the second image view runs beside the first one, so its BatchNorm finalize
+    launches must not touch the running statistics -- they update zero-filled scratch slices (-> m * s) and _BNDefer.apply
+    folds them in after the join: r <- (1 - m) r + (m s), behind view 1's update, i.e. the reference's two sequential
+    encode_image calls [ref: model/clip.py:83,108].  Host logic only: offsets of the flat scratch buffer, which layers were
+    touched, the arithmetic of apply (the kernels' side is tests/test_model_gpu.py::test_encoder_chains_on_side_streams_same_step),
+    and the cache keys warm_weight_images must hit are the ones the autograd functions ask for."""
+    from mammo_clip_amd.breastclip.model.modules import efficientnet_custom as ec
+    enc = load_image_encoder({"source": "cnn", "name": "tf_efficientnetv2-detect", "pretrained": False, "model_type": "cnn"})
+    bns = enc._bn_layers
+    assert len(bns) == sum(1 for m in enc.modules() if isinstance(m, ec._BN)) and len(bns) > 60
+    g = torch.Generator().manual_seed(3)
+    for bn in bns:
+        bn.running_mean.copy_(torch.randn(bn.num_features, generator=g))
+        bn.running_var.copy_(torch.rand(bn.num_features, generator=g) + 0.5)
+    m = ec.BN_MOMENTUM
+    d = ec._BNDefer(enc)
+    assert d.flat.numel() == 2 * sum(bn.num_features for bn in bns) and float(d.flat.abs().max()) == 0.0
+    want, seen = {}, set()
+    for bn in bns[::3]:                                        # a forward that touches every third layer
+        rm, rv = d.scratch(bn)
+        assert rm.shape == rv.shape == (bn.num_features,)
+        assert (rm.data_ptr(), rv.data_ptr()) not in seen      # disjoint slices
+        seen.add((rm.data_ptr(), rv.data_ptr()))
+        s_mean, s_var = torch.randn(bn.num_features, generator=g), torch.rand(bn.num_features, generator=g)
+        rm.copy_(m * s_mean)                                   # what bn_finalize_k leaves: (1 - m) * 0 + m * s
+        rv.copy_(m * s_var)
+        want[id(bn)] = ((1.0 - m) * bn.running_mean + m * s_mean, (1.0 - m) * bn.running_var + m * s_var)
+    untouched = {id(bn): (bn.running_mean.clone(), bn.running_var.clone()) for bn in bns if id(bn) not in want}
+    d.apply()
+    for bn in bns:
+        if id(bn) in want:
+            torch.testing.assert_close(bn.running_mean, want[id(bn)][0], rtol=1e-6, atol=1e-7)
+            torch.testing.assert_close(bn.running_var, want[id(bn)][1], rtol=1e-6, atol=1e-7)
+        else:
+            assert torch.equal(bn.running_mean, untouched[id(bn)][0]) and torch.equal(bn.running_var, untouched[id(bn)][1])
+    assert d.used == []                                        # applied once
+    # side_call_begin / side_call_end bracket: counters are held back, the deferral object is installed only in training mode
+    enc.eval()
+    enc.side_call_begin()
+    assert ec._BN_DEFER is None and enc._hold_counters
+    enc.side_call_end()
+    assert not enc._hold_counters
+    enc.train()
+    enc.side_call_begin()
+    assert isinstance(ec._BN_DEFER, ec._BNDefer)
+    enc.side_call_end()
+    assert ec._BN_DEFER is None
