@@ -11,12 +11,15 @@ if [ "$MODE" = "stats" ] || [ "$MODE" = "all" ]; then
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_c3 -- $C3 --roofline-in-timed-region > $OUT/c3.log 2>&1
   cp $(ls /tmp/p_c3/*/*kernel_stats.csv | head -1) $OUT/cfg3_kernel_stats_streams3.csv
   cp $(ls /tmp/p_c3/*/*agent_info.csv | head -1) $OUT/agent_info.csv
+  python $R/scripts/overlap_stats.py $(ls /tmp/p_c3/*/*kernel_trace.csv | head -1) > $OUT/cfg3_overlap_streams3.txt 2>&1
   # ... and the same command on ONE stream: every kernel alone on the GPU -- the durations bench.py's roofline objects quote
   MC_STREAMS=0 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_c3s0 -- $C3 > $OUT/c3_s0.log 2>&1
   cp $(ls /tmp/p_c3s0/*/*kernel_stats.csv | head -1) $OUT/cfg3_kernel_stats.csv
+  python $R/scripts/overlap_stats.py $(ls /tmp/p_c3s0/*/*kernel_trace.csv | head -1) > $OUT/cfg3_overlap_one_stream.txt 2>&1
 fi
 if [ "$MODE" = "cfg4" ] || [ "$MODE" = "all" ]; then
-  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_c4 -- $C4 > $OUT/c4.log 2>&1
+  # one stream: the launch durations bench.py's roofline objects quote (its default run measures them in one-stream steps)
+  MC_STREAMS=0 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_c4 -- $C4 > $OUT/c4.log 2>&1
   cp $(ls /tmp/p_c4/*/*kernel_stats.csv | head -1) $OUT/cfg4_kernel_stats.csv
 fi
 if [ "$MODE" = "pmc" ] || [ "$MODE" = "all" ]; then
