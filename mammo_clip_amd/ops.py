@@ -45,8 +45,14 @@ def _st():
 _SIDE = {}
 
 
+def _dev_index(device):
+    """device ordinal of ``device`` (None, "cuda" and index-less torch.device objects mean the current device)"""
+    idx = None if device is None else torch.device(device).index
+    return torch.cuda.current_device() if idx is None else idx
+
+
 def side_stream(i, device=None):
-    dev = torch.cuda.current_device() if device is None else torch.device(device).index
+    dev = _dev_index(device)
     key = (dev, i)
     st = _SIDE.get(key)
     if st is None:
@@ -55,7 +61,7 @@ def side_stream(i, device=None):
 
 
 def side_streams(device=None):
-    dev = torch.cuda.current_device() if device is None else torch.device(device).index
+    dev = _dev_index(device)
     return [st for (d, _i), st in _SIDE.items() if d == dev]
 
 
