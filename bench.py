@@ -465,6 +465,17 @@ def main():
                        "streams": streams},
             "roofline": first, "roofline_runner_up": second, "roofline_third": third,
         }
+        # the whole step against both roofs: algorithmic bytes / flops of every launch of ONE step (the survey step's tags,
+        # ops._note: each kernel reads its inputs and writes its outputs once) over the measured step time -- independent of
+        # how the launches overlap
+        sb, sf = sum(v[2] for v in ssum.values()), sum(v[3] for v in ssum.values())
+        res["whole_step"] = {"algorithmic_gb_per_step": round(sb / 1e9, 1), "algorithmic_tflop_per_step": round(sf / 1e12, 2),
+                             "hbm_gb_per_s": round(sb / 1e9 / (ms * 1e-3), 1), "hbm_frac": round(sb / (ms * 1e-3) / (HBM_PEAK_GBS * 1e9), 4),
+                             "mfma_tflop_per_s": round(sf / 1e12 / (ms * 1e-3), 1), "mfma_frac": round(sf / (ms * 1e-3) / (MFMA_PEAK_TFS * 1e12), 4),
+                             # 497 GB per 32-pair B5 step when every conv reads its input and writes its output once
+                             "survey_8d_min_gb_per_step": (round(497.0 * b / 32, 1) if args.workload in ("cfg3", "cfg4", "cfg5") else None),
+                             "hbm_frac_of_survey_min": (round(497e9 * b / 32 / (ms * 1e-3) / (HBM_PEAK_GBS * 1e9), 4) if args.workload in ("cfg3", "cfg4", "cfg5") else None),
+                             "note": "per GPU; bytes / flops as tagged per launch (sum over the kernels' own inputs + outputs, i.e. the traffic of THIS pass structure, not SURVEY 8d's one-read-one-write minimum)"}
         if n8 is not None:
             res["n8_load"] = n8
         if dist_info is not None:
