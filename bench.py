@@ -364,7 +364,7 @@ def main():
         torch.cuda.empty_cache()
         ld = trainer.step(batch, args.micro_batches)
         sync()
-        xsteps = max(1, min(args.steps, 2))
+        xsteps = 1 if args.micro_batches >= 8 else max(1, min(args.steps, 2))     # (a micro-batched step is thousands of launches per class)
         timer_x = L.OpTimer(keys=[k for k in raw if class_key(k) in top])
         L.TIMER = timer_x
         for _ in range(xsteps):
