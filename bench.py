@@ -16,7 +16,7 @@ BioClinicalBERT, GLOBAL batch 1024, 1520x912 images, 256-token reports, bf16 com
 per step (strong scaling) in micro-batches of 32 pairs: the contrastive loss runs over all 1024 pairs of the step, the
 micro-batching costs k - keep extra forwards per step of k micro-batches (engine.Trainer.step(batch, micro_batches=k):
 the last `keep` micro-batches are forwarded once, graph kept; 2 full graphs = 232 GB, or all 4 graphs of the N = 8 load
-with the MBConv recompute mode 3).  At N = 1 a step is 32 micro-batches (about 12.4 s).  "--workload cfg3" is BASELINE configs[2], 32 pairs per GPU in one pass (weak scaling).
+with the MBConv recompute mode 3).  At N = 1 a step is 32 micro-batches (about 8.5 s in round 5).  "--workload cfg3" is BASELINE configs[2], 32 pairs per GPU in one pass (weak scaling).
 
 The JSON line carries, besides the contract fields:
   roofline     -- the dominant kernel class of THIS run.  The last warm-up step is run with HIP events around every C-ABI
@@ -126,16 +126,19 @@ def model_cfg(enc_name, fp8=False, recompute=0):
 
 
 LOSS_CFG = {"breast_clip": dict(label_smoothing=0.0, i2i_weight=1.0, t2t_weight=0.5, loss_ratio=1.0)}
+# SURVEY.md section 8d's secondary metric: the single-view loss (1 image + 1 report per pair through the encoders, half the
+# encoder work per pair) [ref: loss/breast_clip_contrastive.py:28-59]; `--loss breast_clip_contrastive`
+LOSS_CFG_SINGLE = {"breast_clip_contrastive": dict(label_smoothing=0.0, loss_ratio=1.0)}
 
 
-def synth_batch_gpu(b, H, W, T, device, seed):
+def synth_batch_gpu(b, H, W, T, device, seed, views=2):
     """Synthetic batch resident in HBM: images ~ N(0,1) in the trainer's [b,3,H,W] permuted-NHWC view
     (trainer_ddp.py:288-291), full-length token rows ([CLS] ... [SEP]) as in SURVEY.md section 8d throughput runs."""
     g = torch.Generator(device=device).manual_seed(seed)
     batch = {}
-    for k in ("images", "image_views"):
+    for k in ("images", "image_views")[:views]:
         batch[k] = torch.randn((b, H, W, 3), generator=g, device=device).permute(0, 3, 1, 2)
-    for k in ("text_tokens", "text_tokens2"):
+    for k in ("text_tokens", "text_tokens2")[:views]:
         ids = torch.randint(1000, 28996, (b, T), generator=g, device=device)
         ids[:, 0], ids[:, -1] = 101, 102
         batch[k] = {"input_ids": ids, "token_type_ids": torch.zeros_like(ids), "attention_mask": torch.ones_like(ids)}
@@ -199,6 +202,9 @@ def main():
     ap.add_argument("--keep-mode", type=int, default=2, choices=(1, 2, 3, 4), help="recompute mode of those kept graphs")
     ap.add_argument("--as-gpus", type=int, default=0, help="with --gpus 1: run ONE rank's share of the N-GPU strong-scaling run "
                     "(1024 / N pairs, that run's micro-batch / kept-graph policy, no collectives): the per-GPU load of the N-GPU point")
+    ap.add_argument("--loss", default="breast_clip", choices=("breast_clip", "breast_clip_contrastive"),
+                    help="breast_clip = the configured multi-view loss (2 views + 2 reports per pair: the headline metric); "
+                         "breast_clip_contrastive = the single-view loss (1 image + 1 report per pair: SURVEY 8d's secondary metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-n8-load", action="store_true", help="skip the n8_load block of the default N = 1 run")
     ap.add_argument("--fp8", action="store_true", help="fp8 (e4m3) operands for the late-stage 1x1 convolutions (config #5 arithmetic on any workload)")
@@ -285,8 +291,10 @@ def main():
     torch.manual_seed(10)
     if args.recompute < 0:
         args.recompute = 0
-    model = build_model(model_cfg(enc_name, fp8, args.recompute), LOSS_CFG, types.SimpleNamespace(vocab_size=28996)).to(device)
-    loss_func = build_loss(LOSS_CFG)
+    single = args.loss == "breast_clip_contrastive"
+    loss_cfg = LOSS_CFG_SINGLE if single else LOSS_CFG
+    model = build_model(model_cfg(enc_name, fp8, args.recompute), loss_cfg, types.SimpleNamespace(vocab_size=28996)).to(device)
+    loss_func = build_loss(loss_cfg)
     opt = build_optimizer(model, {"name": "adamw", "config": {"lr": 5e-5, "weight_decay": 1e-4}})
     sched = LinearWarmupCosineAnnealingLR(opt, total_steps=10000, warmup_steps=100)
     trainer = engine.Trainer(model, loss_func, opt, sched, device, keep_graphs=args.keep_graphs, keep_recompute=keep_recompute)
@@ -294,7 +302,7 @@ def main():
     if args.streams is not None:
         clipmod._STREAMS = args.streams
     streams = clipmod._STREAMS
-    batch = synth_batch_gpu(b, H, W, T, device, seed=10 + rank)
+    batch = synth_batch_gpu(b, H, W, T, device, seed=10 + rank, views=1 if single else 2)
 
     def sync():
         torch.cuda.synchronize()
@@ -375,7 +383,7 @@ def main():
         clipmod._STREAMS = streams
 
     n8 = None
-    if world == 1 and args.workload == "cfg4" and strong and not args.no_n8_load:
+    if world == 1 and args.workload == "cfg4" and strong and not args.no_n8_load and not single:
         # the step one GPU runs at N = 8 (128 pairs = 4 micro-batches, recompute mode 3, four kept graphs), no communication
         del batch, ld
         trainer.optimizer.zero_grad(set_to_none=True)
@@ -456,7 +464,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": os.environ.get("MC_STORAGE", "bf16").lower() + (" + fp8 e4m3 pointwise-conv operands" if fp8 else ""), "data": "synthetic",
             "config": {"workload": f"{args.workload}: {arch_name} + BioClinicalBERT(BERT-base), {b} pairs/GPU "
-                                   f"(2 views + 2 reports each), {H}x{W} images, {T}-token reports, breast_clip loss, "
+                                   f"({'1 image + 1 report' if single else '2 views + 2 reports'} each), {H}x{W} images, {T}-token reports, {args.loss} loss, "
                                    f"AdamW; fwd+loss+bwd+optimizer; dropout/drop-connect on",
                        "global_batch": b * world, "parallelism": f"dp{world}" + (f" x {args.micro_batches} micro-batches" if args.micro_batches > 1 else ""),
                        "loss": round(loss_val, 5), "peak_hbm_gb": round(peak_gb, 1), "peak_reserved_gb": round(peak_res_gb, 1),
@@ -481,7 +489,7 @@ def main():
         if dist_info is not None:
             res["rccl_ranks"] = dist_info["rccl_ranks"]
             res["dist"] = dist_info
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not single:
             try:
                 res["cpu_baseline"] = cpu_baseline(arch_name, H, W, T)
             except Exception as e:                # pragma: no cover

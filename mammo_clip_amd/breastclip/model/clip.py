@@ -48,6 +48,13 @@ class _L2NormFn(torch.autograd.Function):
         return ops.l2norm_bwd(dy, y, norm)
 
 
+def _record_on(t, stream):
+    """a tensor (or ops.RawImages) allocated on the current stream that ``stream`` is about to read"""
+    t = getattr(t, "data", t) if isinstance(t, ops.RawImages) else t
+    if torch.is_tensor(t) and t.is_cuda:
+        t.record_stream(stream)
+
+
 _TEXT_ONE_CALL = os.environ.get("MC_TEXT_ONE_CALL", "1") != "0"      # developer switch: A/B against two encoder calls
 # MC_STREAMS: encoder calls of one forward on separate HIP streams (ops.side_stream): bit 0 = the text encoder, bit 1 = the
 # second image view (both views then issued block by block in alternation, EfficientNet.forward_pair; bit 2 = call after call
@@ -124,7 +131,10 @@ class BreastClip(nn.Module):
     def _forward_chains(self, batch, device, images, two, main, s_txt, s_view):
         enc = self.image_encoder
         view = None
-        if s_view is not None and (_STREAMS & 4) == 0 and hasattr(enc, "forward_pair") \
+        # (an encoder with forward hooks / pre-hooks takes the call-after-call path: forward_pair is not ``__call__``, the hooks
+        # would silently not fire -- ADVICE r5)
+        hooked = bool(getattr(enc, "_forward_hooks", None) or getattr(enc, "_forward_pre_hooks", None))
+        if s_view is not None and (_STREAMS & 4) == 0 and hasattr(enc, "forward_pair") and not hooked \
                 and self.model_config["image_encoder"]["model_type"].lower() == "cnn":
             # both views block by block in alternation (EfficientNet.forward_pair): the two chains are in flight side by side
             # from the first launch on; MC_STREAMS bit 2 keeps the call-after-call issue order below (A/B)
@@ -135,6 +145,8 @@ class BreastClip(nn.Module):
             # the second view on its own stream, issued right behind the first (same host order of the two encoder calls as
             # without streams: seeds, statistics tapes and the gradient sink's arrival order do not change)
             views = batch["image_views"].to(device)
+            s_view.wait_stream(main)                    # (a fresh H2D copy above is main-stream work issued after the fork)
+            _record_on(views, s_view)
             torch.cuda.set_stream(s_view)
             enc.side_call_begin()
             try:
@@ -147,6 +159,12 @@ class BreastClip(nn.Module):
         tok = _tokens.to_device(batch["text_tokens"], device)
         txt2 = None
         if s_txt is not None:
+            # token tensors moved to the device just now are main-stream allocations read by the text chain: ordered behind
+            # the copy, and recorded on the consuming stream so the allocator does not hand the block out again while the
+            # side stream still reads it (ops.py's crossing-tensor rule)
+            s_txt.wait_stream(main)
+            for t_ in tok.values():
+                _record_on(t_, s_txt)
             torch.cuda.set_stream(s_txt)
         try:
             txt, txt2 = self._encode_reports(batch, tok, two, device)

@@ -814,7 +814,17 @@ class EfficientNet(nn.Module):
             raise RuntimeError("mammo_clip_amd.EfficientNet runs only on a HIP device (no CPU fallback)")
         main = torch.cuda.current_stream(x1.device)
         conv = lambda x: x if isinstance(x, ops.RawImages) or x.dtype == torch.float32 else x.float()   # noqa: E731
-        xs = [conv(x1), conv(x2)]
+        # view 2's dtype conversion (fp16 / bf16 / integer inputs) is a launch of its own: it is issued on the SIDE stream,
+        # where chain 2 reads its result (on the main stream, behind the fork, nothing ordered it before the side
+        # chain's stem); the inputs themselves were produced on the main stream before the caller's fork -- the explicit wait
+        # below also covers callers that built them after it (model/clip.py: ``batch["image_views"].to(device)``)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            x2c = conv(x2)
+        xs = [conv(x1), x2c]
+        for t_ in (x2.data if isinstance(x2, ops.RawImages) else x2,):
+            if torch.is_tensor(t_) and t_.is_cuda:
+                t_.record_stream(side)          # allocated on the main stream, read by the side chain (allocator reuse)
         seeds = [self.rng.next(), self.rng.next()]
         training = self.training
         counters = [[], []] if training else [None, None]

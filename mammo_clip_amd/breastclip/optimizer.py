@@ -55,7 +55,10 @@ class AdamW(torch.optim.Optimizer):
             if all(p.data_ptr() == ptrs[0] and self.state[p]["exp_avg"].data_ptr() == ptrs[1]
                    and self.state[p]["exp_avg_sq"].data_ptr() == ptrs[2] for p, ptrs in zip(params, plan["ptrs"])):
                 return plan
-        if plan is not None:
+        if getattr(self, "_ls_skipped", None) is not None:
+            # a plan is created or rebuilt while the device counts skipped steps: fold them into the host counts FIRST -- the
+            # new plan reads ``state[p]["step"]`` (applied counts) and must not have the same skips subtracted again, and a
+            # group planned for the first time after some skips must not inherit them
             self._fold_skipped()
         steps = []
         arr = (L.AdamwTensor * max(len(params), 1))()
@@ -106,6 +109,10 @@ class AdamW(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         from .. import ops
+        if getattr(self, "_ls", None) is None and getattr(self, "_ls_skipped", None) is not None:
+            # a plain step() after loss-scaled ones: the kernel is handed the APPLIED count (no device counter in this call)
+            self._fold_skipped()
+            self._ls_skipped = None
         for gi, group in enumerate(self.param_groups):
             plan = self._plan(gi, group)
             params, arr, steps = plan["params"], plan["arr"], plan["steps"]

@@ -4,8 +4,11 @@
 #   lib/libmammoclip_hip_f16.so  IEEE f16 storage / operands (-DMC_F16; opt-in: MC_STORAGE=f16)
 # hipcc cross-compiles without a GPU.  MC_BUILD_F16=0 skips the second variant.  All stale objects of both variants are
 # compiled concurrently (the longest translation unit bounds the wall time), then the two libraries are linked.
+# MC_REBUILD=1: clean build -- every object of both variants is recompiled from source (the make-like default only
+# recompiles objects older than their sources; prebuilt objects travel with the tree).
 set -e
 cd "$(dirname "$0")"
+if [ "${MC_REBUILD:-0}" = "1" ]; then rm -f ../lib/*.o ../lib/f16/*.o ../lib/libmammoclip_hip.so ../lib/libmammoclip_hip_f16.so; fi
 SRCS="gemm gemm256 gemm256_tn fp8 gemm_rows gemm_wgrad_rows conv conv_lane bnact bnfold bert attn head optim util"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=fast -Wno-unused-result"
 pids=()

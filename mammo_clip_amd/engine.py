@@ -312,8 +312,11 @@ class Trainer:
         if self.scaler is not None and self.scaler._state is not None:
             # device scalars (no sync): the scale the NEXT step will use and the skipped-step count so far (a skip
             # must be visible to the caller like scaler.get_scale() is in the reference's loop)
-            out["loss_scale"] = self.scaler._state[LossScaler._SCALE]
-            out["skipped_steps"] = self.scaler._state[LossScaler._SKIPPED]
+            # SNAPSHOTS (one small clone launch each, still no sync): a caller that stores them for logging must not see later
+            # steps' update kernels overwrite them.  Note for callers that iterate over the dict: these two keys
+            # are not loss terms.
+            out["loss_scale"] = self.scaler._state[LossScaler._SCALE].clone()
+            out["skipped_steps"] = self.scaler._state[LossScaler._SKIPPED].clone()
         return out
 
     def _backward(self, run):

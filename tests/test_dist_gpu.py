@@ -104,6 +104,8 @@ rank, port, outdir = int(sys.argv[2]), sys.argv[3], sys.argv[4]
 backend = sys.argv[5] if len(sys.argv) > 5 else "gloo"          # "nccl" = RCCL, one GPU per rank
 micro = int(sys.argv[6]) if len(sys.argv) > 6 else 1
 overlap = (int(sys.argv[7]) if len(sys.argv) > 7 else 1) != 0
+keep = int(sys.argv[8]) if len(sys.argv) > 8 else 1              # kept graphs of the micro-batched step
+recompute = int(sys.argv[9]) if len(sys.argv) > 9 else 0         # MBConv recompute mode of the model
 import torch, torch.distributed as dist
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 dev = torch.device("cuda:%d" % (rank if backend == "nccl" else 0)); torch.cuda.set_device(dev)
@@ -146,8 +148,10 @@ if micro > 1:
     for lyr in model.text_encoder.text_encoder.encoder.layer:
         lyr.p_attn = lyr.p_hidden = 0.0
     model.text_encoder.text_encoder.config.hidden_dropout_prob = 0.0
+if recompute:
+    model.image_encoder.set_recompute(recompute)
 tr = engine.Trainer(model, build_loss(loss_cfg), torch.optim.SGD(model.parameters(), lr=0.0), None, dev, bucket_mb=16,
-                    overlap_micro=overlap, grad_sink=not overlap)    # overlapped hooks <-> plain autograd accumulation; serial <-> sink
+                    overlap_micro=overlap, grad_sink=not overlap, keep_graphs=keep)    # overlapped hooks <-> plain autograd accumulation; serial <-> sink
 assert tr.buckets is not None and len(tr.buckets.buckets) > 3
 out = tr.step(bt, micro_batches=micro)
 torch.save({"loss": float(out["total"]), "grads": {n: p.grad.detach().cpu() for n, p in model.named_parameters() if p.grad is not None}},
@@ -245,11 +249,12 @@ def _single_process_reference(n_pairs, k, stochastic_off):
     return float(out["total"]), {n: p.grad.detach().cpu() for n, p in model.named_parameters() if p.grad is not None}
 
 
-def _run_two_ranks(tmp_path, port, backend, micro, overlap=1):
+def _run_two_ranks(tmp_path, port, backend, micro, overlap=1, keep=1, recompute=0):
     script = tmp_path / "w2.py"
     script.write_text(WORKER2)
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(r), str(port), str(tmp_path), backend, str(micro), str(overlap)],
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(r), str(port), str(tmp_path), backend, str(micro), str(overlap),
+                               str(keep), str(recompute)],
                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env) for r in range(2)]
     outs = [p.communicate(timeout=900) for p in procs]
     assert all(p.returncode == 0 and "DP-OK" in o[0] for p, o in zip(procs, outs)), [o[1][-3000:] for o in outs]
@@ -305,6 +310,18 @@ def test_two_rank_micro_batched_step_overlapped_buckets(tmp_path):
     # gradients differs in the last fp32 bit, and BatchNorm over 8 samples per channel (2 images of 2x2 pixels in the
     # last stages at this test size) amplifies that: a few per cent on the deepest layers
     ref_loss, ref_g = _single_process_reference(8, 4, True)
+    _check_against_reference(r0, r1, ref_loss, ref_g, tol=None)
+
+
+@pytest.mark.gpu
+def test_two_rank_kept_graphs_recompute3_is_the_n8_policy(tmp_path):
+    """The policy bench.py picks for the 8-GPU point of the headline workload (bench.py: 128 pairs per GPU = 4 micro-batches,
+    ALL FOUR graphs kept in MBConv recompute mode 3, gradient sink, buckets reduced after the last backward) at world size 2
+    over gloo == the single-process step over the concatenated batch with 8 micro-batches (one kept graph, 7 re-forwards,
+    mode 0): same loss, same averaged gradients -- the kept-graph / recompute path changes what is stored, not what is
+    computed [ref: trainer_ddp.py:53-63,134; util/dist_autograd.py:5-27]."""
+    r0, r1 = _run_two_ranks(tmp_path, 29893, "gloo", 4, overlap=0, keep=4, recompute=3)
+    ref_loss, ref_g = _single_process_reference(16, 8, True)
     _check_against_reference(r0, r1, ref_loss, ref_g, tol=None)
 
 
