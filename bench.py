@@ -31,6 +31,12 @@ The JSON line carries, besides the contract fields:
                   1 -> 8 scaling curve should be read against (the N = 1 point itself carries 31 re-forwards)
   cpu_baseline -- the CPU oracle (oracle/, torch-fp32 restatement of the reference) timed on this box's host cores
                   on a bounded sample of the same workload (rank 0, N = 1 only)
+  parity       -- (N = 1) |loss - fp32 oracle| of THIS run's kernel-library build at the workload's per-sample shape, eval and
+                  train mode, 2 pairs, identical weights / inputs (oracle/probe.py: the oracle is the checker, run on the GPU
+                  after the timed region)
+  parity_build -- (N = 1, bf16 runs) the same workload on the f16 storage build (the reference's AMP dtype; the build that
+                  meets north_star's 1e-3 in train mode), timed for one step in a child process of this
+                  run, with ITS parity object: throughput and tolerance are evidenced by the same command
 """
 import argparse
 import json
@@ -205,6 +211,8 @@ def main():
     ap.add_argument("--loss", default="breast_clip", choices=("breast_clip", "breast_clip_contrastive"),
                     help="breast_clip = the configured multi-view loss (2 views + 2 reports per pair: the headline metric); "
                          "breast_clip_contrastive = the single-view loss (1 image + 1 report per pair: SURVEY 8d's secondary metric)")
+    ap.add_argument("--no-parity", action="store_true", help="skip the parity / parity_build objects (loss deviation from the fp32 oracle)")
+    ap.add_argument("--parity-child", action="store_true", help=argparse.SUPPRESS)     # the f16-build leg spawned by the default run
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-n8-load", action="store_true", help="skip the n8_load block of the default N = 1 run")
     ap.add_argument("--fp8", action="store_true", help="fp8 (e4m3) operands for the late-stage 1x1 convolutions (config #5 arithmetic on any workload)")
@@ -405,6 +413,49 @@ def main():
               "note": "per-GPU load of the N = 8 run of this workload on ONE GPU, no collectives; 8 x this rate is the no-communication ceiling of the 8-GPU point"}
         del b8
 
+    stat_tapes_on = bool(getattr(trainer, "stat_tapes", False)) and args.micro_batches > args.keep_graphs
+    parity = parity_build = None
+    if rank == 0 and world == 1 and not args.no_parity and args.workload in ("cfg2", "cfg3", "cfg4") and not single:
+        # checker legs, after every timed region: free the benchmark's memory first
+        try:
+            del batch, ld
+        except NameError:
+            pass
+        trainer.optimizer.zero_grad(set_to_none=True)
+        del trainer, opt, sched
+        torch.cuda.empty_cache()
+        try:
+            from oracle import probe
+            model.image_encoder.set_recompute(0)
+            r = probe.loss_deviation(model, loss_func, arch_name, H, W, T, pairs=2, device=str(device))
+            parity = {"storage": os.environ.get("MC_STORAGE", "bf16").lower(), "tolerance": 1e-3,
+                      "eval_dloss": round(r["eval_dloss"], 6), "train_dloss": round(r["train_dloss"], 6),
+                      "eval_min_cos": round(r["eval_min_cos"], 6), "train_min_cos": round(r["train_min_cos"], 6),
+                      "within_tolerance": {"eval": abs(r["eval_dloss"]) <= 1e-3, "train": abs(r["train_dloss"]) <= 1e-3},
+                      "probe": f"{r['pairs']} pairs at {r['shape']}, identical synthetic weights and inputs, dropout / drop-connect off; "
+                               "checker = oracle/ (torch fp32 on this GPU, pinned to the reference by tests/golden)"}
+        except Exception as e:                    # pragma: no cover
+            parity = {"error": repr(e)}
+        if os.environ.get("MC_STORAGE", "bf16").lower() == "bf16" and not args.parity_child:
+            # the f16 storage build on the same workload: one timed step in a child process (the storage type is fixed when the
+            # kernel library is loaded), with its own parity object
+            del model
+            torch.cuda.empty_cache()
+            import subprocess
+            cmd = [sys.executable, os.path.abspath(__file__), "--storage", "f16", "--parity-child", "--workload", args.workload,
+                   "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-n8-load", "--roofline-in-timed-region"]
+            if args.batch:
+                cmd += ["--batch", str(args.batch)]
+            try:
+                pr = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, MC_STORAGE="f16"))
+                cj = json.loads([ln for ln in pr.stdout.splitlines() if ln.startswith("{")][-1])
+                parity_build = {"storage": "f16", "pairs_per_s": cj["value"], "ms_per_step": cj["ms_per_step"], "steps": cj["steps"],
+                                "peak_hbm_gb": cj["config"]["peak_hbm_gb"], "parity": cj.get("parity"),
+                                "note": "same workload, same policies, libmammoclip_hip_f16.so (IEEE f16 storage / MFMA operands, dynamic loss scale = "
+                                        "the reference's AMP configuration); child process of this run"}
+            except Exception as e:                # pragma: no cover
+                parity_build = {"error": repr(e)}
+
     if rank == 0:
         ms = dt / args.steps * 1e3
         pairs = b * world * args.steps / dt
@@ -469,7 +520,7 @@ def main():
                        "global_batch": b * world, "parallelism": f"dp{world}" + (f" x {args.micro_batches} micro-batches" if args.micro_batches > 1 else ""),
                        "loss": round(loss_val, 5), "peak_hbm_gb": round(peak_gb, 1), "peak_reserved_gb": round(peak_res_gb, 1),
                        "keep_graphs": args.keep_graphs, "recompute": args.recompute, "keep_recompute": keep_recompute,
-                       "stat_tapes": bool(getattr(trainer, "stat_tapes", False)) and args.micro_batches > args.keep_graphs,
+                       "stat_tapes": stat_tapes_on,
                        "streams": streams},
             "roofline": first, "roofline_runner_up": second, "roofline_third": third,
         }
@@ -486,6 +537,10 @@ def main():
                              "note": "per GPU; bytes / flops as tagged per launch (sum over the kernels' own inputs + outputs, i.e. the traffic of THIS pass structure, not SURVEY 8d's one-read-one-write minimum)"}
         if n8 is not None:
             res["n8_load"] = n8
+        if parity is not None:
+            res["parity"] = parity
+        if parity_build is not None:
+            res["parity_build"] = parity_build
         if dist_info is not None:
             res["rccl_ranks"] = dist_info["rccl_ranks"]
             res["dist"] = dist_info

@@ -267,6 +267,10 @@ typedef struct mc_dwconv_args {
      * argument block); 0 = not checked.  A launch whose kernel form would write a different number of rows is refused --
      * the form can change between the two calls through mc_dwconv_set_lane_mode / MC_DW_LANE. */
     int stat_rows;
+    /* round 6 -- mc_mbconv_xdw_fwd: the expand 1x1 conv in front of the depthwise conv, run inside its staging.  xw = the
+     * expand weight [c][cin] (16-bit, row-major, c = the depthwise conv's channels); x is then the BLOCK INPUT [n,h,w,cin]. */
+    const mc_bf16* xw;
+    int cin;
 } mc_dwconv_args;
 int mc_dwconv_stat_rows(const mc_dwconv_args* args);
 int mc_dwconv_bwd_data_stat_rows(const mc_dwconv_args* args);
@@ -293,6 +297,21 @@ int mc_dwconv_bwd_fused_supported(const mc_dwconv_args* args);
 int mc_dwconv_bwd_fused_preferred(const mc_dwconv_args* args);
 int mc_dwconv_bwd_fused_stat_rows(const mc_dwconv_args* args);
 int mc_dwconv_bwd_fused(const mc_dwconv_args* args, void* stream);
+/* Round 6 -- expand 1x1 conv -> BatchNorm0 + swish -> depthwise k x k conv of an MBConv block in ONE launch
+ * [ref: efficientnet_custom.py:104-111: _expand_conv, _bn0, _swish, _depthwise_conv]: the expanded tensor e = x . xw^T never
+ * exists in HBM.  The lane = column depthwise kernel (conv_lane.hip) stages the block input x (cin channels per pixel) instead
+ * of e: every wave turns 16-pixel groups of the staged rows into its workgroup's 32 expanded channels with
+ * v_mfma_f32_16x16x32 (weight slice resident in LDS as operand fragments), applies z = e*pro_scale + pro_shift and
+ * silu(z) to the fp32 accumulators (e is NOT rounded to 16 bits on the way, unlike the two-launch form), zeroes the static
+ * padding and writes the 16-bit activations into the LDS tile the stencil reads.  Everything behind the staging -- stencil,
+ * output tile, BatchNorm1 statistics partials of the output (stat_partials, mc_mbconv_xdw_stat_rows() rows) -- is the plain
+ * forward launch.  Arguments: the mc_dwconv_fwd block with x = block input [n,h,w,cin], xw, cin, pro_scale / pro_shift =
+ * BatchNorm0's scale / shift over the c expanded channels (required: training mode takes them from mc_bn_gram_partials +
+ * mc_bn_finalize or from a statistics tape, eval mode from the running statistics); epi_* must be NULL.
+ * _supported: k in {3,5}, stride in {1,2}, c % 8 == 0, cin % 8 == 0, cin <= 128. */
+int mc_mbconv_xdw_supported(const mc_dwconv_args* args);
+int mc_mbconv_xdw_stat_rows(const mc_dwconv_args* args);
+int mc_mbconv_xdw_fwd(const mc_dwconv_args* args, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * training-mode BatchNorm pieces [ref: efficientnet_custom.py:64,74,88,177,205; momentum 0.01, eps 1e-3]
@@ -373,6 +392,14 @@ int mc_bn_fold_cvec(const float* gt, const float* we, const float* coef, const f
                     double rows, int n, int k, mc_bf16* gtb, float* cvec, void* stream);
 int mc_bn_fold_wgrad(const float* t1, const float* wx, const float* coef, const float* dbeta, const float* colsum_x,
                      double rows, int n, int k, float* dwe, void* stream);
+/* Round 6 -- training-mode BatchNorm statistics of e = x . W^T (W [n, k] 16-bit, the MFMA operand image) WITHOUT e
+ * [ref: efficientnet_custom.py:104-105: _expand_conv -> _bn0]: column sums and sums of squares of e follow from the k x k Gram
+ * matrix of the (6 x narrower) input: sum_e[c] = w_c . colsum(x), and with the centred Gram S = x^T x - colsum (x) colsum / rows
+ * the centred second moment is w_c^T S w_c (evaluated in fp64).  Writes TWO partials rows [2][2][n] = (sum, sum of squares) rounded to fp32 + the rounding
+ * remainders (mc_bn_finalize adds its rows in fp64) in the layout mc_bn_finalize reads, so finalize / running statistics / the statistics tape are the code every other BatchNorm
+ * uses.  xtx [k, k] fp32 (mc_wgrad_rows_bf16(x, x) / the tile TN GEMM), colsum_x [k] fp32 (mc_colsum_bf16). */
+int mc_bn_gram_partials(const mc_bf16* w, int ldw, const float* xtx, const float* colsum_x, double rows, int n, int k,
+                        float* partials, void* stream);
 
 /* column sums of a bf16 matrix: out[c] = sum_m x[m, c]  (bias gradients).  partials: float[rows][c] */
 int mc_colsum_rows(long long m, int c);

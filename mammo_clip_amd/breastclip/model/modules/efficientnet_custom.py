@@ -210,6 +210,10 @@ FUSE_DW_BWD = os.environ.get("MC_FUSE_DW_BWD", "1") != "0"              # stride
 FUSE_PROJ_DGRAD = os.environ.get("MC_FUSE_PROJ_DGRAD", "1") != "0"        # projection data gradient with the SE / BatchNorm1 backward in its epilogue (ops.proj_dgrad_*)
 BN_FOLD_MIN_BYTES = int(os.environ.get("MC_BN_FOLD_MIN_BYTES", 250_000_000))
 BN_FOLD_S2_MIN_BYTES = int(os.environ.get("MC_BN_FOLD_S2_MIN_BYTES", 0))
+# round 6: blocks whose expand conv runs INSIDE the depthwise forward launch (ops.mbconv_xdw_fwd) wherever the expanded tensor
+# is not stored for a backward (graph-less forwards, recompute modes >= 1, eval): input widths up to this many channels
+# (measured per block shape, scripts/xdw_ab.py: the launch wins up to cin = 64; at cin = 128 it only breaks even)
+XDW_MAX_CIN = int(os.environ.get("MC_XDW_MAX_CIN", 64))
 
 
 class _StemFn(torch.autograd.Function):
@@ -299,10 +303,26 @@ class _MBConvFn(torch.autograd.Function):
         hw, ohw = h * w, oh * ow
         saved = {}
         rc = blk.recompute
+        wkkc = ops.transpose_f32(blk._depthwise_conv.weight.view(a.cexp, k * k), cache=True)
+        xdw = False
         if a.expand != 1:
             we = ops.cast_bf16(blk._expand_conv.weight.view(a.cexp, a.cin))
-            e, part0 = _expand_conv(blk, x, we, n * hw, training)
-            st0 = _bn_stats(part0, n * hw, blk._bn0, training)
+            # round 6: where no backward needs the expanded tensor e stored (no graph, or a recompute mode that rebuilds it), the
+            # expand conv runs inside the depthwise launch's staging and e never exists in HBM: BatchNorm0's batch statistics
+            # then come from the Gram matrix of the block input (one pass over x, 6 x narrower than e), from the statistics
+            # tape of a re-forward, or from the running statistics (eval)
+            # (autograd runs Function.forward with grad mode off and reports needs_input_grad from requires_grad alone:
+            # whether a graph is being recorded is noted by MBConvBlock.forward before the call)
+            xdw = (rc >= 1 or not blk.__dict__.get("_recording", True)) and blk.xdw_ok(n, h, w, oh, ow)
+            if xdw:
+                part0 = ops.bn_gram_partials(x, we, n * hw) if (training and not _replaying()) else None
+                st0 = _bn_stats(part0, n * hw, blk._bn0, training)
+                e = None
+                d, part1 = _conv_stats(ops.mbconv_xdw_fwd, training, x, we, (st0.scale, st0.shift), wkkc, n, h, w, a.cexp, k, s,
+                                       l, t, oh, ow)
+            else:
+                e, part0 = _expand_conv(blk, x, we, n * hw, training)
+                st0 = _bn_stats(part0, n * hw, blk._bn0, training)
             dw_in, pro0 = e, (st0.scale, st0.shift)
             saved.update(we=we, e=None if rc >= 1 else e, st0=st0)
         else:
@@ -310,8 +330,8 @@ class _MBConvFn(torch.autograd.Function):
             link = blk.__dict__.pop("_in_link", None)
             dw_in, pro0 = x, ((link.st.scale, link.st.shift) if link is not None else None)
             saved.update(link=link)
-        wkkc = ops.transpose_f32(blk._depthwise_conv.weight.view(a.cexp, k * k), cache=True)
-        d, part1 = _conv_stats(ops.dwconv_fwd, training, dw_in, wkkc, n, h, w, a.cexp, k, s, l, t, oh, ow, pro=pro0)
+        if not xdw:
+            d, part1 = _conv_stats(ops.dwconv_fwd, training, dw_in, wkkc, n, h, w, a.cexp, k, s, l, t, oh, ow, pro=pro0)
         st1 = _bn_stats(part1, n * ohw, blk._bn1, training)
         # Late stages (project conv on the tiled GEMM): the squeeze pass also stores A = silu(bn1(d)); the project GEMM
         # and its weight gradient then apply only the SE gate instead of re-evaluating BN+SiLU per output tile.
@@ -346,7 +366,7 @@ class _MBConvFn(torch.autograd.Function):
         # tensor e, 2 also the depthwise output d (+ the stored activation of the late stages), 4 also the projection
         # output p; the backward rebuilds them from the block input x and the saved BatchNorm coefficients
         saved.update(x=x, d=None if rc >= 2 else d, p=None if rc >= 4 else p, wkkc=wkkc, wp=wp, st1=st1, st2=st2, pooled=pooled, gate=gate,
-                     act1=None if rc >= 2 else act1, keep_act=keep,
+                     act1=None if rc >= 2 else act1, keep_act=keep, xdw=xdw,
                      rowscale=rowscale if a.skip else None, geo=(n, h, w, oh, ow))
         ctx.blk, ctx.saved = blk, saved
         blk._out_geo = (n, oh, ow)
@@ -370,8 +390,12 @@ class _MBConvFn(torch.autograd.Function):
                 e = _expand_conv(blk, x, sv["we"], n * hw, recompute=True)
         link = sv.get("link")
         if d is None:
-            d = ops.dwconv_fwd(e if a.expand != 1 else x, sv["wkkc"], n, h, w, a.cexp, k, s, l, t, oh, ow,
-                               pro=(st0.scale, st0.shift) if a.expand != 1 else ((link.st.scale, link.st.shift) if link is not None else None))
+            if sv.get("xdw"):
+                # the forward produced d with the fused launch (from the UNROUNDED expand output): rebuilt the same way, bit for bit
+                d = ops.mbconv_xdw_fwd(x, sv["we"], (st0.scale, st0.shift), sv["wkkc"], n, h, w, a.cexp, k, s, l, t, oh, ow)
+            else:
+                d = ops.dwconv_fwd(e if a.expand != 1 else x, sv["wkkc"], n, h, w, a.cexp, k, s, l, t, oh, ow,
+                                   pro=(st0.scale, st0.shift) if a.expand != 1 else ((link.st.scale, link.st.shift) if link is not None else None))
             if sv["keep_act"]:
                 act1 = ops.bnact_pool(d, n, ohw, a.cexp, st1.scale, st1.shift, 1, keep_act=True)[1]
         if p is None:                                        # mode 4: the projection conv again, from the rebuilt d
@@ -589,6 +613,13 @@ class MBConvBlock(nn.Module):
         self.register_buffer("_ones", torch.ones(cin), persistent=False)
         self.register_buffer("_zeros", torch.zeros(cin), persistent=False)
 
+    def xdw_ok(self, n, h, w, oh, ow):
+        """does this block's forward take the fused expand + depthwise launch (ops.mbconv_xdw_fwd) when its expanded tensor
+        need not be stored?"""
+        a = self.args
+        return (a.expand != 1 and a.cin <= XDW_MAX_CIN and not self.fp8
+                and ops.mbconv_xdw_ok(n, h, w, a.cin, a.cexp, a.k, a.s, a.pad[0], a.pad[2], oh, ow))
+
     def _params(self):
         """the block's Parameter objects in ``_param_names`` order (cached: ``named_parameters`` walks the module tree)"""
         # cached with the (owner dict, key) slot of every parameter: a Parameter OBJECT survives .to() / load_state_dict (both
@@ -610,6 +641,7 @@ class MBConvBlock(nn.Module):
         return ps
 
     def forward(self, inputs, n, h, w, rowscale=None):
+        self.__dict__["_recording"] = torch.is_grad_enabled()      # is an autograd graph being recorded for this call?
         return _MBConvFn.apply(inputs, rowscale, self, n, h, w, *self._params())
 
 
@@ -712,6 +744,22 @@ class EfficientNet(nn.Module):
             a = blk.args
             blk.recompute = int(mode) if mode != 3 else (2 if (a.k == 3 and a.s == 1 and a.expand != 1) else 1)
         return self
+
+    def xdw_reforward_modes(self):
+        """Micro-batched step (engine._step_micro): the graph-less first forward of a micro-batch runs its narrow-input blocks
+        through the fused expand + depthwise launch (no expanded tensor).  Its re-forward -- same inputs, replayed statistics,
+        graph recorded -- must produce the SAME embeddings, so those blocks take recompute mode 1 there (fused forward, the
+        expanded tensor rebuilt by one GEMM in the backward) instead of the two-launch forward that rounds e to 16 bits first.
+        Returns the list of (block, previous mode) to restore."""
+        changed = []
+        if not ops.XDW:
+            return changed
+        for blk in self._blocks:
+            a = blk.args
+            if blk.recompute == 0 and a.expand != 1 and a.cin <= XDW_MAX_CIN and not blk.fp8:
+                changed.append((blk, blk.recompute))
+                blk.recompute = 1
+        return changed
 
     def set_swish(self, memory_efficient=True):
         """No-op: the swish is always the fused, recompute-in-backward form."""

@@ -79,7 +79,51 @@ __global__ void fold_wgrad_k(const float* __restrict__ t1, const float* __restri
     }
 }
 
+// Round 6 (mc_mbconv_xdw_fwd runs the expand conv inside the depthwise kernel: e never exists).  BatchNorm0 batch statistics of
+// e = x W^T from the Gram matrix of x: one workgroup per expanded channel c,
+//     sum_e[c] = w_c . cs,      sumsq_e[c] = w_c^T S w_c + sum_e[c]^2 / rows,      S = x^T x - cs cs^T / rows   (centred, fp64)
+// written as TWO partials rows (value rounded to fp32 + the rounding remainder): mc_bn_finalize adds its rows in fp64, so the
+// variance does not lose the digits a single fp32 sum of squares would drop when mean^2 >> var.
+__global__ __launch_bounds__(256) void gram_partials_k(const bf16_t* __restrict__ w, int ldw, const float* __restrict__ xtx,
+                                                       const float* __restrict__ cs, double rows, int n, int k,
+                                                       float* __restrict__ part) {
+    const int c = blockIdx.x;
+    const bf16_t* wc = w + (long long)c * ldw;
+    double s = 0.0, q = 0.0;
+    for (int j = threadIdx.x; j < k; j += 256) s += (double)bf2f(wc[j]) * (double)cs[j];
+    for (int idx = threadIdx.x; idx < k * k; idx += 256) {
+        const int i = idx / k, j = idx - i * k;
+        const double sij = (double)xtx[idx] - (double)cs[i] * (double)cs[j] / rows;
+        q += (double)bf2f(wc[i]) * sij * (double)bf2f(wc[j]);
+    }
+    __shared__ double red[2][256];
+    red[0][threadIdx.x] = s; red[1][threadIdx.x] = q;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (threadIdx.x < st) { red[0][threadIdx.x] += red[0][threadIdx.x + st]; red[1][threadIdx.x] += red[1][threadIdx.x + st]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double sum = red[0][0];
+        double sq = red[1][0];
+        if (sq < 0.0) sq = 0.0;
+        sq += sum * sum / rows;
+        const float s_hi = (float)sum, q_hi = (float)sq;
+        part[c] = s_hi; part[n + c] = q_hi;                                    // row 0: (sum, sumsq)
+        part[2 * n + c] = (float)(sum - (double)s_hi); part[3 * n + c] = (float)(sq - (double)q_hi);   // row 1: the remainders
+    }
+}
+
 }  // namespace
+
+extern "C" int mc_bn_gram_partials(const mc_bf16* w, int ldw, const float* xtx, const float* colsum_x, double rows, int n, int k,
+                                   float* partials, void* stream) {
+    MC_CHECK(w && xtx && colsum_x && partials && n > 0 && k > 0 && ldw >= k && rows > 0, "bn_gram_partials: bad args");
+    hipLaunchKernelGGL(gram_partials_k, dim3(n), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)w, ldw, xtx, colsum_x, rows, n, k,
+                       partials);
+    MC_LAUNCH_CHECK();
+    return MC_OK;
+}
 
 extern "C" int mc_bn_fold_prepare(const float* we, const float* coef, const float* xtx, const float* colsum_x, double rows,
                                   int n, int k, mc_bf16* w1t, mc_bf16* wb, mc_bf16* sxx, void* stream) {

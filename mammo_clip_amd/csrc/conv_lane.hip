@@ -65,6 +65,10 @@ template <int K, int S, int NCOL, int G = 1> struct Cfg {
     static constexpr int NVO = (ORB * G * TOW * VPP + NT - 1) / NT;
     static constexpr int LDS_BYTES = (2 * IN_DW + 2 * OUT_DW) * 4 + 2 * TCH * 4 + (128 * 16 + 24) * 4;
     static constexpr int LDS_BYTES_FUSED = LDS_BYTES + 2 * OUT_DW * 4;      // MODE 3: the e rows have a tile of their own
+    // MODE 4 (expand conv inside the staging): the staged pixels of a block in 16-pixel MFMA column groups, MTW per wave
+    static constexpr int PB = RB * G * IW_T;
+    static constexpr int NT16 = (PB + 15) / 16;
+    static constexpr int MTW = (NT16 + WAVES - 1) / WAVES;
     static_assert(RB % S == 0 && (K - 1) % S == 0, "block / tap geometry");
     static_assert(TOW <= LPI * NCOL, "a group's lanes cover its segment");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
@@ -92,11 +96,22 @@ constexpr int NDESC = 128;
 // a0 and of the packed e values, which the epilogue needs again when the row completes); the e rows therefore enter K-1 rows
 // EARLIER than in MODE 1 and get an LDS tile of their own.  dd and e are read once, dZ0 is written once: 3 passes over the
 // expanded tensor instead of 5 (MODE 1: dd + e read, dZ0 written; MODE 2: dd + e read).
-template <int K, int S, int NCOL, int MODE, int G>
+// MODE 4 (round 6, mc_mbconv_xdw_fwd): the forward launch with the EXPAND 1x1 CONV of the MBConv block inside the staging
+// [ref: efficientnet_custom.py:104-111: _expand_conv -> _bn0 -> swish -> _depthwise_conv].  The global tensor is the block input x
+// (cin = 32 * KC channels at most, 6 x narrower than the expanded tensor e, which never exists in HBM): the staged pixels of a
+// block are cut into 16-pixel groups, MTW per wave; a lane prefetches its 16-byte pieces of x straight into MFMA B-operand
+// fragments (pixel = lane & 15, k group = lane >> 4), one block ahead like the plain form's vectors; at store time the wave runs
+// D = W_frag . X_frag^T on v_mfma_f32_16x16x32 against the workgroup's 32 x cin weight slice (resident in LDS as A-operand
+// fragments), which leaves every lane with 2 x 4 consecutive expanded channels of ONE pixel: BatchNorm0 + swish on the fp32
+// accumulators, zero for the static padding, 16-bit pairs into the [row][position][17 dwords] tile -- the layout the stencil
+// reads, so everything behind the staging (stencil, output tile, BatchNorm1 statistics) is MODE 0 unchanged.
+template <int K, int S, int NCOL, int MODE, int G, int KC = 0>
 __global__ __launch_bounds__(1024, 4) void dwconv_lane_fwd_kernel(const mc_dwconv_args p, int strips, int nunits, int cpairs,
                                                                   int ctiles, int ymax, int xmap) {
     using C = Cfg<K, S, NCOL, G>;
     constexpr bool FUSED = MODE == 3;
+    constexpr bool XF = MODE == 4;
+    static_assert(!XF || (KC >= 1 && KC <= 4), "MODE 4: cin <= 128");
     constexpr bool EPI = MODE == 1 || FUSED, BWW = MODE == 2, ETILE = EPI || BWW;       // ETILE: a second global tensor staged beside the input
     static_assert(!EPI || S == 1, "the BatchNorm-backward epilogue is provided for stride 1");
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
@@ -105,6 +120,7 @@ __global__ __launch_bounds__(1024, 4) void dwconv_lane_fwd_kernel(const mc_dwcon
     uint32_t* const s_e = FUSED ? smem + 2 * C::IN_DW + 2 * C::OUT_DW : s_out;   // e / dy rows (MODE 1 / 2: they travel in the output tile)
     float* const pro_lds = reinterpret_cast<float*>(smem + 2 * C::IN_DW + (FUSED ? 4 : 2) * C::OUT_DW);   // [2][TCH]
     int* const s_desc = reinterpret_cast<int*>(pro_lds + 2 * C::TCH);                        // [NDESC][D_WORDS]
+    uint4* const s_w = reinterpret_cast<uint4*>(smem + C::LDS_BYTES / 4);                    // MODE 4: [KC][2][64] A-operand fragments
 
     // ---- workgroup -> (channel tile, virtual-row range); the two tiles of a 128-byte line share an XCD (block id % 8)
     const int bid = blockIdx.x;
@@ -163,16 +179,28 @@ __global__ __launch_bounds__(1024, 4) void dwconv_lane_fwd_kernel(const mc_dwcon
         const float* src = tid < C::TCH ? p.pro_scale : p.pro_shift;
         pro_lds[tid] = (c0 + ch < p.c) ? src[c0 + ch] : 0.f;
     }
+    if constexpr (XF) {
+        // expand weights of the tile's 32 channels as MFMA A-operand fragments: fragment (kc, f), lane (i = l & 15, kg = l >> 4) =
+        // xw[c0 + f*16 + i][kc*32 + kg*8 .. +8]; zero rows / columns beyond c / cin
+        for (int idx = tid; idx < KC * 2 * 64; idx += C::NT) {
+            const int l = idx & 63, f = (idx >> 6) & 1, kc = idx >> 7;
+            const int ch = c0 + f * 16 + (l & 15), k = kc * 32 + (l >> 4) * 8;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (ch < p.c && k < p.cin) v = *reinterpret_cast<const uint4*>(p.xw + (long long)ch * p.cin + k);
+            s_w[idx] = v;
+        }
+    }
 
     // (plain local copies: lambdas that capture the by-value argument struct by reference make the compiler keep a
     // private-memory image of it)
     const int a_h = p.h, a_w = p.w, a_c = p.c, a_oh = p.oh, a_ow = p.ow, a_pad_t = p.pad_t, a_pad_l = p.pad_l, a_n = p.n;
+    const int a_cin = XF ? p.cin : p.c;                                  // channels per pixel of the STAGED global tensor
     const bf16_t* const a_x = p.x;
     const bf16_t* const a_epi_x = p.epi_x;
     const bf16_t* const a_dy = p.dy;
     bf16_t* const a_out = reinterpret_cast<bf16_t*>(p.out);
     // ---- per-thread staging geometry (constant for the whole kernel)
-    const int in_row_pitch = a_w * a_c, out_row_pitch = a_ow * a_c;      // elements (< 2^31: one image row)
+    const int in_row_pitch = a_w * a_cin, out_row_pitch = a_ow * a_c;    // elements (< 2^31: one image row)
     const int in_img_pitch = G > 1 ? a_h * in_row_pitch : 0, out_img_pitch = G > 1 ? a_oh * out_row_pitch : 0;   // (G > 1: small maps)
     const int vv = tid % C::VPP;
     const bool st_ch = c0 + vv * 8 < p.c;
@@ -220,10 +248,29 @@ __global__ __launch_bounds__(1024, 4) void dwconv_lane_fwd_kernel(const mc_dwcon
             goffo[i] = (int)((metao[i] >> 4) & 0xfu) * out_img_pitch + (int)(metao[i] & 0xfu) * out_row_pitch + (int)((metao[i] >> 8) & 0xffu) * a_c;
     }
 
+    // ---- MODE 4: the lane's pixel in each of its wave's MTW 16-pixel groups (B-operand column = lane & 15, k group = lane >> 4)
+    const int xkg = x >> 4;
+    unsigned xmeta[XF ? C::MTW : 1];                       // row | segment << 4 | col << 8 | LDS dword offset of the pixel << 16
+    int xgoff[XF ? C::MTW : 1];
+    unsigned xkok = 0;                                     // bit kc: this lane's 8 input channels of K chunk kc exist
+    if constexpr (XF) {
+#pragma unroll
+        for (int j = 0; j < C::MTW; ++j) {
+            const int pidx = (wv * C::MTW + j) * 16 + (x & 15);
+            const int row = pidx / (G * C::IW_T), seg = (pidx % (G * C::IW_T)) / C::IW_T, col = pidx % C::IW_T;
+            const int pos = seg * C::SEGP + (col % C::NS) * C::HQ + col / C::NS;
+            xmeta[j] = (unsigned)row | ((unsigned)seg << 4) | ((unsigned)col << 8) | ((unsigned)((row * C::IWP + pos) * C::PXD) << 16);
+            if (pidx >= C::PB) xmeta[j] = 0xffffu;
+            xgoff[j] = seg * in_img_pitch + row * in_row_pitch + col * a_cin + xkg * 8;
+        }
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) xkok |= (kc * 32 + xkg * 8 < a_cin ? 1u : 0u) << kc;
+    }
+
     // ---- block descriptors: closed form of (block index -> item, block of the item), 64 blocks at a time by the lanes
     // of wave 0.  A range is: rest of the first (image, strip) unit, whole units, head of the last unit.
     int* const s_gen = s_desc + NDESC * D_WORDS;                      // range parameters (thread 0 computes them once)
-    enum { G_U0 = 0, G_U1, G_O0, G_O1, G_NR0, G_NB0, G_NBF, G_NFULL, G_NBTOT, G_H, G_W, G_C, G_OH, G_OW, G_PT, G_PL, G_STRIPS, G_C0, G_N, G_WORDS = 24 };
+    enum { G_U0 = 0, G_U1, G_O0, G_O1, G_NR0, G_NB0, G_NBF, G_NFULL, G_NBTOT, G_H, G_W, G_C, G_OH, G_OW, G_PT, G_PL, G_STRIPS, G_C0, G_N, G_CIN, G_WORDS = 24 };
     auto nblk_of = [&](int nrows) { return ((nrows - 1) * S + K + C::RB - 1) / C::RB; };
     if (tid == 0) {
         const long long vt = (long long)((a_n + G - 1) / G) * strips * a_oh;      // (image groups, strip, row)
@@ -237,7 +284,7 @@ __global__ __launch_bounds__(1024, 4) void dwconv_lane_fwd_kernel(const mc_dwcon
         s_gen[G_U0] = u0; s_gen[G_U1] = u1; s_gen[G_O0] = o0; s_gen[G_O1] = o1; s_gen[G_NR0] = nr0; s_gen[G_NB0] = nb0;
         s_gen[G_NBF] = nbf; s_gen[G_NFULL] = nfull; s_gen[G_NBTOT] = nb0 + nfull * nbf + nbl;   // blocks of this workgroup
         s_gen[G_H] = a_h; s_gen[G_W] = a_w; s_gen[G_C] = a_c; s_gen[G_OH] = a_oh; s_gen[G_OW] = a_ow; s_gen[G_PT] = a_pad_t;
-        s_gen[G_PL] = a_pad_l; s_gen[G_STRIPS] = strips; s_gen[G_C0] = c0; s_gen[G_N] = a_n;
+        s_gen[G_PL] = a_pad_l; s_gen[G_STRIPS] = strips; s_gen[G_C0] = c0; s_gen[G_N] = a_n; s_gen[G_CIN] = a_cin;
     }
     __syncthreads();
     const int nbtot = __builtin_amdgcn_readfirstlane(s_gen[G_NBTOT]);
@@ -260,7 +307,9 @@ __global__ __launch_bounds__(1024, 4) void dwconv_lane_fwd_kernel(const mc_dwcon
         const int img = grp * G;                                        // first image of the group
         const int ox0 = strip * C::TOW;
         const int iy0 = oy0 * S - g_pt + b * C::RB, ix0 = ox0 * S - g_pl;
-        const long long inb = (((long long)img * g_h + iy0) * g_w + ix0) * (long long)g_c + g_c0;
+        // (MODE 4 stages the block input: cin channels per pixel, all of them -- no channel-tile offset)
+        const long long inb = XF ? (((long long)img * g_h + iy0) * g_w + ix0) * (long long)s_gen[G_CIN]
+                                 : (((long long)img * g_h + iy0) * g_w + ix0) * (long long)g_c + g_c0;
         const int need = (nrows - 1) * S + K - b * C::RB;             // input rows of this block the item still needs
         int rhi = g_h - iy0; if (rhi > C::RB) rhi = C::RB; if (rhi > need) rhi = need;
         int chi = g_w - ix0; if (chi > C::IW_T) chi = C::IW_T;
@@ -289,8 +338,10 @@ __global__ __launch_bounds__(1024, 4) void dwconv_lane_fwd_kernel(const mc_dwcon
     for (int i = tid; i < (FUSED ? 4 : 2) * C::OUT_DW + ((BWW || FUSED) ? 2 * C::IN_DW : 0); i += C::NT) ((BWW || FUSED) ? s_in : s_out)[i] = 0u;
     __syncthreads();                                        // pro_lds, descriptors
 
-    uint4 vals[C::NV];
+    uint4 vals[XF ? 1 : C::NV];
     unsigned inb = 0;
+    uint4 xf[XF ? C::MTW : 1][XF ? KC : 1];               // MODE 4: B-operand fragments of the block in flight
+    unsigned xinb = 0;
     uint4 evals[ETILE ? C::NVO : 1];
     unsigned einb = 0;
     // global -> registers for block q
@@ -300,6 +351,19 @@ __global__ __launch_bounds__(1024, 4) void dwconv_lane_fwd_kernel(const mc_dwcon
         const int* d = s_desc + (q & (NDESC - 1)) * D_WORDS;
         const long long base = ((long long)d[D_INB_HI] << 32) | (unsigned)d[D_INB_LO];
         const int rlo = d[D_RLO], rhi = d[D_RHI], clo = d[D_CLO], chi = d[D_CHI], nseg = d[D_NSEG];
+        if constexpr (XF) {
+            const bf16_t* org = a_x + base;
+            xinb = 0;
+#pragma unroll
+            for (int j = 0; j < C::MTW; ++j) {
+                const int row = (int)(xmeta[j] & 0xfu), seg = (int)((xmeta[j] >> 4) & 0xfu), col = (int)((xmeta[j] >> 8) & 0xffu);
+                const bool ok = live && (xmeta[j] & 0xffffu) != 0xffffu && row >= rlo && row < rhi && col >= clo && col < chi && seg < nseg;
+#pragma unroll
+                for (int kc = 0; kc < KC; ++kc)     // unconditional loads, clamped addresses (zeroed at use where they do not exist)
+                    xf[j][kc] = *reinterpret_cast<const uint4*>((ok && ((xkok >> kc) & 1u)) ? org + xgoff[j] + kc * 32 : a_x);
+                xinb |= (ok ? 1u : 0u) << j;
+            }
+        } else {
         const bf16_t* org = a_x + base + vv * 8;
         inb = 0;
 #pragma unroll
@@ -312,6 +376,7 @@ __global__ __launch_bounds__(1024, 4) void dwconv_lane_fwd_kernel(const mc_dwcon
 #endif
             vals[i] = *reinterpret_cast<const uint4*>(ok ? org + in_off(i) : a_x);   // unconditional load, clamped address
             inb |= (ok ? 1u : 0u) << i;
+        }
         }
         if constexpr (ETILE) {                             // e rows of the output rows block q completes (MODE 3: that enter in it) / its dy rows
             const long long obase = FUSED ? (((long long)d[D_EB_HI] << 32) | (unsigned)d[D_EB_LO]) : (((long long)d[D_OUTB_HI] << 32) | (unsigned)d[D_OUTB_LO]);
@@ -331,6 +396,36 @@ __global__ __launch_bounds__(1024, 4) void dwconv_lane_fwd_kernel(const mc_dwcon
     // registers -> LDS in-buffer `buf` (BN+SiLU prologue on real pixels; padding stays zero)
     auto stage_store = [&](int buf) {
         uint32_t* dst = s_in + buf * C::IN_DW;
+        if constexpr (XF) {
+#pragma unroll
+            for (int j = 0; j < C::MTW; ++j) {
+                f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kc = 0; kc < KC; ++kc) {
+                    uint4 xv = xf[j][kc];
+                    if (!((xkok >> kc) & 1u)) xv = make_uint4(0u, 0u, 0u, 0u);      // (K padding: 0 * garbage must not be NaN)
+                    const bf16x8_t b = __builtin_bit_cast(bf16x8_t, xv);
+                    acc0 = MC_MFMA_16x16x32(__builtin_bit_cast(bf16x8_t, s_w[(kc * 2 + 0) * 64 + x]), b, acc0, 0, 0, 0);
+                    acc1 = MC_MFMA_16x16x32(__builtin_bit_cast(bf16x8_t, s_w[(kc * 2 + 1) * 64 + x]), b, acc1, 0, 0, 0);
+                }
+                if ((xmeta[j] & 0xffffu) != 0xffffu) {
+                    // the lane holds channels f*16 + kg*4 .. +3 (f = 0, 1) of pixel lane & 15: BatchNorm0 + swish, zero padding
+                    const uint32_t keep = ((xinb >> j) & 1u) ? 0xffffffffu : 0u;
+                    uint32_t* dd = dst + (xmeta[j] >> 16) + xkg * 2;
+#pragma unroll
+                    for (int f = 0; f < 2; ++f) {
+                        const f32x4_t a = f ? acc1 : acc0;
+                        const float4 sc = *reinterpret_cast<const float4*>(&pro_lds[f * 16 + xkg * 4]);
+                        const float4 sh = *reinterpret_cast<const float4*>(&pro_lds[C::TCH + f * 16 + xkg * 4]);
+                        const f32x2_t z0 = silu2_f(__builtin_elementwise_fma(f32x2_t{a[0], a[1]}, f32x2_t{sc.x, sc.y}, f32x2_t{sh.x, sh.y}));
+                        const f32x2_t z1 = silu2_f(__builtin_elementwise_fma(f32x2_t{a[2], a[3]}, f32x2_t{sc.z, sc.w}, f32x2_t{sh.z, sh.w}));
+                        dd[f * 8] = pack_bf2(z0.x, z0.y) & keep;
+                        dd[f * 8 + 1] = pack_bf2(z1.x, z1.y) & keep;
+                    }
+                }
+            }
+            return;
+        }
         float ps[8], pt[8];
         if (has_pro) { load8f(&pro_lds[vv * 8], ps); load8f(&pro_lds[C::TCH + vv * 8], pt); }
 #pragma unroll
@@ -659,10 +754,10 @@ template <typename C> Plan plan(const mc_dwconv_args& p) {
     return m;
 }
 
-template <typename C, int MODE> int launch(const mc_dwconv_args& p, hipStream_t st) {
+template <typename C, int MODE, int KC = 0> int launch(const mc_dwconv_args& p, hipStream_t st) {
     static unsigned long long attr_done = 0;
-    auto kern = dwconv_lane_fwd_kernel<C::K_, C::S_, C::NCOL_, MODE, C::G_>;
-    constexpr int lds = MODE == 3 ? C::LDS_BYTES_FUSED : C::LDS_BYTES;
+    auto kern = dwconv_lane_fwd_kernel<C::K_, C::S_, C::NCOL_, MODE, C::G_, KC>;
+    constexpr int lds = MODE == 3 ? C::LDS_BYTES_FUSED : (MODE == 4 ? C::LDS_BYTES + KC * 2048 : C::LDS_BYTES);
     static_assert(lds <= 160 * 1024, "LDS budget");
     MC_SET_MAX_LDS(attr_done, kern, lds);
     const Plan m = plan<C>(p);
@@ -789,4 +884,33 @@ extern "C" int mc_dwconv_bwd_weight_lane(const mc_dwconv_args* a, void* stream) 
     MC_CHECK(p.x && p.dy && p.out, "dwconv_bwd_weight_lane: null x / dy / out");
     hipStream_t st = (hipStream_t)stream;
     return lane::pick_ks<2>(p, [&](auto cfg) { return lane::launch<decltype(cfg), 2>(p, st); });
+}
+
+// ---- MODE 4: expand 1x1 conv + BatchNorm0 + swish inside the staging of the depthwise forward (include/mammoclip_hip.h)
+extern "C" int mc_mbconv_xdw_supported(const mc_dwconv_args* a) {
+    const mc_dwconv_args& p = *a;
+    if (!mc_dwconv_lane_supported(a) || p.epi_x) return 0;
+    return p.cin > 0 && p.cin % 8 == 0 && p.cin <= 128;
+}
+
+extern "C" int mc_mbconv_xdw_stat_rows(const mc_dwconv_args* a) {
+    const mc_dwconv_args& p = *a;
+    return lane::pick_ks<4>(p, [&](auto cfg) { return lane::plan<decltype(cfg)>(p).ymax; });
+}
+
+extern "C" int mc_mbconv_xdw_fwd(const mc_dwconv_args* a, void* stream) {
+    const mc_dwconv_args& p = *a;
+    MC_CHECK(mc_mbconv_xdw_supported(a), "mbconv_xdw_fwd: unsupported shape (k in {3,5}, stride in {1,2}, c % 8 == 0, cin % 8 == 0, cin <= 128, no epilogue)");
+    MC_CHECK(p.x && p.xw && p.w_kkc && p.out, "mbconv_xdw_fwd: null x / xw / w / out");
+    MC_CHECK(p.pro_scale && p.pro_shift, "mbconv_xdw_fwd: BatchNorm0 scale / shift (pro_scale / pro_shift) are required");
+    MC_CHECK(mc_aligned16(p.x) && mc_aligned16(p.xw) && mc_aligned16(p.out), "mbconv_xdw_fwd: operands must be 16-byte aligned");
+    MC_CHECK(!(p.stat_partials && p.stat_rows > 0) || p.stat_rows == mc_mbconv_xdw_stat_rows(a),
+             "mbconv_xdw_fwd: stat_partials was sized for another configuration");
+    hipStream_t st = (hipStream_t)stream;
+    return lane::pick_ks<4>(p, [&](auto cfg) {
+        using Cf = decltype(cfg);
+        if (p.cin <= 32) return lane::launch<Cf, 4, 1>(p, st);
+        if (p.cin <= 64) return lane::launch<Cf, 4, 2>(p, st);
+        return lane::launch<Cf, 4, 4>(p, st);
+    });
 }

@@ -400,6 +400,21 @@ def _step_micro(self, batch: Dict, k: int) -> Dict[str, torch.Tensor]:
          gradient buckets are all-reduced from the hooks of the LAST backward (overlapped with it).
     Cost: k - 1 extra forwards per step (of k forwards + k backwards); activation memory: one micro-batch."""
     model = self.model
+    enc_ = getattr(model, "image_encoder", None)
+    # round 6: a graph-less forward runs the narrow-input MBConv blocks through the fused expand + depthwise launch (the
+    # expanded tensor never exists); every other forward of a micro-batched step -- re-forwards AND kept graphs -- takes the same
+    # launch (recompute mode 1 on those blocks: the expanded tensor is rebuilt by one GEMM in the backward), so all micro-batches
+    # of a step see one arithmetic and a re-forward reproduces its first forward bit for bit
+    xdw_modes = enc_.xdw_reforward_modes() if hasattr(enc_, "xdw_reforward_modes") else []
+    try:
+        return self._step_micro_body(batch, k)
+    finally:
+        for blk, mode_ in xdw_modes:
+            blk.recompute = mode_
+
+
+def _step_micro_body(self, batch: Dict, k: int) -> Dict[str, torch.Tensor]:
+    model = self.model
     model.train()
     self.optimizer.zero_grad(set_to_none=True)
     if self.buckets is not None:
@@ -484,6 +499,7 @@ def _step_micro(self, batch: Dict, k: int) -> Dict[str, torch.Tensor]:
 
 
 Trainer._step_micro = _step_micro
+Trainer._step_micro_body = _step_micro_body
 
 
 def init_distributed():

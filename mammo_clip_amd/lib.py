@@ -75,6 +75,7 @@ class DwconvArgs(C.Structure):
         ("pro_scale", P), ("pro_shift", P), ("stat_partials", P),
         ("epi_x", P), ("epi_scale", P), ("epi_shift", P), ("epi_mean", P), ("epi_invstd", P),
         ("dw_out", P), ("stat_rows", I),
+        ("xw", P), ("cin", I),
     ]
 
 
@@ -140,6 +141,10 @@ _SIGS = {
     "mc_dwconv_bwd_fused_preferred": ([C.POINTER(DwconvArgs)], I),
     "mc_dwconv_bwd_fused_stat_rows": ([C.POINTER(DwconvArgs)], I),
     "mc_dwconv_bwd_fused": ([C.POINTER(DwconvArgs), P], I),
+    "mc_mbconv_xdw_supported": ([C.POINTER(DwconvArgs)], I),
+    "mc_mbconv_xdw_stat_rows": ([C.POINTER(DwconvArgs)], I),
+    "mc_mbconv_xdw_fwd": ([C.POINTER(DwconvArgs), P], I),
+    "mc_bn_gram_partials": ([P, I, P, P, D, I, I, P, P], I),
     "mc_bn_finalize": ([P, I, I, D, P, P, P, P, F, F, I, P, P, P, P, P], I),
     "mc_bn_eval_coeffs": ([P, P, P, P, F, I, P, P, P], I),
     "mc_bnact_rows": ([C.POINTER(BnactArgs)], I),

@@ -712,6 +712,55 @@ def dwconv_bwd_fused(dd, e, st, w_kkc_flipped, n, h, w, c, k, pad_l, pad_t, oh, 
     return dz, part, dw
 
 
+# ---- round 6: expand 1x1 conv + BatchNorm0 + swish inside the depthwise forward launch (conv_lane.hip MODE 4): the expanded
+# tensor of an MBConv block never exists in HBM when no backward needs it stored
+XDW = int(os.environ.get("MC_XDW", "1"))      # 0 never; 1 wherever the launch is supported (developer A/B switch)
+_XDW_OK = {}
+
+
+def mbconv_xdw_ok(n, h, w, cin, c, k, stride, pad_l, pad_t, oh, ow):
+    """does mc_mbconv_xdw_fwd take this block?  (geometry only; cached: the launch-bound configurations notice ctypes calls)"""
+    if not XDW:
+        return False
+    key = (n, h, w, cin, c, k, stride, pad_l, pad_t, oh, ow)
+    hit = _XDW_OK.get(key)
+    if hit is None:
+        a = _dw_args(n, h, w, c, k, stride, pad_l, pad_t, oh, ow)
+        a.cin = cin
+        hit = _XDW_OK[key] = bool(L.load().mc_mbconv_xdw_supported(C.byref(a)))
+    return hit
+
+
+def mbconv_xdw_fwd(x, we, pro, w_kkc, n, h, w, c, k, stride, pad_l, pad_t, oh, ow, stats=False):
+    """d [n*oh*ow, c] = depthwise(silu(bn0(x . we^T))) in ONE launch [ref: efficientnet_custom.py:104-111]; x [n*h*w, cin],
+    we [c, cin] (16-bit image), pro = (scale, shift) of BatchNorm0.  stats -> also the BatchNorm1 partials of d."""
+    cin = x.shape[1]
+    assert we.shape == (c, cin) and we.is_contiguous() and x.is_contiguous()
+    a = _dw_args(n, h, w, c, k, stride, pad_l, pad_t, oh, ow)
+    y = empty((n * oh * ow, c), BF16, x)
+    a.x, a.out, a.w_kkc, a.xw, a.cin = _p(x), _p(y), _p(w_kkc), _p(we), cin
+    a.pro_scale, a.pro_shift = _p(pro[0]), _p(pro[1])
+    part = None
+    if stats:
+        rows = L.load().mc_mbconv_xdw_stat_rows(C.byref(a))
+        part = empty((rows, 2, c), torch.float32, x)
+        a.stat_partials, a.stat_rows = _p(part), rows
+    _note(2 * n * (cin * h * w + c * oh * ow) + 2 * c * cin, 2 * n * c * (oh * ow * k * k + h * w * cin))
+    L.call("mc_mbconv_xdw_fwd", C.byref(a), _st(), kind=f"k{k}s{stride}")
+    return (y, part) if stats else y
+
+
+def bn_gram_partials(x, we, rows):
+    """BatchNorm statistics partials [2, 2, c] of e = x . we^T without e (bnfold.hip gram_partials_k): from the cin x cin Gram
+    matrix and the column sums of x -- one pass over the 6 x narrower block input instead of a statistics epilogue over e"""
+    c, cin = we.shape
+    xtx = linear_wgrad(x, x, tag="_xtx")
+    cs = colsum(x)
+    part = empty((2, 2, c), torch.float32, x)
+    L.call("mc_bn_gram_partials", _p(we), we.stride(0), _p(xtx), _p(cs), float(rows), c, cin, _p(part), _st())
+    return part
+
+
 def _dwconv_bwd_weight_impl(x, dy, n, h, w, c, k, stride, pad_l, pad_t, oh, ow, pro=None):
     a = _dw_args(n, h, w, c, k, stride, pad_l, pad_t, oh, ow)
     dw = torch.zeros((k * k, c), dtype=torch.float32, device=x.device)

@@ -1285,3 +1285,79 @@ def test_bnact_bwd_reduce_with_dz_store():
     # the plain reduce pass leaves the same partials and stores nothing
     de, dg, db = ops.bnact_bwd(x, n_img, hw, c, st, gamma, 1, g=g)
     check(db, sums[0], 1e-5, "dbeta == sum dz")
+
+
+# ------------------------------------------------------------------------------------------------ round 6: expand conv inside the depthwise launch
+XDW_CASES = [  # k, s, n, h, w, cin, c: strips / image groups / ragged channel tiles / all three K-chunk instances (cin <= 32, 64, 128)
+    (3, 1, 2, 70, 300, 40, 240), (3, 2, 2, 77, 131, 24, 144), (5, 2, 2, 120, 250, 40, 240), (5, 1, 3, 150, 130, 64, 384),
+    (3, 2, 3, 61, 95, 64, 384), (3, 1, 5, 95, 57, 128, 768), (5, 1, 3, 48, 57, 128, 200), (5, 1, 9, 48, 29, 48, 288),
+    (3, 1, 9, 7, 9, 16, 96), (5, 2, 3, 9, 11, 24, 144), (5, 1, 2, 33, 70, 88, 528), (3, 1, 1, 20, 20, 8, 48)]
+
+
+@pytest.mark.parametrize("k,s,n,h,w,cin,c", XDW_CASES)
+def test_mbconv_xdw_fused_expand_depthwise(k, s, n, h, w, cin, c):
+    """mc_mbconv_xdw_fwd (conv_lane.hip MODE 4): expand 1x1 conv -> BatchNorm0 + swish -> depthwise conv in one launch
+    [ref: efficientnet_custom.py:104-111] against (a) the fp32 torch composition and (b) the two launches it replaces.  The
+    fused launch does not round e to 16 bits before BatchNorm0 (the two-launch form does): (b) is therefore a closeness
+    check at the 16-bit rounding level, not bit equality; the BatchNorm1 statistics partials must be the sums of the STORED
+    output."""
+    pad = (k - 1) // 2 if s == 1 else (k - 2) // 2
+    oh, ow = (h + s - 1) // s, (w + s - 1) // s
+    x = rnd(n * h * w, cin, seed=41)
+    we = rnd(c, cin, seed=42, scale=cin ** -0.5)
+    wk = rnd(k * k, c, seed=43, dtype=torch.float32) * 0.3
+    pro = (rnd(c, seed=44, dtype=torch.float32) * 0.3 + 1.0, rnd(c, seed=45, dtype=torch.float32) * 0.3)
+    assert ops.mbconv_xdw_ok(n, h, w, cin, c, k, s, pad, pad, oh, ow)
+    y, part = ops.mbconv_xdw_fwd(x, we, pro, wk, n, h, w, c, k, s, pad, pad, oh, ow, stats=True)
+    torch.cuda.synchronize()
+    # (a) fp32 reference: activations rounded to 16 bits where the kernel rounds them (the staged tile), nothing else
+    e = x.float() @ we.float().T
+    a0 = F.silu(e * pro[0] + pro[1]).to(BF).float().view(n, h, w, c).permute(0, 3, 1, 2)
+    wt = wk.t().contiguous().view(c, 1, k, k)
+    ref = F.conv2d(F.pad(a0, (pad, k - 1 - pad + (s - 1), pad, k - 1 - pad + (s - 1))), wt, None, s, 0, 1, c)[:, :, :oh, :ow]
+    check(y.view(n, oh, ow, c).permute(0, 3, 1, 2), ref, 1e-2, "xdw vs fp32 torch")
+    # (b) the two launches: e rounded to 16 bits in between
+    e16 = ops.linear_fwd(x, we)
+    y2 = ops.dwconv_fwd(e16, wk, n, h, w, c, k, s, pad, pad, oh, ow, pro=pro)
+    check(y, y2, 2e-2, "xdw vs expand GEMM + depthwise launch")
+    st = part.double().sum(0)
+    yf = y.float().double()
+    check(st[0].float(), yf.sum(0).float(), 1e-4, "xdw colsum")
+    check(st[1].float(), (yf * yf).sum(0).float(), 1e-4, "xdw colsumsq")
+
+
+def test_mbconv_xdw_identity_weights_asymmetric_input():
+    """A = I check of the MFMA staging (operand / accumulator layout, pixel -> LDS position, zero padding): with the expand
+    weight a 0/1 selection matrix and BatchNorm0 the identity, the fused launch must equal the plain depthwise launch on the
+    selected channels BIT FOR BIT (silu is applied to exactly representable values in both)."""
+    k, s, n, h, w, cin, c = 3, 1, 2, 37, 131, 32, 64
+    x = rnd(n * h * w, cin, seed=51)
+    sel = torch.arange(c, device=DEV) * 7 % cin                 # asymmetric: expanded channel i reads input channel 7 i mod cin
+    we = torch.zeros(c, cin, device=DEV)
+    we[torch.arange(c, device=DEV), sel] = 1.0
+    we = we.to(BF)
+    wk = rnd(k * k, c, seed=53, dtype=torch.float32) * 0.3
+    one, zero = torch.ones(c, device=DEV), torch.zeros(c, device=DEV)
+    y = ops.mbconv_xdw_fwd(x, we, (one, zero), wk, n, h, w, c, k, s, 1, 1, h, w)
+    y2 = ops.dwconv_fwd(x[:, sel].contiguous(), wk, n, h, w, c, k, s, 1, 1, h, w, pro=(one, zero))
+    assert torch.equal(y, y2)
+
+
+@pytest.mark.parametrize("rows,cin,c,shift", [(20000, 40, 240, 0.0), (9000, 24, 144, 3.0), (12000, 64, 384, -1.5), (8200, 128, 768, 0.5)])
+def test_bn_statistics_from_the_gram_matrix(rows, cin, c, shift):
+    """mc_bn_gram_partials: training-mode BatchNorm statistics of e = x W^T from x^T x and colsum(x) alone, against fp64
+    statistics of the fp32 product (the tensor the fused launch normalises -- never rounded to 16 bits), including inputs
+    whose mean dominates their spread (mean^2 >> var on many channels)."""
+    x = (rnd(rows, cin, seed=61, dtype=torch.float32) + shift).to(BF)
+    we = rnd(c, cin, seed=62, scale=cin ** -0.5)
+    part = ops.bn_gram_partials(x, we, rows)
+    gamma, beta = torch.ones(c, device=DEV), torch.zeros(c, device=DEV)
+    rm, rv = torch.zeros(c, device=DEV), torch.ones(c, device=DEV)
+    st = ops.bn_finalize(part, rows, gamma, beta, rm, rv, 0.01, 1e-3, True)
+    e = x.double() @ we.double().T
+    mean, var = e.mean(0), e.var(0, unbiased=False)
+    assert float((st.mean.double() - mean).abs().max()) <= 1e-5 * float(mean.abs().max() + 1.0)
+    invstd = 1.0 / torch.sqrt(var + 1e-3)
+    assert float((st.invstd.double() / invstd - 1.0).abs().max()) <= 2e-5
+    assert float((rm.double() - 0.01 * mean).abs().max()) <= 1e-6 * float(mean.abs().max() + 1.0)
+    assert float((rv.double() - (0.99 + 0.01 * e.var(0, unbiased=True))).abs().max()) <= 1e-5 * float(var.max() + 1.0)

@@ -420,7 +420,11 @@ def test_micro_batched_step_matches_full_graph():
     model, lossf, sd = _build("tf_efficientnet_b5_ns-detect", "efficientnet-b5", stochastic_off=False)
     util.GlobalEnv.reset()
     model.train()
+    # (round 6: every forward of a micro-batched step runs the narrow-input blocks through the fused expand + depthwise launch
+    # -- graph-less, or recompute mode 1 where a graph is recorded: the ground truth takes the same arithmetic)
+    model.image_encoder.set_recompute(1)
     outs = [model(mb, DEV) for mb in mbs]
+    model.image_encoder.set_recompute(0)
     full = {kk: torch.cat([o[kk] for o in outs]) for kk in keys}
     ld = lossf(**full, labels=torch.arange(b, device=DEV), logit_scale=model.logit_scale.exp(), is_train=True)
     ld["total"].backward()
@@ -517,10 +521,24 @@ def test_recompute_modes_same_gradients_less_memory():
     b, H, W, T = [int(v) for v in z["meta"]]
     model, lossf, sd = _build("tf_efficientnet_b5_ns-detect", "efficientnet-b5")
     batch = ow.synth_batch(b, H, W, T, seed=33)
-    res = {}
     _o, _l = _run(model, lossf, batch, True)          # warm-up: derived weight images, caches of earlier tests settle
     _l["total"].backward()
     _o = _l = None
+    # round 6: with the fused expand + depthwise launch (ops.XDW) the modes that do not store the expanded tensor run a
+    # DIFFERENT forward for the narrow-input blocks (e is not rounded to 16 bits before BatchNorm0): modes 1-4 stay identical
+    # among themselves and are compared with mode 0 at the 16-bit rounding level; with the launch switched off every mode is
+    # the same arithmetic as before
+    for xdw in (0, 1):
+        old_xdw = ops.XDW
+        ops.XDW = xdw
+        try:
+            _recompute_mode_sweep(model, lossf, batch, base=0 if not xdw else 1)
+        finally:
+            ops.XDW = old_xdw
+
+
+def _recompute_mode_sweep(model, lossf, batch, base):
+    res = {}
     for mode in (0, 1, 3, 2, 4):
         model.image_encoder.set_recompute(mode)
         assert {blk.recompute for blk in model.image_encoder._blocks} == ({mode} if mode != 3 else {1, 2})
@@ -545,11 +563,24 @@ def test_recompute_modes_same_gradients_less_memory():
         held = a_fwd - a_before
         res[mode] = (lv, emb, grads, held)
     for mode in (1, 2, 3, 4):
-        assert res[mode][0] == res[0][0]
-        assert torch.equal(res[mode][1], res[0][1])
-        assert res[mode][2].keys() == res[0][2].keys()
-        for n, g in res[0][2].items():
+        assert res[mode][0] == res[base][0]
+        assert torch.equal(res[mode][1], res[base][1])
+        assert res[mode][2].keys() == res[base][2].keys()
+        for n, g in res[base][2].items():
             assert relerr(res[mode][2][n], g) < 5e-3, (mode, n, relerr(res[mode][2][n], g))
+    if base != 0:
+        # fused forward (modes >= 1) against the two-launch forward (mode 0): same function, one 16-bit rounding fewer
+        cosv = float(torch.nn.functional.cosine_similarity(res[1][1].float(), res[0][1].float(), dim=1).min())
+        dots = [0.0, 0.0, 0.0]
+        for n, g in res[0][2].items():
+            a_, b_ = g.double().reshape(-1), res[1][2][n].double().reshape(-1)
+            dots[0] += float(a_ @ b_); dots[1] += float(a_ @ a_); dots[2] += float(b_ @ b_)
+        gcos = dots[0] / (dots[1] * dots[2]) ** 0.5
+        print(f"fused vs two-launch forward: |dloss| {abs(res[1][0] - res[0][0]):.2e}, min embedding cosine {cosv:.6f}, gradient cosine {gcos:.5f}")
+        # (sanity bounds only: this fixture's maps shrink to 2 x 2 pixels, BatchNorm over 8-16 samples amplifies the one
+        # 16-bit rounding the two forms differ by -- measured 0.10 / 0.988 / 0.80; the production-shape comparison with tight
+        # bounds is tests/test_fullsize_gpu.py)
+        assert abs(res[1][0] - res[0][0]) < 0.3 and cosv > 0.95 and gcos > 0.6
     print("graph bytes held after forward by mode:", {m: res[m][3] for m in res})
     # (the text encoder's share of the graph is the same in every mode; since round 3 it includes the kept GELU outputs)
     assert res[1][3] < 0.85 * res[0][3] and res[2][3] < 0.6 * res[0][3] and res[4][3] < res[2][3] < res[3][3] < res[1][3], \
@@ -746,7 +777,9 @@ def test_side_stream_views_with_converted_input_dtypes():
               "text_tokens2": {kk: v.to(DEV) for kk, v in batch["text_tokens2"].items()}}
         with torch.no_grad():
             out = model(bt, DEV)
-        assert len(seen) == 2 and torch.equal(out["image_embeddings"], model(bt, DEV)["image_embeddings"])
+            assert len(seen) == 2
+            h.remove()
+            assert torch.equal(out["image_embeddings"], model(bt, DEV)["image_embeddings"])        # (forward_pair again)
     finally:
         h.remove()
 
@@ -782,5 +815,6 @@ def test_micro_batch_batchnorm_statistics_deviation_is_bounded():
     dl = abs(losses[0] - losses[1])
     cos = float(torch.nn.functional.cosine_similarity(embs[0], embs[1], dim=1).min())
     print(f"micro-batch BN statistics (4 x 4 pairs vs 16 pairs): loss {losses[1]:.5f} vs {losses[0]:.5f}, |d| = {dl:.2e}, min embedding cosine {cos:.5f}")
-    # measured on MI355X (random-init weights, N(0,1) images): see DESIGN.md section 8; the bound is 3 x the measured value
-    assert dl < 0.15 and cos > 0.90, (losses, cos)
+    # measured on MI355X (random-init weights, N(0,1) images): |d loss| = 4.6e-3 of 6.93, min embedding cosine 0.9976 (DESIGN.md
+    # section 8); the bounds are 3 x the measured deviations
+    assert dl < 1.5e-2 and cos > 0.992, (losses, cos)
