@@ -77,6 +77,7 @@ KERNEL_NAMES = {
     "mc_dwconv_bwd_weight": "dwconv_march_bww_kernel + lane::dwconv_lane_fwd_kernel<K,S,NCOL,2> (depthwise conv weight gradient)",
     "mc_dwconv_bwd_data": "dwconv_march_bwd_s2_kernel (depthwise conv stride-2 data gradient, with the BatchNorm0+SiLU backward epilogue)",
     "mc_dwconv_bwd_fused": "lane::dwconv_lane_fwd_kernel<3,1,1,3,G> (round 5: whole stride-1 3x3 depthwise backward in one launch -- data gradient + BatchNorm0 epilogue + weight gradient from one staging of (dd, e))",
+    "mc_mbconv_xdw_fwd": "lane::dwconv_lane_fwd_kernel<K,S,NCOL,4,G,KC> (round 6: expand 1x1 conv (MFMA, weight slice in LDS) + BatchNorm0 + swish inside the staging of the depthwise forward -- the expanded tensor never reaches HBM; algorithmic bytes = block input + depthwise output)",
     "mc_xbwd_rows_bf16": "xbwd_rows_kernel (round 5: expand-conv backward, weight + data gradient from one pass over the upstream gradient, LDS transpose-reads + register-resident weight slice)",
     "mc_gemm_rows_bf16": "gemm_rows_kernel (row-streaming 1x1 conv forward / data gradient, weights resident in LDS)",
     "mc_wgrad_rows_bf16": "wgrad_rows_kernel (row-streaming 1x1 conv weight gradient, LDS transpose-reads)",
@@ -109,7 +110,8 @@ def class_key(key):
         for side in ("mfma", "hbm"):
             if ep == "mc_gemm_bf16" and kind.endswith(f"|{tag}|{side}"):
                 return f"{ep}:|{tag}|{side}"
-    if ep in ("mc_dwconv_fwd", "mc_gemm_rows_bf16", "mc_dwconv_bwd_weight", "mc_wgrad_rows_bf16", "mc_dwconv_bwd_fused", "mc_xbwd_rows_bf16"):
+    if ep in ("mc_dwconv_fwd", "mc_gemm_rows_bf16", "mc_dwconv_bwd_weight", "mc_wgrad_rows_bf16", "mc_dwconv_bwd_fused", "mc_xbwd_rows_bf16",
+              "mc_mbconv_xdw_fwd"):
         return ep
     return key
 
@@ -460,8 +462,8 @@ def main():
         ms = dt / args.steps * 1e3
         pairs = b * world * args.steps / dt
         # per-workload PMC tables: rNN_roofline_traffic_cfg4.json (the default run's launch mix) when present, else the cfg3 table
-        cands = ([os.path.join(ROOT, "profiles", f"r{r:02d}_roofline_traffic_{args.workload}.json") for r in (5, 4)] +
-                 [os.path.join(ROOT, "profiles", f"r{r:02d}_roofline_traffic.json") for r in (5, 4, 3)])
+        cands = ([os.path.join(ROOT, "profiles", f"r{r:02d}_roofline_traffic_{args.workload}.json") for r in (6, 5, 4)] +
+                 [os.path.join(ROOT, "profiles", f"r{r:02d}_roofline_traffic.json") for r in (6, 5, 4, 3)])
         tpath = next((q for q in cands if os.path.exists(q)), "")
         own_mix = tpath.endswith(f"_{args.workload}.json") or args.workload == "cfg3"
         tj = json.load(open(tpath)) if tpath and args.workload in ("cfg3", "cfg4") and not args.batch else {}

@@ -1,5 +1,6 @@
-"""no-graph train-mode forward of one 32-pair micro-batch (B5 @1520x912 + BERT T=256), N times: what the 24 + 24 extra
-forwards of the N = 1 step cost (run under rocprofv3 --kernel-trace --stats)"""
+"""no-graph train-mode forward of one 32-pair micro-batch (B5 @1520x912 + BERT T=256), N times: what the 25 graph-less first
+passes of the N = 1 headline step cost (run under rocprofv3 --kernel-trace --stats / --pmc; MC_XDW=0|1 switches the fused
+expand + depthwise forward launch of round 6, MC_STREAMS=0 puts every kernel alone on the GPU for the counter passes)"""
 import os, sys, types
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, bench
