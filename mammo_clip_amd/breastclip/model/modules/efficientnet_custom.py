@@ -304,7 +304,7 @@ class _MBConvFn(torch.autograd.Function):
         saved = {}
         rc = blk.recompute
         wkkc = ops.transpose_f32(blk._depthwise_conv.weight.view(a.cexp, k * k), cache=True)
-        xdw = False
+        xdw = efree = False
         if a.expand != 1:
             we = ops.cast_bf16(blk._expand_conv.weight.view(a.cexp, a.cin))
             # round 6: where no backward needs the expanded tensor e stored (no graph, or a recompute mode that rebuilds it), the
@@ -314,6 +314,10 @@ class _MBConvFn(torch.autograd.Function):
             # (autograd runs Function.forward with grad mode off and reports needs_input_grad from requires_grad alone:
             # whether a graph is being recorded is noted by MBConvBlock.forward before the call)
             xdw = (rc >= 1 or not blk.__dict__.get("_recording", True)) and blk.xdw_ok(n, h, w, oh, ow)
+            # ... and stride-1 3x3 blocks whose backward forms its e rows from x as well (ops.dwconv_bwd_fused with xw) and
+            # folds the BatchNorm0 backward into the expand conv's gradient GEMMs never need e anywhere: fused forward always
+            efree = blk.efree_ok(n, h, w, oh, ow)
+            xdw = xdw or efree
             if xdw:
                 part0 = ops.bn_gram_partials(x, we, n * hw) if (training and not _replaying()) else None
                 st0 = _bn_stats(part0, n * hw, blk._bn0, training)
@@ -324,7 +328,7 @@ class _MBConvFn(torch.autograd.Function):
                 e, part0 = _expand_conv(blk, x, we, n * hw, training)
                 st0 = _bn_stats(part0, n * hw, blk._bn0, training)
             dw_in, pro0 = e, (st0.scale, st0.shift)
-            saved.update(we=we, e=None if rc >= 1 else e, st0=st0)
+            saved.update(we=we, e=None if (rc >= 1 or efree) else e, st0=st0)
         else:
             # block 0 behind a linked stem: x is the stem's RAW conv output, its bn0 + swish is this block's prologue
             link = blk.__dict__.pop("_in_link", None)
@@ -366,7 +370,7 @@ class _MBConvFn(torch.autograd.Function):
         # tensor e, 2 also the depthwise output d (+ the stored activation of the late stages), 4 also the projection
         # output p; the backward rebuilds them from the block input x and the saved BatchNorm coefficients
         saved.update(x=x, d=None if rc >= 2 else d, p=None if rc >= 4 else p, wkkc=wkkc, wp=wp, st1=st1, st2=st2, pooled=pooled, gate=gate,
-                     act1=None if rc >= 2 else act1, keep_act=keep, xdw=xdw,
+                     act1=None if rc >= 2 else act1, keep_act=keep, xdw=xdw, efree=(a.expand != 1 and efree),
                      rowscale=rowscale if a.skip else None, geo=(n, h, w, oh, ow))
         ctx.blk, ctx.saved = blk, saved
         blk._out_geo = (n, oh, ow)
@@ -384,9 +388,10 @@ class _MBConvFn(torch.autograd.Function):
         x, d, p = sv["x"], sv["d"], sv["p"]
         st1, st2, gate, pooled = sv["st1"], sv["st2"], sv["gate"], sv["pooled"]
         e, act1 = sv.get("e"), sv["act1"]
+        efree = bool(sv.get("efree"))
         if a.expand != 1:
             st0 = sv["st0"]
-            if e is None:                                    # (recompute modes: same kernels, statistics epilogues off)
+            if e is None and not efree:                      # (recompute modes: same kernels, statistics epilogues off)
                 e = _expand_conv(blk, x, sv["we"], n * hw, recompute=True)
         link = sv.get("link")
         if d is None:
@@ -445,7 +450,8 @@ class _MBConvFn(torch.autograd.Function):
         # round 5: stride-1 3x3 blocks run the WHOLE depthwise backward as one launch (conv_lane.hip MODE 3): data gradient with
         # the bn0 + swish epilogue AND the weight gradient from one staging of (dd, e) -- 3 passes over the expanded tensor
         # instead of 5; where that launch is not preferred: weight gradient + data gradient as two launches
-        fused_dw = (FUSE_DW_BWD and a.expand != 1 and ops.dwconv_bwd_fused_ok(n, h, w, a.cexp, k, s, l, t, oh, ow))
+        fused_dw = (FUSE_DW_BWD and a.expand != 1 and ops.dwconv_bwd_fused_ok(n, h, w, a.cexp, k, s, l, t, oh, ow, cin=a.cin if efree else 0))
+        assert fused_dw or not efree                         # (efree_ok asked the same question in the forward)
         if not fused_dw:
             dwdw = ops.dwconv_bwd_weight(dw_in, dd, n, h, w, a.cexp, k, s, l, t, oh, ow, pro=pro0)
         grads = {}
@@ -456,12 +462,13 @@ class _MBConvFn(torch.autograd.Function):
             # forward kernel on flipped taps; stride 2, round 3: the marching super-pixel kernel -- dA0 of the stride-2
             # blocks, the largest tensors of the network, is never written)
             if fused_dw:
-                dz0, part0, dwdw = ops.dwconv_bwd_fused(dd, e, st0, wflip, n, h, w, a.cexp, k, l, t, oh, ow)
+                dz0, part0, dwdw = ops.dwconv_bwd_fused(dd, e, st0, wflip, n, h, w, a.cexp, k, l, t, oh, ow,
+                                                        xw=(x, sv["we"]) if efree else None)
             else:
                 dz0, part0 = ops.dwconv_bwd_data(dd, sv["wkkc"], n, h, w, a.cexp, k, s, l, t, oh, ow, w_kkc_flipped=wflip,
                                                  epi=(e, st0))
             del dd
-            if 2 * n * hw * a.cexp >= (BN_FOLD_MIN_BYTES if s == 1 else max(BN_FOLD_MIN_BYTES, BN_FOLD_S2_MIN_BYTES)):
+            if efree or 2 * n * hw * a.cexp >= (BN_FOLD_MIN_BYTES if s == 1 else max(BN_FOLD_MIN_BYTES, BN_FOLD_S2_MIN_BYTES)):
                 # bn0 backward is linear in (dZ0, e) and e = x We^T: it is folded into the operands of the expand conv's
                 # two gradient GEMMs (ops.bn_fold_expand_bwd) -- de is never formed, e is not read again.  Three passes
                 # over the expanded tensor against ~10 small launches and 6 passes over the (6x smaller) block input:
@@ -619,6 +626,15 @@ class MBConvBlock(nn.Module):
         a = self.args
         return (a.expand != 1 and a.cin <= XDW_MAX_CIN and not self.fp8
                 and ops.mbconv_xdw_ok(n, h, w, a.cin, a.cexp, a.k, a.s, a.pad[0], a.pad[2], oh, ow))
+
+    def efree_ok(self, n, h, w, oh, ow):
+        """may this block's expanded tensor never exist -- fused forward, fused backward with the e rows formed from the block
+        input, folded BatchNorm0 backward?  (stride-1 3x3, at most 64 input channels, the shapes on which the fused backward
+        launch is the preferred form, and enough expanded bytes for the fold to be the chosen BatchNorm0 backward)"""
+        a = self.args
+        return bool(ops.EFREE and FUSE_DW_BWD and a.k == 3 and a.s == 1 and self.training and self.xdw_ok(n, h, w, oh, ow)
+                    and 2 * n * h * w * a.cexp >= BN_FOLD_MIN_BYTES
+                    and ops.dwconv_bwd_fused_ok(n, h, w, a.cexp, a.k, a.s, a.pad[0], a.pad[2], oh, ow, cin=a.cin))
 
     def _params(self):
         """the block's Parameter objects in ``_param_names`` order (cached: ``named_parameters`` walks the module tree)"""

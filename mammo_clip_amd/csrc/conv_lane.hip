@@ -69,6 +69,9 @@ template <int K, int S, int NCOL, int G = 1> struct Cfg {
     static constexpr int PB = RB * G * IW_T;
     static constexpr int NT16 = (PB + 15) / 16;
     static constexpr int MTW = (NT16 + WAVES - 1) / WAVES;
+    // MODE 5 (fused backward, e rows from the block input): the ORB x G x TOW pixels of an e tile in 16-pixel groups
+    static constexpr int PBE = ORB * G * TOW;
+    static constexpr int MTWE = ((PBE + 15) / 16 + WAVES - 1) / WAVES;
     static_assert(RB % S == 0 && (K - 1) % S == 0, "block / tap geometry");
     static_assert(TOW <= LPI * NCOL, "a group's lanes cover its segment");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
@@ -109,9 +112,15 @@ template <int K, int S, int NCOL, int MODE, int G, int KC = 0>
 __global__ __launch_bounds__(1024, 4) void dwconv_lane_fwd_kernel(const mc_dwconv_args p, int strips, int nunits, int cpairs,
                                                                   int ctiles, int ymax, int xmap) {
     using C = Cfg<K, S, NCOL, G>;
-    constexpr bool FUSED = MODE == 3;
+    // MODE 5 (round 6): MODE 3 whose e rows -- the expand conv's output at the output positions, read for silu'(bn0(e)), the
+    // BatchNorm0 reductions and a0 = silu(bn0(e)) of the weight gradient -- are FORMED from the block input x (epi_x = x
+    // [n, oh, ow, cin], xw = the expand weight) by the MFMA staging of MODE 4 instead of being read: with MODE 4 in the forward
+    // the expanded tensor of a stride-1 3x3 block never exists in HBM, forward or backward.  The tile holds RAW e (16-bit, rounded
+    // once from the fp32 accumulators, like the tensor the expand GEMM stores): everything behind the staging is MODE 3.
+    constexpr bool XE = MODE == 5;
+    constexpr bool FUSED = MODE == 3 || XE;
     constexpr bool XF = MODE == 4;
-    static_assert(!XF || (KC >= 1 && KC <= 4), "MODE 4: cin <= 128");
+    static_assert(!(XF || XE) || (KC >= 1 && KC <= 4), "MODE 4 / 5: cin <= 128");
     constexpr bool EPI = MODE == 1 || FUSED, BWW = MODE == 2, ETILE = EPI || BWW;       // ETILE: a second global tensor staged beside the input
     static_assert(!EPI || S == 1, "the BatchNorm-backward epilogue is provided for stride 1");
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
@@ -120,7 +129,7 @@ __global__ __launch_bounds__(1024, 4) void dwconv_lane_fwd_kernel(const mc_dwcon
     uint32_t* const s_e = FUSED ? smem + 2 * C::IN_DW + 2 * C::OUT_DW : s_out;   // e / dy rows (MODE 1 / 2: they travel in the output tile)
     float* const pro_lds = reinterpret_cast<float*>(smem + 2 * C::IN_DW + (FUSED ? 4 : 2) * C::OUT_DW);   // [2][TCH]
     int* const s_desc = reinterpret_cast<int*>(pro_lds + 2 * C::TCH);                        // [NDESC][D_WORDS]
-    uint4* const s_w = reinterpret_cast<uint4*>(smem + C::LDS_BYTES / 4);                    // MODE 4: [KC][2][64] A-operand fragments
+    uint4* const s_w = reinterpret_cast<uint4*>(smem + (XE ? C::LDS_BYTES_FUSED : C::LDS_BYTES) / 4);   // MODE 4 / 5: [KC][2][64] A-operand fragments
 
     // ---- workgroup -> (channel tile, virtual-row range); the two tiles of a 128-byte line share an XCD (block id % 8)
     const int bid = blockIdx.x;
@@ -179,7 +188,7 @@ __global__ __launch_bounds__(1024, 4) void dwconv_lane_fwd_kernel(const mc_dwcon
         const float* src = tid < C::TCH ? p.pro_scale : p.pro_shift;
         pro_lds[tid] = (c0 + ch < p.c) ? src[c0 + ch] : 0.f;
     }
-    if constexpr (XF) {
+    if constexpr (XF || XE) {
         // expand weights of the tile's 32 channels as MFMA A-operand fragments: fragment (kc, f), lane (i = l & 15, kg = l >> 4) =
         // xw[c0 + f*16 + i][kc*32 + kg*8 .. +8]; zero rows / columns beyond c / cin
         for (int idx = tid; idx < KC * 2 * 64; idx += C::NT) {
@@ -267,6 +276,26 @@ __global__ __launch_bounds__(1024, 4) void dwconv_lane_fwd_kernel(const mc_dwcon
         for (int kc = 0; kc < KC; ++kc) xkok |= (kc * 32 + xkg * 8 < a_cin ? 1u : 0u) << kc;
     }
 
+    // ---- MODE 5: the lane's pixel in each of its wave's MTWE 16-pixel groups of the e tile (output positions)
+    const int e_cin = XE ? p.cin : 0;
+    unsigned emeta[XE ? C::MTWE : 1];                      // row | segment << 4 | col << 8 | LDS dword offset of the pixel << 16
+    int egoff[XE ? C::MTWE : 1];
+    unsigned ekok = 0;
+    if constexpr (XE) {
+        const int xrow = a_ow * e_cin, ximg = G > 1 ? a_oh * xrow : 0;
+#pragma unroll
+        for (int j = 0; j < C::MTWE; ++j) {
+            const int pidx = (wv * C::MTWE + j) * 16 + (x & 15);
+            const int row = pidx / (G * C::TOW), seg = (pidx % (G * C::TOW)) / C::TOW, col = pidx % C::TOW;
+            const int pos = (col % NCOL) * 64 + seg * C::LPI + col / NCOL;
+            emeta[j] = (unsigned)row | ((unsigned)seg << 4) | ((unsigned)col << 8) | ((unsigned)((row * C::TOWP + pos) * C::PXD) << 16);
+            if (pidx >= C::PBE) emeta[j] = 0xffffu;
+            egoff[j] = seg * ximg + row * xrow + col * e_cin + xkg * 8;
+        }
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) ekok |= (kc * 32 + xkg * 8 < e_cin ? 1u : 0u) << kc;
+    }
+
     // ---- block descriptors: closed form of (block index -> item, block of the item), 64 blocks at a time by the lanes
     // of wave 0.  A range is: rest of the first (image, strip) unit, whole units, head of the last unit.
     int* const s_gen = s_desc + NDESC * D_WORDS;                      // range parameters (thread 0 computes them once)
@@ -284,7 +313,7 @@ __global__ __launch_bounds__(1024, 4) void dwconv_lane_fwd_kernel(const mc_dwcon
         s_gen[G_U0] = u0; s_gen[G_U1] = u1; s_gen[G_O0] = o0; s_gen[G_O1] = o1; s_gen[G_NR0] = nr0; s_gen[G_NB0] = nb0;
         s_gen[G_NBF] = nbf; s_gen[G_NFULL] = nfull; s_gen[G_NBTOT] = nb0 + nfull * nbf + nbl;   // blocks of this workgroup
         s_gen[G_H] = a_h; s_gen[G_W] = a_w; s_gen[G_C] = a_c; s_gen[G_OH] = a_oh; s_gen[G_OW] = a_ow; s_gen[G_PT] = a_pad_t;
-        s_gen[G_PL] = a_pad_l; s_gen[G_STRIPS] = strips; s_gen[G_C0] = c0; s_gen[G_N] = a_n; s_gen[G_CIN] = a_cin;
+        s_gen[G_PL] = a_pad_l; s_gen[G_STRIPS] = strips; s_gen[G_C0] = c0; s_gen[G_N] = a_n; s_gen[G_CIN] = XE ? p.cin : a_cin;
     }
     __syncthreads();
     const int nbtot = __builtin_amdgcn_readfirstlane(s_gen[G_NBTOT]);
@@ -326,7 +355,9 @@ __global__ __launch_bounds__(1024, 4) void dwconv_lane_fwd_kernel(const mc_dwcon
         d[D_OCHI] = ochi;
         d[D_NSEG] = g_n - img < G ? g_n - img : G;                     // images of the group that exist
         if constexpr (FUSED) {                                          // the e rows of the output rows that ENTER in this block
-            const long long eb = (((long long)img * g_oh + oy0 + b * C::RB) * g_ow + ox0) * (long long)g_c + g_c0;
+            // (MODE 5: the rows are formed from the block input -- its element offset, cin channels per pixel, all of them)
+            const long long eb = XE ? (((long long)img * g_oh + oy0 + b * C::RB) * g_ow + ox0) * (long long)s_gen[G_CIN]
+                                    : (((long long)img * g_oh + oy0 + b * C::RB) * g_ow + ox0) * (long long)g_c + g_c0;
             int erhi = nrows - b * C::RB; if (erhi > C::ORB) erhi = C::ORB;
             d[D_EB_LO] = (int)(unsigned)eb; d[D_EB_HI] = (int)(eb >> 32); d[D_ERHI] = erhi;
         }
@@ -342,7 +373,8 @@ __global__ __launch_bounds__(1024, 4) void dwconv_lane_fwd_kernel(const mc_dwcon
     unsigned inb = 0;
     uint4 xf[XF ? C::MTW : 1][XF ? KC : 1];               // MODE 4: B-operand fragments of the block in flight
     unsigned xinb = 0;
-    uint4 evals[ETILE ? C::NVO : 1];
+    uint4 evals[(ETILE && !XE) ? C::NVO : 1];
+    uint4 xe[XE ? C::MTWE : 1][XE ? KC : 1];              // MODE 5: B-operand fragments of the e rows in flight
     unsigned einb = 0;
     // global -> registers for block q
     // (always executed -- `live` = the block exists: straight-line loads keep the compiler from treating the prefetch registers as
@@ -378,7 +410,21 @@ __global__ __launch_bounds__(1024, 4) void dwconv_lane_fwd_kernel(const mc_dwcon
             inb |= (ok ? 1u : 0u) << i;
         }
         }
-        if constexpr (ETILE) {                             // e rows of the output rows block q completes (MODE 3: that enter in it) / its dy rows
+        if constexpr (XE) {                                // the x pixels under the e rows that ENTER in block q
+            const long long obase = ((long long)d[D_EB_HI] << 32) | (unsigned)d[D_EB_LO];
+            const int orhi = d[D_ERHI], ochi = d[D_OCHI];
+            const bf16_t* eorg = a_epi_x + obase;
+            einb = 0;
+#pragma unroll
+            for (int j = 0; j < C::MTWE; ++j) {
+                const int row = (int)(emeta[j] & 0xfu), seg = (int)((emeta[j] >> 4) & 0xfu), col = (int)((emeta[j] >> 8) & 0xffu);
+                const bool ok = live && (emeta[j] & 0xffffu) != 0xffffu && row < orhi && col < ochi && seg < nseg;
+#pragma unroll
+                for (int kc = 0; kc < KC; ++kc)
+                    xe[j][kc] = *reinterpret_cast<const uint4*>((ok && ((ekok >> kc) & 1u)) ? eorg + egoff[j] + kc * 32 : a_epi_x);
+                einb |= (ok ? 1u : 0u) << j;
+            }
+        } else if constexpr (ETILE) {                      // e rows of the output rows block q completes (MODE 3: that enter in it) / its dy rows
             const long long obase = FUSED ? (((long long)d[D_EB_HI] << 32) | (unsigned)d[D_EB_LO]) : (((long long)d[D_OUTB_HI] << 32) | (unsigned)d[D_OUTB_LO]);
             const int orlo = FUSED ? 0 : d[D_ORLO], orhi = FUSED ? d[D_ERHI] : d[D_ORHI], ochi = d[D_OCHI];
             const bf16_t* const esrc = BWW ? a_dy : a_epi_x;
@@ -465,7 +511,28 @@ __global__ __launch_bounds__(1024, 4) void dwconv_lane_fwd_kernel(const mc_dwcon
         }
     };
     auto estore = [&](int buf) {                           // EPI / BWW: the e / dy rows of the block just loaded, into its output slots
-        if constexpr (ETILE) {
+        if constexpr (XE) {
+            uint32_t* dst = s_e + buf * C::OUT_DW;
+#pragma unroll
+            for (int j = 0; j < C::MTWE; ++j) {
+                f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kc = 0; kc < KC; ++kc) {
+                    uint4 xv = xe[j][kc];
+                    if (!((ekok >> kc) & 1u)) xv = make_uint4(0u, 0u, 0u, 0u);
+                    const bf16x8_t b = __builtin_bit_cast(bf16x8_t, xv);
+                    acc0 = MC_MFMA_16x16x32(__builtin_bit_cast(bf16x8_t, s_w[(kc * 2 + 0) * 64 + x]), b, acc0, 0, 0, 0);
+                    acc1 = MC_MFMA_16x16x32(__builtin_bit_cast(bf16x8_t, s_w[(kc * 2 + 1) * 64 + x]), b, acc1, 0, 0, 0);
+                }
+                if ((emeta[j] & 0xffffu) != 0xffffu) {
+                    // raw e of channels f*16 + kg*4 .. +3 (f = 0, 1) of pixel lane & 15; rows / columns that do not exist: zero
+                    const uint32_t keep = ((einb >> j) & 1u) ? 0xffffffffu : 0u;
+                    uint32_t* dd = dst + (emeta[j] >> 16) + xkg * 2;
+                    dd[0] = pack_bf2(acc0[0], acc0[1]) & keep; dd[1] = pack_bf2(acc0[2], acc0[3]) & keep;
+                    dd[8] = pack_bf2(acc1[0], acc1[1]) & keep; dd[9] = pack_bf2(acc1[2], acc1[3]) & keep;
+                }
+            }
+        } else if constexpr (ETILE) {
             uint32_t* dst = s_e + buf * C::OUT_DW;
 #pragma unroll
             for (int i = 0; i < C::NVO; ++i) {
@@ -757,7 +824,7 @@ template <typename C> Plan plan(const mc_dwconv_args& p) {
 template <typename C, int MODE, int KC = 0> int launch(const mc_dwconv_args& p, hipStream_t st) {
     static unsigned long long attr_done = 0;
     auto kern = dwconv_lane_fwd_kernel<C::K_, C::S_, C::NCOL_, MODE, C::G_, KC>;
-    constexpr int lds = MODE == 3 ? C::LDS_BYTES_FUSED : (MODE == 4 ? C::LDS_BYTES + KC * 2048 : C::LDS_BYTES);
+    constexpr int lds = MODE == 3 ? C::LDS_BYTES_FUSED : (MODE == 4 ? C::LDS_BYTES + KC * 2048 : (MODE == 5 ? C::LDS_BYTES_FUSED + KC * 2048 : C::LDS_BYTES));
     static_assert(lds <= 160 * 1024, "LDS budget");
     MC_SET_MAX_LDS(attr_done, kern, lds);
     const Plan m = plan<C>(p);
@@ -779,7 +846,7 @@ static bool g_fits(const mc_dwconv_args& p, int g) {
 template <int K, int S, int MODE, typename F> auto pick(const mc_dwconv_args& p, F&& f) {
     // one column per lane: stride 2; the 5x5 weight gradient (50 tap accumulators: no registers for two); the fused backward
     // (its third LDS tile -- the e rows -- does not fit beside two-column input / output tiles)
-    constexpr bool one_col = (S == 2) || (MODE == 2 && K == 5) || MODE == 3;
+    constexpr bool one_col = (S == 2) || (MODE == 2 && K == 5) || MODE == 3 || MODE == 5;
     if constexpr (one_col) {
         if (gmax1() >= 2 && p.n >= 2 && p.ow <= Cfg<K, S, 1, 2>::TOW && g_fits(p, 2)) return f(Cfg<K, S, 1, 2>{});
         return f(Cfg<K, S, 1, 1>{});
@@ -841,6 +908,8 @@ extern "C" int mc_dwconv_fwd_lane(const mc_dwconv_args* a, void* stream) {
 // 5x5 backward stays two launches (MODE 1 + MODE 2).
 extern "C" int mc_dwconv_bwd_fused_lane_supported(const mc_dwconv_args* a) {
     const mc_dwconv_args& p = *a;
+    // (round 6: xw != NULL -- epi_x is the block input x [n, oh, ow, cin] and the e rows are formed from it: cin <= 64)
+    if (p.xw && !(p.cin > 0 && p.cin % 8 == 0 && p.cin <= 64)) return 0;
     return mc_dwconv_lane_supported(a) && p.k == 3 && p.stride == 1 && p.epi_x != nullptr;
 }
 
@@ -858,6 +927,14 @@ extern "C" int mc_dwconv_bwd_fused_lane(const mc_dwconv_args* a, void* stream) {
     MC_CHECK(!p.pro_scale, "dwconv_bwd_fused: dd carries no prologue");
     MC_CHECK(!(p.stat_rows > 0) || p.stat_rows == mc_dwconv_bwd_fused_lane_stat_rows(a), "dwconv_bwd_fused: stat_partials was sized for another configuration");
     hipStream_t st = (hipStream_t)stream;
+    if (p.xw) {
+        MC_CHECK(mc_aligned16(p.epi_x) && mc_aligned16(p.xw), "dwconv_bwd_fused (e from the block input): x / xw must be 16-byte aligned");
+        return lane::pick<3, 1, 5>(p, [&](auto cfg) {
+            using Cf = decltype(cfg);
+            if (p.cin <= 32) return lane::launch<Cf, 5, 1>(p, st);
+            return lane::launch<Cf, 5, 2>(p, st);
+        });
+    }
     return lane::pick<3, 1, 3>(p, [&](auto cfg) { return lane::launch<decltype(cfg), 3>(p, st); });
 }
 

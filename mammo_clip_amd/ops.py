@@ -670,51 +670,64 @@ def _dwconv_bwd_data_impl(dy, w_kkc, n, h, w, c, k, stride, pad_l, pad_t, oh, ow
     return dx if epi is None else (dx, part)
 
 
-def _dw_fused_args(dd, w_kkc_flipped, n, h, w, c, k, pad_l, pad_t, oh, ow, e, st):
+def _dw_fused_args(dd, w_kkc_flipped, n, h, w, c, k, pad_l, pad_t, oh, ow, e, st, xw=None):
     """argument block of the fused stride-1 backward = the data-gradient launch on flipped taps: the conv's OUTPUT geometry
-    (oh, ow) is this launch's input geometry"""
+    (oh, ow) is this launch's input geometry.  xw = (x, we) (round 6): the e rows are formed from the block input x [n*h*w, cin]
+    and the expand weight we [c, cin] inside the launch -- e is not read (and need not exist)"""
     a = _dw_args(n, oh, ow, c, k, 1, k - 1 - pad_l, k - 1 - pad_t, h, w)
     a.x, a.w_kkc = _p(dd), _p(w_kkc_flipped)
     a.epi_x, a.epi_scale, a.epi_shift, a.epi_mean, a.epi_invstd = _p(e), _p(st.scale), _p(st.shift), _p(st.mean), _p(st.invstd)
+    if xw is not None:
+        x, we = xw
+        assert x.is_contiguous() and we.is_contiguous() and we.shape == (c, x.shape[1])
+        a.epi_x, a.xw, a.cin = _p(x), _p(we), x.shape[1]
     return a
 
 
 _FUSED_OK = {}
 
 
-def dwconv_bwd_fused_ok(n, h, w, c, k, stride, pad_l, pad_t, oh, ow, force=False):
+def dwconv_bwd_fused_ok(n, h, w, c, k, stride, pad_l, pad_t, oh, ow, force=False, cin=0):
     """does the fused backward launch (mc_dwconv_bwd_fused) take / win this stride-1 conv?  (pointers are not looked at; the
     answer is a function of the geometry alone and is cached: the launch-bound configurations notice every ctypes call)"""
     if stride != 1:
         return False
-    key = (n, h, w, c, k, pad_l, pad_t, oh, ow, force)
+    key = (n, h, w, c, k, pad_l, pad_t, oh, ow, force, cin)
     hit = _FUSED_OK.get(key)
     if hit is None:
         a = _dw_args(n, oh, ow, c, k, 1, k - 1 - pad_l, k - 1 - pad_t, h, w)
         a.epi_x = 16                                    # any non-null value: only looked at
+        if cin:                                         # (cin > 0: the form whose e rows are formed from the block input)
+            a.xw, a.cin = 16, cin
         lib_ = L.load()
         hit = _FUSED_OK[key] = bool(lib_.mc_dwconv_bwd_fused_supported(C.byref(a)) if force else lib_.mc_dwconv_bwd_fused_preferred(C.byref(a)))
     return hit
 
 
-def dwconv_bwd_fused(dd, e, st, w_kkc_flipped, n, h, w, c, k, pad_l, pad_t, oh, ow):
+def dwconv_bwd_fused(dd, e, st, w_kkc_flipped, n, h, w, c, k, pad_l, pad_t, oh, ow, xw=None):
     """Whole backward of a stride-1 depthwise conv y = dw(silu(bn0(e))) in one launch (conv_lane.hip MODE 3):
     returns (dZ0 [n*h*w, c] bf16 = dL/d bn0(e), BatchNorm0-backward partials [rows, 2, c], dW [k*k, c] f32 in the conv's own
     tap order).  dd = dL/dy [n*oh*ow, c]; e = the expand conv's output [n*h*w, c]; st = its BatchNorm statistics."""
-    a = _dw_fused_args(dd, w_kkc_flipped, n, h, w, c, k, pad_l, pad_t, oh, ow, e, st)
+    a = _dw_fused_args(dd, w_kkc_flipped, n, h, w, c, k, pad_l, pad_t, oh, ow, e, st, xw)
     dz = empty((n * h * w, c), BF16, dd)
     dw = torch.zeros((k * k, c), dtype=torch.float32, device=dd.device)
     rows = L.load().mc_dwconv_bwd_fused_stat_rows(C.byref(a))
     part = empty((rows, 2, c), torch.float32, dd)
     a.out, a.dw_out, a.stat_partials, a.stat_rows = _p(dz), _p(dw), _p(part), rows
-    _note(2 * n * c * (oh * ow + 2 * h * w), 4 * n * c * h * w * k * k)
-    L.call("mc_dwconv_bwd_fused", C.byref(a), _st(), kind=f"k{k}s1")
+    if xw is None:
+        _note(2 * n * c * (oh * ow + 2 * h * w), 4 * n * c * h * w * k * k)
+    else:
+        _note(2 * n * (c * (oh * ow + h * w) + xw[0].shape[1] * h * w), 4 * n * c * h * w * k * k + 2 * n * h * w * c * xw[0].shape[1])
+    L.call("mc_dwconv_bwd_fused", C.byref(a), _st(), kind=f"k{k}s1" + ("|x" if xw is not None else ""))
     return dz, part, dw
 
 
 # ---- round 6: expand 1x1 conv + BatchNorm0 + swish inside the depthwise forward launch (conv_lane.hip MODE 4): the expanded
 # tensor of an MBConv block never exists in HBM when no backward needs it stored
 XDW = int(os.environ.get("MC_XDW", "1"))      # 0 never; 1 wherever the launch is supported (developer A/B switch)
+# stride-1 3x3 blocks whose expanded tensor NEVER exists: fused forward above + fused backward with its e rows formed from the
+# block input (mc_dwconv_bwd_fused with xw) + the folded BatchNorm0 backward; 0 = off (A/B)
+EFREE = int(os.environ.get("MC_EFREE", "1"))
 _XDW_OK = {}
 
 

@@ -1361,3 +1361,46 @@ def test_bn_statistics_from_the_gram_matrix(rows, cin, c, shift):
     assert float((st.invstd.double() / invstd - 1.0).abs().max()) <= 2e-5
     assert float((rm.double() - 0.01 * mean).abs().max()) <= 1e-6 * float(mean.abs().max() + 1.0)
     assert float((rv.double() - (0.99 + 0.01 * e.var(0, unbiased=True))).abs().max()) <= 1e-5 * float(var.max() + 1.0)
+
+
+XE_CASES = [  # n, h, w, cin, c: strips (w > 62), image groups, ragged channel tiles, both K-chunk instances (cin <= 32 / 64)
+    (2, 70, 300, 40, 240), (3, 33, 59, 24, 144), (5, 95, 57, 64, 72), (33, 48, 29, 16, 96), (9, 7, 9, 8, 24), (1, 200, 62, 48, 40),
+    (2, 41, 130, 64, 384)]
+
+
+@pytest.mark.parametrize("n,h,w,cin,c", XE_CASES)
+def test_dwconv_fused_backward_with_e_rows_formed_from_the_block_input(n, h, w, cin, c):
+    """Round 6 (conv_lane.hip MODE 5): mc_dwconv_bwd_fused with xw -- the launch forms the e rows it needs (silu'(bn0(e)), the
+    BatchNorm0 reductions, a0 = silu(bn0(e)) of the weight gradient) from the block input x and the expand weight by the MFMA
+    staging of the fused forward, instead of reading e [ref: efficientnet_custom.py:104-111 backwards].  Against the same launch
+    reading e = the expand GEMM's stored output: the staged e is the same fp32 accumulation rounded once to 16 bits, so dZ0,
+    the partials and dW agree to the last-bit spread of two MFMA accumulation orders (<= 2 units of 16-bit rounding on dZ0
+    where an e value differs, which moves silu' by <= 1e-2 relative)."""
+    k, pad = 3, 1
+    x = rnd(n * h * w, cin, seed=71)
+    we = rnd(c, cin, seed=72, scale=cin ** -0.5)
+    dd = rnd(n * h * w, c, seed=73)
+    wk = rnd(k * k, c, seed=74, dtype=torch.float32)
+    gamma, beta = rnd(c, seed=75, dtype=torch.float32) * 0.2 + 1.0, rnd(c, seed=76, dtype=torch.float32) * 0.1
+    e = ops.linear_fwd(x, we)
+    ef = e.float()
+    mean, var = ef.mean(0), ef.var(0, unbiased=False)
+    st = ops.BNStats()
+    st.mean, st.invstd = mean.contiguous(), (var + 1e-3).rsqrt().contiguous()
+    st.scale = (gamma * st.invstd).contiguous()
+    st.shift = (beta - mean * st.scale).contiguous()
+    st.count = float(n * h * w)
+    wflip = wk.flip(0).contiguous()
+    assert ops.dwconv_bwd_fused_ok(n, h, w, c, k, 1, pad, pad, h, w, force=True, cin=cin)
+    dz_ref, part_ref, dw_ref = ops.dwconv_bwd_fused(dd, e, st, wflip, n, h, w, c, k, pad, pad, h, w)
+    for _ in range(2):
+        dz, part, dw = ops.dwconv_bwd_fused(dd, None, st, wflip, n, h, w, c, k, pad, pad, h, w, xw=(x, we))
+    torch.cuda.synchronize()
+    assert torch.isfinite(dz.float()).all() and torch.isfinite(dw).all()
+    frac_equal = float((dz == dz_ref).float().mean())
+    check(dz, dz_ref, 1e-2, "dZ0 (e rows from x) vs dZ0 (e read)")
+    assert frac_equal >= 0.98, frac_equal                   # almost every element bit-identical: the staged e IS the stored e
+    s0, s1 = part_ref.double().sum(0), part.double().sum(0)
+    scale = s0.abs().amax(dim=1, keepdim=True)
+    assert float(((s0 - s1).abs() / scale).max()) <= 2e-3, "BatchNorm-backward partials"
+    assert float((dw - dw_ref).abs().max()) <= 2e-3 * float(dw_ref.abs().max()), "dW"

@@ -650,7 +650,10 @@ def test_bn0_backward_folded_into_expand_gemms():
     model, lossf, sd = _build("tf_efficientnet_b5_ns-detect", "efficientnet-b5")
     batch = ow.synth_batch(b, H, W, T, seed=41)
     res = {}
-    old = enc.BN_FOLD_MIN_BYTES
+    # (ops.EFREE off: with the fold threshold at 0 the narrow-input 3x3 blocks would otherwise take the E-free path -- another
+    # forward; this test compares the two BatchNorm0 backward forms on ONE forward)
+    old, old_efree = enc.BN_FOLD_MIN_BYTES, ops.EFREE
+    ops.EFREE = 0
     try:
         for tag, thr in (("explicit", 1 << 62), ("folded", 0)):
             enc.BN_FOLD_MIN_BYTES = thr
@@ -660,6 +663,7 @@ def test_bn0_backward_folded_into_expand_gemms():
             res[tag] = (float(ld["total"]), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None})
     finally:
         enc.BN_FOLD_MIN_BYTES = old
+        ops.EFREE = old_efree
     assert res["explicit"][0] == res["folded"][0]
     # Some parameters have a mathematically ZERO gradient (the _bn2.bias of a block whose output only reaches BatchNorm'd
     # convolutions: a per-channel constant is removed by the next bn0) -- what either path computes for them is rounding
