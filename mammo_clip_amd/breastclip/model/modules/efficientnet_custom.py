@@ -318,8 +318,18 @@ class _MBConvFn(torch.autograd.Function):
             # folds the BatchNorm0 backward into the expand conv's gradient GEMMs never need e anywhere: fused forward always
             efree = blk.efree_ok(n, h, w, oh, ow)
             xdw = xdw or efree
+            gram = None
             if xdw:
-                part0 = ops.bn_gram_partials(x, we, n * hw) if (training and not _replaying()) else None
+                # x^T x and colsum(x) of the Gram statistics pass are what the folded BatchNorm0 backward of this block needs
+                # again: they stay in the graph (a few KB) and travel on the statistics tape to the re-forward's backward
+                if training and _replaying():
+                    part0, gram = None, _TAPE.get()
+                elif training:
+                    part0, gram = ops.bn_gram_partials(x, we, n * hw)
+                    if _TAPE is not None:
+                        _TAPE.put(gram)
+                else:
+                    part0 = None
                 st0 = _bn_stats(part0, n * hw, blk._bn0, training)
                 e = None
                 d, part1 = _conv_stats(ops.mbconv_xdw_fwd, training, x, we, (st0.scale, st0.shift), wkkc, n, h, w, a.cexp, k, s,
@@ -328,7 +338,7 @@ class _MBConvFn(torch.autograd.Function):
                 e, part0 = _expand_conv(blk, x, we, n * hw, training)
                 st0 = _bn_stats(part0, n * hw, blk._bn0, training)
             dw_in, pro0 = e, (st0.scale, st0.shift)
-            saved.update(we=we, e=None if (rc >= 1 or efree) else e, st0=st0)
+            saved.update(we=we, e=None if (rc >= 1 or efree) else e, st0=st0, gram=gram)
         else:
             # block 0 behind a linked stem: x is the stem's RAW conv output, its bn0 + swish is this block's prologue
             link = blk.__dict__.pop("_in_link", None)
@@ -477,7 +487,7 @@ class _MBConvFn(torch.autograd.Function):
                 del e, dw_in
                 coef0, dg0, db0 = ops.bn_bwd_coefs(part0, n * hw, st0, blk._bn0.weight)
                 dx, dwe = ops.bn_fold_expand_bwd(dz0, x, blk._expand_conv.weight.view(a.cexp, a.cin), sv["we"], coef0,
-                                                 db0, n * hw, residual=dy if a.skip else None)
+                                                 db0, n * hw, residual=dy if a.skip else None, gram=sv.get("gram"))
                 de = None
             else:
                 de, dg0, db0 = ops.bnact_bwd(e, n, hw, a.cexp, st0, blk._bn0.weight, 0, g=dz0, partials=part0)

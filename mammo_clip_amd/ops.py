@@ -765,13 +765,14 @@ def mbconv_xdw_fwd(x, we, pro, w_kkc, n, h, w, c, k, stride, pad_l, pad_t, oh, o
 
 def bn_gram_partials(x, we, rows):
     """BatchNorm statistics partials [2, 2, c] of e = x . we^T without e (bnfold.hip gram_partials_k): from the cin x cin Gram
-    matrix and the column sums of x -- one pass over the 6 x narrower block input instead of a statistics epilogue over e"""
+    matrix and the column sums of x -- one pass over the 6 x narrower block input instead of a statistics epilogue over e.
+    Returns (partials, (x^T x, colsum(x))): the folded BatchNorm0 backward of the same block needs the same two (bn_fold_expand_bwd)"""
     c, cin = we.shape
     xtx = linear_wgrad(x, x, tag="_xtx")
     cs = colsum(x)
     part = empty((2, 2, c), torch.float32, x)
     L.call("mc_bn_gram_partials", _p(we), we.stride(0), _p(xtx), _p(cs), float(rows), c, cin, _p(part), _st())
-    return part
+    return part, (xtx, cs)
 
 
 def _dwconv_bwd_weight_impl(x, dy, n, h, w, c, k, stride, pad_l, pad_t, oh, ow, pro=None):
@@ -935,15 +936,18 @@ def bn_bwd_coefs(partials, count, stats, gamma):
     return coef, dgamma, dbeta
 
 
-def bn_fold_expand_bwd(dz, x, we_f32, we_bf16, coef, dbeta, rows, residual=None):
+def bn_fold_expand_bwd(dz, x, we_f32, we_bf16, coef, dbeta, rows, residual=None, gram=None):
     """Backward of e = x We^T under training-mode BatchNorm, from dz = dL/d bn(e) alone (bnfold.hip): returns
     (dx [rows, cin] bf16 (+ residual), dWe [cexp, cin] fp32).  Neither e nor de is read or written: the BatchNorm
     backward's linear combination lives in the small folded operands (A.We, G = We^T diag(B) We, Sxx)."""
     n, k = we_f32.shape
     fused = xbwd_rows_ok(x.shape[0], n, k)                  # round 5: dz is read ONCE for both of its GEMMs (below)
     t1 = None if fused else linear_wgrad(dz, x)            # dz^T x   [cexp, cin]
-    xtx = linear_wgrad(x, x, tag="_xtx")                   # x^T x    [cin, cin]
-    cs = colsum(x)
+    if gram is not None:                                   # (round 6: the forward's Gram statistics pass left both behind)
+        xtx, cs = gram
+    else:
+        xtx = linear_wgrad(x, x, tag="_xtx")               # x^T x    [cin, cin]
+        cs = colsum(x)
     w1t, wb, sxx = empty((k, n), BF16, x), empty((n, k), BF16, x), empty((k, k), BF16, x)
     L.call("mc_bn_fold_prepare", _p(we_f32), _p(coef), _p(xtx), _p(cs), float(rows), n, k, _p(w1t), _p(wb), _p(sxx), _st())
     gt = linear_wgrad(we_bf16, wb, tag="_gt")              # (We^T (B.We))^T  [cin, cin] fp32

@@ -48,7 +48,7 @@ for name, k, s, h, w, cin, c, pad in SHAPES:
         print(f"{name:12s} {t_e:8.3f} {t_d:8.3f} {t_e + t_d:8.3f}   (fused launch not supported)")
         continue
     t_x = timeit(lambda: ops.mbconv_xdw_fwd(x, we, (sc, sh), wk, N, h, w, c, k, s, pad, pad, oh, ow, stats=True))
-    t_g = timeit(lambda: ops.bn_gram_partials(x, we, N * h * w))
+    t_g = timeit(lambda: ops.bn_gram_partials(x, we, N * h * w)[0])
     d = ops.mbconv_xdw_fwd(x, we, (sc, sh), wk, N, h, w, c, k, s, pad, pad, oh, ow)
     err = float((d.float() - d2.float()).abs().max() / d2.float().abs().max())
     gbs = 2 * N * (h * w * cin + oh * ow * c) / (t_x * 1e-3) / 1e9

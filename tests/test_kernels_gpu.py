@@ -1350,7 +1350,8 @@ def test_bn_statistics_from_the_gram_matrix(rows, cin, c, shift):
     whose mean dominates their spread (mean^2 >> var on many channels)."""
     x = (rnd(rows, cin, seed=61, dtype=torch.float32) + shift).to(BF)
     we = rnd(c, cin, seed=62, scale=cin ** -0.5)
-    part = ops.bn_gram_partials(x, we, rows)
+    part, (xtx, cs) = ops.bn_gram_partials(x, we, rows)
+    check(cs, x.float().sum(0), 1e-4, "colsum")
     gamma, beta = torch.ones(c, device=DEV), torch.zeros(c, device=DEV)
     rm, rv = torch.zeros(c, device=DEV), torch.ones(c, device=DEV)
     st = ops.bn_finalize(part, rows, gamma, beta, rm, rv, 0.01, 1e-3, True)
