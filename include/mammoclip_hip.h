@@ -268,7 +268,9 @@ typedef struct mc_dwconv_args {
      * the form can change between the two calls through mc_dwconv_set_lane_mode / MC_DW_LANE. */
     int stat_rows;
     /* round 6 -- mc_mbconv_xdw_fwd: the expand 1x1 conv in front of the depthwise conv, run inside its staging.  xw = the
-     * expand weight [c][cin] (16-bit, row-major, c = the depthwise conv's channels); x is then the BLOCK INPUT [n,h,w,cin]. */
+     * expand weight [c][cin] (16-bit, row-major, c = the depthwise conv's channels); x is then the BLOCK INPUT [n,h,w,cin].
+     * mc_dwconv_bwd_fused with xw != NULL: epi_x is the block input [n,oh,ow,cin] (the launch's output geometry = the conv's
+     * input geometry) and the e rows the epilogue / weight gradient need are formed from it in the staging (cin <= 64). */
     const mc_bf16* xw;
     int cin;
 } mc_dwconv_args;
@@ -293,6 +295,10 @@ int mc_dwconv_lane_supported(const mc_dwconv_args* args);
  * with mc_dwconv_bwd_fused_stat_rows() rows) plus dw_out: f32 [k*k][c], accumulated into (+=) in the conv's OWN tap order.
  * _supported: 3x3, stride 1, c % 8 == 0, epi_x given (the 5x5 form does not fit a wave's registers: see conv_lane.hip).
  * _preferred: the shapes on which this launch measured faster than the two it replaces. */
+/* Round 6: with args->xw (+ cin <= 64) the launch does not READ e: epi_x is the block input x and e = x . xw^T is formed per
+ * 16-pixel group on the MFMA unit while the rows are staged (the staging of mc_mbconv_xdw_fwd, raw e rounded once to 16 bits
+ * like the tensor the expand GEMM stores).  Together with mc_mbconv_xdw_fwd and the folded BatchNorm0 backward
+ * (mc_bn_fold_*) the expanded tensor of a stride-1 3x3 block then never exists in HBM, forward or backward. */
 int mc_dwconv_bwd_fused_supported(const mc_dwconv_args* args);
 int mc_dwconv_bwd_fused_preferred(const mc_dwconv_args* args);
 int mc_dwconv_bwd_fused_stat_rows(const mc_dwconv_args* args);

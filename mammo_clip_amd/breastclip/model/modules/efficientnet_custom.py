@@ -214,6 +214,8 @@ BN_FOLD_S2_MIN_BYTES = int(os.environ.get("MC_BN_FOLD_S2_MIN_BYTES", 0))
 # is not stored for a backward (graph-less forwards, recompute modes >= 1, eval): input widths up to this many channels
 # (measured per block shape, scripts/xdw_ab.py: the launch wins up to cin = 64; at cin = 128 it only breaks even)
 XDW_MAX_CIN = int(os.environ.get("MC_XDW_MAX_CIN", 64))
+# recompute mode 3 drops the depthwise output of the stride-1 3x3 blocks up to this many expanded channels (developer sweep)
+MODE3_MAX_CEXP = int(os.environ.get("MC_MODE3_MAX_CEXP", 1 << 30))
 
 
 class _StemFn(torch.autograd.Function):
@@ -768,7 +770,7 @@ class EfficientNet(nn.Module):
         assert mode in (0, 1, 2, 3, 4)
         for blk in self._blocks:
             a = blk.args
-            blk.recompute = int(mode) if mode != 3 else (2 if (a.k == 3 and a.s == 1 and a.expand != 1) else 1)
+            blk.recompute = int(mode) if mode != 3 else (2 if (a.k == 3 and a.s == 1 and a.expand != 1 and a.cexp <= MODE3_MAX_CEXP) else 1)
         return self
 
     def xdw_reforward_modes(self):

@@ -74,7 +74,8 @@ for key, kn in cls.items():
         # (round 4 selected by the last argument and mixed weight-gradient launches into the forward class: VERDICT r4 weak #5)
         # (round 6: a sixth argument KC = 32-channel K chunks of the fused expand conv, 0 elsewhere)
         assert len(targs) in (5, 6), name
-        return {"0": "fwd", "1": "fwd", "2": "bww", "3": "fused", "4": "xdw"}[targs[3]] == mode
+        # (MODE 5 = the fused backward whose e rows are formed from the block input: the mc_dwconv_bwd_fused entry point)
+        return {"0": "fwd", "1": "fwd", "2": "bww", "3": "fused", "4": "xdw", "5": "fused"}[targs[3]] == mode
     sel = [r for r in rows if any(match(r[0], q) for q in ((kn,) if isinstance(kn, str) else kn))]
     n = sum(r[2] for r in sel)
     if n:
