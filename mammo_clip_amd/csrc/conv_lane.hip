@@ -369,6 +369,15 @@ __global__ __launch_bounds__(1024, 4) void dwconv_lane_fwd_kernel(const mc_dwcon
     for (int i = tid; i < (FUSED ? 4 : 2) * C::OUT_DW + ((BWW || FUSED) ? 2 * C::IN_DW : 0); i += C::NT) ((BWW || FUSED) ? s_in : s_out)[i] = 0u;
     __syncthreads();                                        // pro_lds, descriptors
 
+    // MODE 4, 3x3 instances with cin <= 64 (registers to spare): the lane's A-operand fragments live in registers for the whole
+    // kernel -- the per-group weight reads were half of the staging's LDS instructions (profiles/r06_xdw_sq_counters.csv: LDS busy
+    // 0.47 against 0.35 for the plain forward)
+    constexpr bool WREG = XF && K == 3 && KC <= 2;
+    uint4 wreg[WREG ? KC : 1][2];
+    if constexpr (WREG) {
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) { wreg[kc][0] = s_w[(kc * 2 + 0) * 64 + x]; wreg[kc][1] = s_w[(kc * 2 + 1) * 64 + x]; }
+    }
     uint4 vals[XF ? 1 : C::NV];
     unsigned inb = 0;
     uint4 xf[XF ? C::MTW : 1][XF ? KC : 1];               // MODE 4: B-operand fragments of the block in flight
@@ -451,8 +460,13 @@ __global__ __launch_bounds__(1024, 4) void dwconv_lane_fwd_kernel(const mc_dwcon
                     uint4 xv = xf[j][kc];
                     if (!((xkok >> kc) & 1u)) xv = make_uint4(0u, 0u, 0u, 0u);      // (K padding: 0 * garbage must not be NaN)
                     const bf16x8_t b = __builtin_bit_cast(bf16x8_t, xv);
-                    acc0 = MC_MFMA_16x16x32(__builtin_bit_cast(bf16x8_t, s_w[(kc * 2 + 0) * 64 + x]), b, acc0, 0, 0, 0);
-                    acc1 = MC_MFMA_16x16x32(__builtin_bit_cast(bf16x8_t, s_w[(kc * 2 + 1) * 64 + x]), b, acc1, 0, 0, 0);
+                    if constexpr (WREG) {
+                        acc0 = MC_MFMA_16x16x32(__builtin_bit_cast(bf16x8_t, wreg[kc][0]), b, acc0, 0, 0, 0);
+                        acc1 = MC_MFMA_16x16x32(__builtin_bit_cast(bf16x8_t, wreg[kc][1]), b, acc1, 0, 0, 0);
+                    } else {
+                        acc0 = MC_MFMA_16x16x32(__builtin_bit_cast(bf16x8_t, s_w[(kc * 2 + 0) * 64 + x]), b, acc0, 0, 0, 0);
+                        acc1 = MC_MFMA_16x16x32(__builtin_bit_cast(bf16x8_t, s_w[(kc * 2 + 1) * 64 + x]), b, acc1, 0, 0, 0);
+                    }
                 }
                 if ((xmeta[j] & 0xffffu) != 0xffffu) {
                     // the lane holds channels f*16 + kg*4 .. +3 (f = 0, 1) of pixel lane & 15: BatchNorm0 + swish, zero padding
