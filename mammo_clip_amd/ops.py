@@ -57,6 +57,12 @@ def side_stream(i, device=None):
     st = _SIDE.get(key)
     if st is None:
         st = _SIDE[key] = torch.cuda.Stream(device=dev)
+        # Parameters are leaves made on the main stream, the chains' backward nodes produce their gradients on the side streams:
+        # autograd orders the accumulation itself, and its once-per-backward "AccumulateGrad node's stream does not match"
+        # warning describes exactly this intended arrangement.
+        quiet = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
+        if quiet is not None:
+            quiet(False)
     return st
 
 
