@@ -353,11 +353,15 @@ def main():
     timer = L.OpTimer(keys=None if args.op_profile else [k for k in raw if class_key(k) in top])
     L.TIMER = timer
     torch.cuda.reset_peak_memory_stats()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]     # per-step spread (no sync inside the region)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         ld = trainer.step(batch, args.micro_batches)
+        marks[i + 1].record()
     sync()
     dt = time.perf_counter() - t0
+    step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
     L.TIMER = None
     tmax = torch.tensor([dt], device=device, dtype=torch.float64)
     if world > 1:
@@ -523,7 +527,9 @@ def main():
                        "loss": round(loss_val, 5), "peak_hbm_gb": round(peak_gb, 1), "peak_reserved_gb": round(peak_res_gb, 1),
                        "keep_graphs": args.keep_graphs, "recompute": args.recompute, "keep_recompute": keep_recompute,
                        "stat_tapes": stat_tapes_on,
-                       "streams": streams},
+                       "streams": streams,
+                       "step_ms": {"first": round(step_ms[0], 1), "last": round(step_ms[-1], 1), "min": round(min(step_ms), 1),
+                                   "max": round(max(step_ms), 1)}},     # rank 0's steps (HIP events on the main stream, which joins the chains)
             "roofline": first, "roofline_runner_up": second, "roofline_third": third,
         }
         # the whole step against both roofs: algorithmic bytes / flops of every launch of ONE step (the survey step's tags,
