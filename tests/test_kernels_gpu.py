@@ -25,6 +25,15 @@ DEV = torch.device("cuda:0")
 BF = ops.BF16               # the 16-bit storage dtype of the loaded kernel library (bf16; f16 under MC_STORAGE=f16)
 
 
+@pytest.fixture(autouse=True)
+def _kernel_switches_on():
+    """the kernels are tested whatever the developer A/B switches of the environment say (MC_XDW / MC_EFREE = 0)"""
+    old = ops.XDW, ops.EFREE
+    ops.XDW, ops.EFREE = 1, 1
+    yield
+    ops.XDW, ops.EFREE = old
+
+
 def rnd(*shape, seed=0, scale=1.0, dtype=BF):
     g = torch.Generator(device="cpu").manual_seed(seed)
     return (torch.randn(*shape, generator=g) * scale).to(DEV).to(dtype)
