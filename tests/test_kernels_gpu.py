@@ -1414,3 +1414,15 @@ def test_dwconv_fused_backward_with_e_rows_formed_from_the_block_input(n, h, w, 
     scale = s0.abs().amax(dim=1, keepdim=True)
     assert float(((s0 - s1).abs() / scale).max()) <= 2e-3, "BatchNorm-backward partials"
     assert float((dw - dw_ref).abs().max()) <= 2e-3 * float(dw_ref.abs().max()), "dW"
+
+
+def test_fused_launches_random_geometry_screen():
+    """scripts/xdw_fuzz.py: 150 random geometries (kernel 3 / 5, stride 1 / 2 with the reference's symmetric and asymmetric static
+    paddings, 1-17 images, maps from k x k to 90 x 320, cin 8-128, c 8-384) of the fused expand + depthwise forward against the two
+    launches it replaces and fp32 torch, and of the fused backward with its e rows formed from the block input against the same
+    launch reading the stored e."""
+    import subprocess
+    import sys
+    script = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "xdw_fuzz.py")
+    r = subprocess.run([sys.executable, script, "150", "7"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and " 0 mismatches" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
